@@ -1,0 +1,98 @@
+"""Synthetic egocentric sequences in the reference's pickle schema.
+
+The real `data/` pickles and VAE checkpoints are external downloads (`README.md:25-34`), so
+tests, `bench.py` and the golden-vector script all use the workload described in SURVEY.md
+section 8(d): the mean skeleton in the camera frame plus per-joint sinusoids, 2 cm estimator
+noise, unit-peak Gaussian heat-maps (sigma 1.5 heat-map px) at the noise-free fisheye projection,
+and a camera that translates 4 mm per frame.  The dict returned by `make_sequence` has exactly
+the keys `optimizer.py:315-324` reads from `test_data.pkl`.
+"""
+import numpy as np
+
+from .camera import FisheyeCamera, DEFAULT_CALIBRATION
+from .skeleton import MEAN3D_MM, N_JOINTS
+
+HEATMAP_SIZE = 64
+FPS = 25.0
+
+
+def rest_skeleton():
+    """[15,3] metres, camera frame (z in 0.18..1.41 m in front of the head-mounted camera)."""
+    return (MEAN3D_MM.T / 1000.0).copy()
+
+
+def heatmap_coords(uv):
+    """image pixels -> heat-map pixel coordinates sampled by optimizer.py:143-147."""
+    ix = (uv[..., 0] - 128.0) * (HEATMAP_SIZE - 1) / 1024.0
+    iy = uv[..., 1] * (HEATMAP_SIZE - 1) / 1024.0
+    return ix, iy
+
+
+def gaussian_heatmaps(ix, iy, sigma=1.5, size=HEATMAP_SIZE, dtype=np.float32):
+    """[..., J] centre coordinates -> [..., size, size, J] unit-peak Gaussians (H, W, J layout)."""
+    ys = np.arange(size, dtype=np.float64)[:, None, None]
+    xs = np.arange(size, dtype=np.float64)[None, :, None]
+    d2 = (xs - ix[..., None, None, :]) ** 2 + (ys - iy[..., None, None, :]) ** 2
+    return np.exp(-d2 / (2.0 * sigma * sigma)).astype(dtype)
+
+
+N_MODES = 6
+
+
+def motion_modes():
+    """Fixed [N_MODES,15,3] unit-peak displacement fields: the synthetic body moves as a random
+    mixture of a few whole-body modes, so joint trajectories are correlated like real motion."""
+    rng = np.random.default_rng(20211011)
+    m = rng.normal(size=(N_MODES, N_JOINTS, 3))
+    # extremities move more than the torso
+    reach = np.linalg.norm(rest_skeleton() - rest_skeleton()[0], axis=1)
+    m *= (0.3 + reach / reach.max())[None, :, None]
+    return m / np.abs(m).max(axis=(1, 2), keepdims=True)
+
+
+def make_motion(n_frames, rng, amp=0.06, t0=0.0):
+    """Noise-free local poses [n,15,3]: rest skeleton + sinusoidal mixture of `motion_modes()`
+    (0.3-2 Hz at 25 fps, peak displacement <= amp metres per mode)."""
+    t = t0 + np.arange(n_frames, dtype=np.float64)[:, None] / FPS
+    freq = rng.uniform(0.3, 2.0, size=(1, N_MODES))
+    phase = rng.uniform(0.0, 2.0 * np.pi, size=(1, N_MODES))
+    a = rng.uniform(0.2 * amp, amp, size=(1, N_MODES))
+    coef = a * np.sin(2.0 * np.pi * freq * t + phase)                 # [n, N_MODES]
+    return rest_skeleton()[None] + np.einsum("nm,mjc->njc", coef, motion_modes())
+
+
+def make_cameras(n_frames, step=0.004):
+    cams = np.tile(np.eye(4, dtype=np.float64), (n_frames, 1, 1))
+    cams[:, 0, 3] = step * np.arange(n_frames)
+    return cams
+
+
+def make_sequence(n_frames=100, seed=1, camera=None, noise=0.02, sigma=1.5, with_heatmaps=True):
+    """Synthetic `test_data.pkl` content (numpy float64 poses/cams, float32 heat-maps)."""
+    cam = camera or FisheyeCamera.from_json(DEFAULT_CALIBRATION)
+    rng = np.random.default_rng(seed)
+    clean = make_motion(n_frames, rng)
+    est = clean + rng.normal(0.0, noise, size=clean.shape)
+    cams = make_cameras(n_frames)
+    homo = np.concatenate([clean, np.ones(clean.shape[:2] + (1,))], axis=-1)
+    gt_global = np.einsum("nij,nkj->nki", cams, homo)[..., :3]
+    out = {
+        "estimated_local_skeleton": [p for p in est],
+        "gt_global_skeleton": [p for p in gt_global],
+        "camera_pose_list": [c for c in cams],
+    }
+    uv = cam.project_numpy(clean.reshape(-1, 3)).reshape(n_frames, N_JOINTS, 2)
+    ix, iy = heatmap_coords(uv)
+    out["heatmap_centres"] = np.stack([ix, iy], axis=-1)          # not in the reference pickle
+    if with_heatmaps:
+        out["heatmap_list"] = [h for h in gaussian_heatmaps(ix, iy, sigma=sigma)]
+    return out
+
+
+def make_training_windows(n_windows, seq_len, seed):
+    """Smooth synthetic motion windows [n, seq_len, 45] for briefly fitting a test VAE."""
+    rng = np.random.default_rng(seed)
+    out = np.empty((n_windows, seq_len, N_JOINTS * 3), dtype=np.float32)
+    for i in range(n_windows):
+        out[i] = make_motion(seq_len, rng, t0=rng.uniform(0.0, 10.0)).reshape(seq_len, -1)
+    return out

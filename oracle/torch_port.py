@@ -1,0 +1,173 @@
+"""PyTorch-CPU port of the reference window optimiser -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+This is the `cpu_baseline` ("port") that `bench.py` times on the GPU box's host cores, and a
+second opinion for the numpy oracle: it runs the same algorithm the way the reference does --
+autograd through an `nn.Module` VAE (including the wasted weight gradients of the frozen VAE,
+BASELINE.md section 4) and the stock `torch.optim.LBFGS(lr=2, max_iter=25, strong_wolfe)`.
+It is validated against the golden vectors of the real reference in
+`tests/test_oracle_golden.py`.  Only `tests/`, `__graft_entry__.smoke()` and
+`bench.py`'s cpu_baseline leg may import it.
+
+Reference: networks/models/SeqConvVAE.py:11-140,184-189; optimizer.py:139-149,172-177,202-276;
+utils/fisheye/FishEyeCalibrated.py:96-129.
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+PARENTS = [0, 0, 1, 2, 0, 4, 5, 1, 7, 8, 9, 4, 11, 12, 13]
+
+
+def _block(conv, c_out):
+    return nn.Sequential(conv, nn.BatchNorm1d(c_out), nn.LeakyReLU())
+
+
+class MotionVAE(nn.Module):
+    """Same layer graph and state_dict keys as the reference ConvVAE (with_bone_length=False)."""
+
+    def __init__(self, latent_dim=2048, seq_len=10, hidden=(64, 64, 128, 256, 512), channels=45):
+        super().__init__()
+        self.seq_len, self.top = seq_len, hidden[-1]
+        dims = [channels] + list(hidden)
+        self.encoder = nn.Sequential(*[_block(nn.Conv1d(a, b, 3, padding=1), b) for a, b in zip(dims, dims[1:])])
+        self.fc_mu = nn.Linear(self.top * seq_len, latent_dim)
+        self.fc_var = nn.Linear(self.top * seq_len, latent_dim)
+        self.decoder_input = nn.Linear(latent_dim, self.top * seq_len)
+        rev = list(reversed(hidden))
+        self.decoder = nn.Sequential(*[_block(nn.ConvTranspose1d(a, b, 3, padding=1), b) for a, b in zip(rev, rev[1:])])
+        last = rev[-1]
+        self.final_layer = nn.Sequential(nn.ConvTranspose1d(last, last, 3, padding=1), nn.BatchNorm1d(last),
+                                         nn.LeakyReLU(), nn.Conv1d(last, channels, 3, padding=1))
+
+    def moments(self, pose):                       # pose [B,T,45]
+        h = self.encoder(pose.permute(0, 2, 1).contiguous()).flatten(1)
+        return self.fc_mu(h), self.fc_var(h)
+
+    def latent(self, pose, eps):
+        mu, logvar = self.moments(pose)
+        return eps * torch.exp(0.5 * logvar) + mu
+
+    def decode_raw(self, z):                       # -> [B,45,T]
+        h = self.decoder_input(z).view(-1, self.top, self.seq_len)
+        return self.final_layer(self.decoder(h))
+
+    def to_pose(self, z):                          # -> [B,T,15,3]
+        return self.decode_raw(z).permute(0, 2, 1).reshape(-1, self.seq_len, 15, 3)
+
+    def vae_loss(self, pose, kl_weight):
+        """sum-MSE + kl_weight * KL (SeqConvVAE.py:213-219), used to fit test weights briefly."""
+        mu, logvar = self.moments(pose)
+        z = torch.randn_like(mu) * torch.exp(0.5 * logvar) + mu
+        rec = self.decode_raw(z).permute(0, 2, 1)
+        kld = torch.mean(-0.5 * torch.sum(1 + logvar - mu ** 2 - logvar.exp(), dim=1), dim=0)
+        return F.mse_loss(rec, pose, reduction="sum") + kl_weight * kld
+
+
+def vae_from_state_dict(sd, seq_len=10):
+    sd = OrderedDict((k, torch.as_tensor(np.asarray(v)) if not torch.is_tensor(v) else v) for k, v in sd.items())
+    hidden, i = [], 0
+    while ("encoder.%d.0.weight" % i) in sd:
+        hidden.append(sd["encoder.%d.0.weight" % i].shape[0])
+        i += 1
+    net = MotionVAE(latent_dim=sd["fc_mu.weight"].shape[0], seq_len=seq_len, hidden=tuple(hidden),
+                    channels=sd["encoder.0.0.weight"].shape[1])
+    net.load_state_dict(sd)
+    return net.eval()
+
+
+def fit_vae(net, windows, steps=600, batch=64, lr=1e-3, kl_weight=0.5, seed=0):
+    """A few hundred Adam steps on synthetic motion so that decode(encode(x)) ~ x."""
+    g = torch.Generator().manual_seed(seed)
+    torch.manual_seed(seed)
+    data = torch.as_tensor(windows, dtype=torch.float32)
+    opt = torch.optim.Adam(net.parameters(), lr=lr)
+    net.train()
+    for _ in range(steps):
+        idx = torch.randint(0, data.shape[0], (batch,), generator=g)
+        opt.zero_grad()
+        net.vae_loss(data[idx], kl_weight).backward()
+        opt.step()
+    return net.eval()
+
+
+def project(poly, cx, cy, P):
+    """FishEyeCalibrated.py:96-129 on a [n,3] float32 tensor."""
+    n = torch.norm(P[:, :2], dim=1)
+    if not bool((n != 0).all()):
+        raise Exception("norm is zero!")
+    theta = torch.atan(-P[:, 2] / n)
+    rho, t_i = poly[0], 1.0
+    for c in poly[1:]:
+        t_i = t_i * theta
+        rho = rho + t_i * c
+    return torch.stack([P[:, 0] / n * rho + cx, P[:, 1] / n * rho + cy], dim=1)
+
+
+class WindowOptimizerPort:
+    """The reference's BodyPoseOptimizer restated on torch-CPU (one window per call)."""
+
+    def __init__(self, net, poly, cx, cy, mean_skeleton, lr=2, max_iter=25):
+        self.net, self.poly, self.cx, self.cy = net, [float(c) for c in poly], float(cx), float(cy)
+        s = torch.as_tensor(mean_skeleton, dtype=torch.float32).view(-1, 15, 3)
+        self.mean_bone = torch.norm(s - s[:, PARENTS], dim=-1).mean(0)
+        self.lr, self.max_iter = lr, max_iter
+        self.w = None
+
+    def set_weights(self, w3d, smooth, bone, vae, reproj):
+        self.w = (w3d, smooth, bone, vae, reproj)
+
+    def energy_parts(self, X, X0, heat):
+        T = X.shape[0]
+        e3d = torch.sum((X - X0) ** 2)
+        acc = X[:-2] - 2 * X[1:-1] + X[2:]
+        esm = torch.sum(acc ** 2)
+        ebone = torch.sum((torch.norm(X - X[:, PARENTS], dim=-1) - self.mean_bone) ** 2)
+        evae = torch.sum(X ** 2)
+        if self.w[4] == 0:
+            erep = torch.zeros(())
+        else:
+            uv = project(self.poly, self.cx, self.cy, X.reshape(-1, 3))
+            grid = torch.stack([(uv[:, 0] - 128 - 512) / 512, (uv[:, 1] - 512) / 512], dim=1).view(-1, 1, 1, 2)
+            erep = -torch.sum(F.grid_sample(heat.view(T * 15, 1, heat.shape[-2], heat.shape[-1]), grid,
+                                            align_corners=True))
+        return e3d, esm, ebone, evae, erep
+
+    def total(self, z, X0, heat):
+        e = self.energy_parts(self.net.to_pose(z)[0], X0, heat)
+        w = self.w
+        return w[0] * e[0] + w[1] * e[1] + w[2] * e[2] + w[3] * e[3] + w[4] * e[4]
+
+    def optimize(self, pose, heatmaps, eps, frozen_grads=True):
+        """pose [T,15,3], heatmaps [T,H,W,15], eps [D] -> (float32 [T,15,3], stats).
+
+        frozen_grads=True keeps the VAE parameters requiring grad as the reference does
+        (its closure back-propagates into every frozen weight)."""
+        X0 = torch.as_tensor(np.asarray(pose), dtype=torch.float32)
+        heat = None
+        if self.w[4] != 0:
+            heat = torch.as_tensor(np.asarray(heatmaps), dtype=torch.float32).permute(0, 3, 1, 2).contiguous()
+        for p in self.net.parameters():
+            p.requires_grad_(frozen_grads)
+        with torch.no_grad():
+            z0 = self.net.latent(X0.view(1, X0.shape[0], 45), torch.as_tensor(np.asarray(eps), dtype=torch.float32).view(1, -1))
+        z = nn.Parameter(z0.clone())
+        opt = torch.optim.LBFGS([z], lr=self.lr, max_iter=self.max_iter, tolerance_change=1e-6,
+                                line_search_fn="strong_wolfe")
+        trace = []
+
+        def closure():
+            opt.zero_grad()
+            loss = self.total(z, X0, heat)
+            loss.backward()
+            trace.append((float(loss), float(z.grad.abs().max())))
+            return loss
+
+        opt.step(closure)
+        st = opt.state[z]
+        with torch.no_grad():
+            out = self.net.to_pose(z)[0].numpy().astype(np.float32)
+        return out, {"n_iter": st["n_iter"], "func_evals": st["func_evals"], "trace": trace,
+                     "z0": z0.numpy()[0], "z": z.detach().numpy()[0]}
