@@ -1,0 +1,93 @@
+"""ctypes binding of libgem_hip.so (include/gem_hip.h).
+
+There is no CPU fallback: if the HIP library has not been built (`python -c "import
+__graft_entry__ as g; g.build()"`) importing the compute path raises, and every entry point that
+returns non-zero raises `GemError` with `gem_last_error()`.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "libgem_hip.so")
+
+GEM_MAX_HIDDEN, GEM_MAX_POLY, GEM_MAX_JOINTS = 8, 16, 16
+STAGE_LOCAL, STAGE_GLOBAL = 0, 1
+
+
+class GemError(RuntimeError):
+    pass
+
+
+class GemConfig(C.Structure):
+    _fields_ = [("seq_len", C.c_int32), ("n_joints", C.c_int32), ("latent_dim", C.c_int32), ("n_hidden", C.c_int32),
+                ("hidden", C.c_int32 * GEM_MAX_HIDDEN), ("heat_h", C.c_int32), ("heat_w", C.c_int32),
+                ("n_poly", C.c_int32), ("poly", C.c_double * GEM_MAX_POLY), ("cx", C.c_double), ("cy", C.c_double),
+                ("parents", C.c_int32 * GEM_MAX_JOINTS), ("max_windows", C.c_int32), ("device", C.c_int32)]
+
+
+class GemEnergyWeights(C.Structure):
+    _fields_ = [("w3d", C.c_double), ("smooth", C.c_double), ("bone", C.c_double), ("vae", C.c_double),
+                ("reproj", C.c_double)]
+
+
+class GemLbfgsOpts(C.Structure):
+    _fields_ = [("lr", C.c_double), ("max_iter", C.c_int32), ("max_eval", C.c_int32), ("history", C.c_int32),
+                ("reserved", C.c_int32), ("tol_grad", C.c_double), ("tol_change", C.c_double), ("c1", C.c_double),
+                ("c2", C.c_double), ("ls_tol_change", C.c_double)]
+
+
+class GemWindowStats(C.Structure):
+    _fields_ = [("n_iter", C.c_int32), ("func_evals", C.c_int32), ("final_loss", C.c_float), ("status", C.c_int32)]
+
+
+# name -> (restype, argtypes); every symbol include/gem_hip.h declares
+_P = C.c_void_p
+SIGNATURES = {
+    "gem_last_error": (C.c_char_p, []),
+    "gem_version": (C.c_int, []),
+    "gem_create": (C.c_int, [C.POINTER(GemConfig), C.POINTER(_P)]),
+    "gem_destroy": (None, [_P]),
+    "gem_load_vae": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P), C.POINTER(C.c_int64)]),
+    "gem_mean_bone_length": (C.c_int, [_P, _P, C.c_int, _P, _P]),
+    "gem_encode": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),
+    "gem_decode": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P]),
+    "gem_energy_grad": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, _P, C.POINTER(GemEnergyWeights), _P, _P, _P, _P, _P]),
+    "gem_optimize_stage": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, _P, C.POINTER(GemEnergyWeights),
+                                     C.POINTER(GemLbfgsOpts), _P, _P, _P]),
+    "gem_optimize_windows": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.POINTER(GemEnergyWeights),
+                                       C.POINTER(GemEnergyWeights), C.POINTER(GemLbfgsOpts), _P, _P, _P, _P]),
+    "gem_profile_enable": (C.c_int, [_P, C.c_int]),
+    "gem_profile_read": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+}
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen the HIP library and bind every declared symbol; raises GemError if it is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise GemError("HIP library %s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(there is no CPU fallback for the optimiser)" % p)
+    lib = C.CDLL(p)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)           # AttributeError here = header and library out of sync
+        fn.restype, fn.argtypes = res, args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(rc, lib=None):
+    if rc != 0:
+        msg = (lib or load_library()).gem_last_error()
+        raise GemError(msg.decode() if msg else "libgem_hip call failed")
+
+
+def default_lbfgs_opts(lr=2.0, max_iter=25, tol_change=1e-6):
+    """torch.optim.LBFGS defaults as instantiated at optimizer.py:261-262."""
+    return GemLbfgsOpts(lr=float(lr), max_iter=int(max_iter), max_eval=int(max_iter) * 5 // 4, history=100, reserved=0,
+                        tol_grad=1e-7, tol_change=float(tol_change), c1=1e-4, c2=0.9, ls_tol_change=1e-9)

@@ -1,0 +1,143 @@
+// Internal declarations shared by the HIP translation units of libgem_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/gem_hip.h"
+
+namespace gem {
+
+constexpr int PAD = 64;                    // every feature dimension is zero-padded to a multiple of 64
+constexpr float LEAKY_SLOPE = 0.01f;       // torch.nn.LeakyReLU default (SeqConvVAE.py:38,77,90)
+constexpr double BN_EPS = 1e-5;            // torch.nn.BatchNorm1d default
+constexpr int MAX_HIST = 128;              // capacity of the per-window (s,y) ring
+
+inline int pad64(int x) { return (x + PAD - 1) / PAD * PAD; }
+
+void set_error(const std::string& msg);
+bool hip_ok(hipError_t e, const char* what);
+#define GEM_HIP(call) do { if (!gem::hip_ok((call), #call)) return 1; } while (0)
+
+// epilogues of the GEMM kernel
+enum Epi { EPI_BIAS = 0, EPI_BIAS_LRELU = 1, EPI_MASK = 2, EPI_NONE = 3 };
+
+// One dense layer as the MFMA kernel sees it:  C[M,N] = epi( sum_tap shift_tap(A)[M,K] * W[tap][N][K]^T + bias ).
+struct Layer {
+    int taps = 1;          // 1 = linear, 3 = temporal conv (k=3, s=1, p=1)
+    int K = 0, N = 0;      // padded
+    float* w = nullptr;    // device, [taps][N][K], k contiguous
+    float* bias = nullptr; // device, [N] (forward layers only)
+};
+
+struct StageNet {
+    bool loaded = false;
+    std::vector<Layer> enc;        // conv blocks of the encoder (all + LeakyReLU)
+    Layer fc;                      // [mu | logvar] = flat @ W^T + b, N = 2*Dp
+    Layer dec_in;                  // decoder_input, N = T*Cp (time-major: n = t*Cp + c)
+    std::vector<Layer> dec;        // decoder convs, last one without activation
+    Layer dec_in_bwd;              // backward-data twins (no bias)
+    std::vector<Layer> dec_bwd;    // dec_bwd[i] is the adjoint of dec[i]
+    std::vector<void*> allocs;
+};
+
+// per-window scalar state of the L-BFGS / strong-Wolfe machine (doubles: torch keeps these as python
+// floats or 0-dim tensors; see lbfgs.hip)
+struct alignas(16) LbfgsState {
+    int phase, n_iter, evals, ls_iter, ls_evals, max_ls, first_bracket, ls_done, insuf, low, high;
+    int hist_count, hist_start, pad0;
+    double loss, prev_loss, t, gtd, d_norm, H_diag;
+    double t_prev, f_prev, gtd_prev;
+    double br_t[2], br_f[2], br_gtd[2];
+    double ro[MAX_HIST];
+};
+
+struct Workspace {
+    int Bmax = 0;
+    // activations, all [B*T, Cpad] float
+    float* pose_p = nullptr;            // encoder input [B*T, 64]
+    std::vector<float*> enc_act;        // outputs of the encoder convs
+    float* mulv = nullptr;              // [B, 2*Dp]
+    float* h0 = nullptr;                // [B, T*Cp_top]
+    std::vector<float*> dec_act;        // outputs of decoder convs (last = Xp [B*T, 64])
+    std::vector<float*> dec_grad;       // gradient w.r.t. the input of decoder conv i
+    float* dXp = nullptr;               // [B*T, 64]
+    float* dz = nullptr;                // [B, Dp]
+    // L-BFGS vectors, each [B, Dp]
+    float *x = nullptr, *d = nullptr, *g = nullptr, *gp = nullptr, *bg0 = nullptr, *bg1 = nullptr, *trial = nullptr;
+    float *S = nullptr, *Y = nullptr;   // [B, hist_cap, Dp]
+    int hist_cap = 0;
+    LbfgsState* state = nullptr;        // [B]
+    double* f = nullptr;                // [B] energy of the trial point
+    double* parts = nullptr;            // [B,5]
+    // pipeline scratch
+    float* pose_a = nullptr;            // [B,T,J,3] gathered local poses / stage outputs
+    float* pose_b = nullptr;
+    std::vector<void*> allocs;
+};
+
+struct Profile {
+    bool on = false;
+    struct Rec { hipEvent_t a, b; int family; double flops; };
+    std::vector<Rec> recs;
+    double total_ms[3] = {0, 0, 0};
+    int64_t n[3] = {0, 0, 0};
+    double flops[3] = {0, 0, 0};
+};
+
+}  // namespace gem
+
+struct gem_handle {
+    gem_config cfg;
+    int T, J, C, Cp, D, Dp, top, topp;
+    gem::StageNet net[2];
+    gem::Workspace ws;
+    gem::Profile prof;
+    int* d_parents = nullptr;
+    int* d_children = nullptr;     // [J][J] child lists, -1 terminated
+};
+
+namespace gem {
+
+// ---- kernel launchers (each enqueues on `s`, returns 0/1) -------------------------------------------
+int launch_gemm(gem_handle* h, const Layer& L, int epi, const float* A, int lda, const float* aux, float* Cout, int ldc,
+                int M, int T, hipStream_t s, int family);
+
+int launch_pack_pose(const float* src, float* dst, int rows, int C, hipStream_t s);      // [rows,C] -> [rows,64]
+int launch_unpack_pose(const float* src, float* dst, int rows, int C, hipStream_t s);    // [rows,64] -> [rows,C]
+int launch_reparam(const float* mulv, const float* eps, float* mu, float* logvar, float* z, float* z2, int B, int D, int Dp,
+                   hipStream_t s);
+int launch_pad_latent(const float* z, float* zp, int B, int D, int Dp, hipStream_t s);
+int launch_unpad_latent(const float* zp, float* z, int B, int D, int Dp, hipStream_t s);
+
+struct EnergyArgs {
+    const float* Xp;          // [B*T, 64] decoded pose (padded rows)
+    const float* X0;          // [B,T,J,3] stage input pose
+    const float* heat;        // [F,H,W,J] or nullptr
+    const int32_t* frame0;    // [B]
+    const float* mean_bone;   // [B,J]
+    float* dXp;               // [B*T, 64]
+    double* f;                // [B]
+    double* parts;            // [B,5]
+    float w3d, ws, wb, wv, wr;
+    double dw3d, dws, dwb, dwv, dwr;
+    int T, J, H, W, n_poly;
+    float poly[GEM_MAX_POLY];
+    float cx, cy;
+    const int* parents;
+    const int* children;
+};
+int launch_energy(gem_handle* h, const EnergyArgs& a, int B, hipStream_t s);
+int launch_mean_bone(gem_handle* h, const float* pose, int n_frames, float* out, hipStream_t s);
+int launch_gather_windows(const float* frames, const int32_t* frame0, float* out, int B, int T, int JC, hipStream_t s);
+int launch_relative_global(const float* local, const double* cams, const int32_t* frame0, float* rel, int B, int T, int J,
+                           hipStream_t s);
+int launch_to_global(const float* rel, const double* cams, const int32_t* frame0, double* out, int B, int T, int J,
+                     hipStream_t s);
+
+int launch_lbfgs_init(gem_handle* h, int B, const gem_lbfgs_opts& o, hipStream_t s);
+int launch_lbfgs_advance(gem_handle* h, int B, const gem_lbfgs_opts& o, hipStream_t s);
+int launch_lbfgs_stats(gem_handle* h, int B, gem_window_stats* out, hipStream_t s);
+
+}  // namespace gem

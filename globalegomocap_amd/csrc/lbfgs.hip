@@ -1,0 +1,465 @@
+// Batched L-BFGS with strong-Wolfe line search: one resumable state machine per window (gfx950).
+//
+// The reference runs `torch.optim.LBFGS(lr=2, max_iter=25, tolerance_change=1e-6,
+// line_search_fn='strong_wolfe').step(closure)` once per window-stage (optimizer.py:261-270).  Its
+// control flow is data dependent (bracketing / zoom phases, early exits), so here every window carries
+// its own state and all windows advance in lock-step "evaluation rounds": a round evaluates
+// (loss, dloss/dz) at every window's trial point with the batched decoder + energy kernels, then this
+// kernel consumes the evaluation and either finishes the window or emits its next trial point.
+// At most max_eval+1 rounds are needed (lbfgs.py: the line search gets max_ls = max_eval - evals and
+// uses at most max_ls+1 evaluations).
+//
+// Semantics restated from torch/optim/lbfgs.py (torch 2.10): `_cubic_interpolate`, `_strong_wolfe`
+// (c1=1e-4, c2=0.9, inner tolerance_change=1e-9), and `LBFGS.step` (first step min(1,1/|g|_1)*lr, memory
+// update only if y.s > 1e-10, H_diag = y.s/y.y, two-loop recursion, exits on max_iter, max_eval,
+// max|g| <= tol_grad, max|t d| <= tol_change, |dloss| < tol_change, g.d > -tol_change).
+// Vectors are fp32 (as the reference's tensors); scalars of the line search are fp64.
+//
+// One 256-thread workgroup per window; the D latent values are strided over the threads (coalesced),
+// dot products / max-norms are wavefront butterflies + a 4-entry LDS combine.
+#include "gem_internal.h"
+
+namespace gem {
+
+enum { PH_INIT = 0, PH_BRACKET = 1, PH_ZOOM = 2, PH_DONE = 3 };
+
+struct AdvArgs {
+    LbfgsState* state;
+    const double* f;
+    const float* gnew;
+    float *x, *d, *g, *gp, *bg0, *bg1, *trial, *S, *Y;
+    int Dp, hist_cap;
+    gem_lbfgs_opts o;
+};
+
+__device__ __forceinline__ double cubic_interpolate(double x1, double f1, double g1, double x2, double f2, double g2,
+                                                    bool has_bounds, double lo, double hi) {
+    if (!has_bounds) {
+        lo = x1 <= x2 ? x1 : x2;
+        hi = x1 <= x2 ? x2 : x1;
+    }
+    const double d1 = g1 + g2 - 3.0 * (f1 - f2) / (x1 - x2);
+    const double d2s = d1 * d1 - g1 * g2;
+    if (d2s >= 0.0) {
+        const double d2 = sqrt(d2s);
+        double m;
+        if (x1 <= x2) m = x2 - (x2 - x1) * ((g2 + d2 - d1) / (g2 - g1 + 2.0 * d2));
+        else m = x1 - (x1 - x2) * ((g1 + d2 - d1) / (g1 - g2 + 2.0 * d2));
+        // python's min(max(m, lo), hi): a NaN m propagates as `lo` would not be chosen; mirror max/min order
+        double r = (m > lo) ? m : lo;
+        if (!(m == m)) r = m;          // max(nan, lo) -> nan in python (first argument kept)
+        double q = (r < hi) ? r : hi;
+        if (!(r == r)) q = r;
+        return q;
+    }
+    return (lo + hi) / 2.0;
+}
+
+struct BlockRed {
+    double* red;
+    __device__ __forceinline__ double sum(double v) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        const double r = red[0] + red[1] + red[2] + red[3];
+        __syncthreads();
+        return r;
+    }
+    __device__ __forceinline__ double max(double v) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double w = __shfl_xor(v, o, 64);
+            v = (w > v || w != w) ? w : v;       // NaN wins, like torch's max
+        }
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        double r = red[0];
+        for (int i = 1; i < 4; ++i) r = (red[i] > r || red[i] != red[i]) ? red[i] : r;
+        __syncthreads();
+        return r;
+    }
+};
+
+template <int EPT>
+__global__ __launch_bounds__(256) void lbfgs_advance_kernel(AdvArgs a) {
+    __shared__ double red[4];
+    __shared__ double ro_s[MAX_HIST];
+    __shared__ double al_s[MAX_HIST];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    LbfgsState* sp = a.state + b;
+    int phase = sp->phase;
+    if (phase == PH_DONE) return;
+    BlockRed R{red};
+    const gem_lbfgs_opts& o = a.o;
+    const int Dp = a.Dp;
+    const size_t off = (size_t)b * Dp;
+
+    int n_iter = sp->n_iter, evals = sp->evals, ls_iter = sp->ls_iter, ls_evals = sp->ls_evals, max_ls = sp->max_ls;
+    int first_bracket = sp->first_bracket, ls_done = sp->ls_done, insuf = sp->insuf, low = sp->low, high = sp->high;
+    int hist_count = sp->hist_count, hist_start = sp->hist_start;
+    double loss = sp->loss, prev_loss = sp->prev_loss, t = sp->t, gtd = sp->gtd, d_norm = sp->d_norm, H_diag = sp->H_diag;
+    double t_prev = sp->t_prev, f_prev = sp->f_prev, gtd_prev = sp->gtd_prev;
+    double br_t[2] = {sp->br_t[0], sp->br_t[1]}, br_f[2] = {sp->br_f[0], sp->br_f[1]};
+    double br_gtd[2] = {sp->br_gtd[0], sp->br_gtd[1]};
+    for (int i = tid; i < a.hist_cap; i += 256) ro_s[i] = sp->ro[i];
+    __syncthreads();
+
+    const double f_new = a.f[b];
+    float gn[EPT], xv[EPT], dv[EPT], gcur[EPT], yv[EPT], sv[EPT];
+    bool have_x = false, have_d = false;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const int e = tid + 256 * i;
+        gn[i] = e < Dp ? a.gnew[off + e] : 0.f;
+        xv[i] = dv[i] = gcur[i] = yv[i] = sv[i] = 0.f;
+    }
+    auto load = [&](const float* p, float (&v)[EPT]) {
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) { const int e = tid + 256 * i; v[i] = e < Dp ? p[off + e] : 0.f; }
+    };
+    auto store = [&](float* p, const float (&v)[EPT]) {
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) { const int e = tid + 256 * i; if (e < Dp) p[off + e] = v[i]; }
+    };
+    auto copy = [&](float* dst, const float* src) {
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) { const int e = tid + 256 * i; if (e < Dp) dst[off + e] = src[off + e]; }
+    };
+    auto dot = [&](const float (&u)[EPT], const float (&v)[EPT]) {
+        float p = 0.f;
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) p += u[i] * v[i];
+        return R.sum((double)p);
+    };
+    auto maxabs = [&](const float (&u)[EPT], float scale) {
+        float p = 0.f;
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) { const float w = fabsf(u[i] * scale); p = (w > p || w != w) ? w : p; }
+        return R.max((double)p);
+    };
+    float* BG[2] = {a.bg0, a.bg1};
+
+    bool do_zoom_head = false, do_ls_end = false, do_start_iter = false, finished = false, emit = false;
+    bool have_ys = false;
+
+    if (phase == PH_INIT) {
+        loss = f_new;
+        evals = 1;
+        n_iter = 0;
+        store(a.g, gn);
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) gcur[i] = gn[i];
+        if (maxabs(gn, 1.f) <= o.tol_grad) finished = true;
+        else do_start_iter = true;
+    } else {
+        load(a.d, dv);
+        have_d = true;
+        const double gtd_new = dot(gn, dv);
+        if (phase == PH_BRACKET) {
+            if (!first_bracket) ls_iter++;
+            first_bracket = 0;
+            bool enter_zoom = false;
+            if (ls_iter < max_ls) {
+                const bool c1 = f_new > (loss + o.c1 * t * gtd) || (ls_iter > 1 && f_new >= f_prev);
+                const bool c2 = fabs(gtd_new) <= -o.c2 * gtd;
+                const bool c3 = gtd_new >= 0.0;
+                if (c1 || (!c2 && c3)) {
+                    br_t[0] = t_prev; br_t[1] = t;
+                    br_f[0] = f_prev; br_f[1] = f_new;
+                    br_gtd[0] = gtd_prev; br_gtd[1] = gtd_new;
+                    copy(a.bg0, a.gp);
+                    store(a.bg1, gn);
+                    ls_done = 0;
+                    enter_zoom = true;
+                } else if (c2) {
+                    br_t[0] = br_t[1] = t;
+                    br_f[0] = br_f[1] = f_new;
+                    br_gtd[0] = br_gtd[1] = gtd_new;
+                    store(a.bg0, gn);
+                    ls_done = 1;
+                    enter_zoom = true;
+                } else {
+                    const double lo_b = t + 0.01 * (t - t_prev), hi_b = t * 10.0;
+                    const double t_next = cubic_interpolate(t_prev, f_prev, gtd_prev, t, f_new, gtd_new, true, lo_b, hi_b);
+                    t_prev = t; f_prev = f_new; gtd_prev = gtd_new;
+                    store(a.gp, gn);
+                    t = t_next;
+                    emit = true;
+                }
+            } else {   // ran out of line-search iterations while bracketing: bracket = [0, t]
+                br_t[0] = 0.0; br_t[1] = t;
+                br_f[0] = loss; br_f[1] = f_new;
+                br_gtd[0] = gtd; br_gtd[1] = gtd_new;
+                copy(a.bg0, a.g);
+                store(a.bg1, gn);
+                ls_done = 0;
+                enter_zoom = true;
+            }
+            if (enter_zoom) {
+                insuf = 0;
+                if (br_f[0] <= br_f[1]) { low = 0; high = 1; } else { low = 1; high = 0; }
+                do_zoom_head = true;
+            }
+        } else {   // PH_ZOOM
+            ls_iter++;
+            if (f_new > (loss + o.c1 * t * gtd) || f_new >= br_f[low]) {
+                br_t[high] = t; br_f[high] = f_new; br_gtd[high] = gtd_new;
+                store(BG[high], gn);
+                if (br_f[0] <= br_f[1]) { low = 0; high = 1; } else { low = 1; high = 0; }
+            } else {
+                if (fabs(gtd_new) <= -o.c2 * gtd) {
+                    ls_done = 1;
+                } else if (gtd_new * (br_t[high] - br_t[low]) >= 0.0) {
+                    br_t[high] = br_t[low]; br_f[high] = br_f[low]; br_gtd[high] = br_gtd[low];
+                    copy(BG[high], BG[low]);
+                }
+                br_t[low] = t; br_f[low] = f_new; br_gtd[low] = gtd_new;
+                store(BG[low], gn);
+            }
+            do_zoom_head = true;
+        }
+    }
+
+    if (do_zoom_head) {
+        if (ls_done || ls_iter >= max_ls) {
+            do_ls_end = true;
+        } else if (fabs(br_t[1] - br_t[0]) * d_norm < o.ls_tol_change) {
+            do_ls_end = true;
+        } else {
+            double tn = cubic_interpolate(br_t[0], br_f[0], br_gtd[0], br_t[1], br_f[1], br_gtd[1], false, 0.0, 0.0);
+            const double hi = br_t[0] > br_t[1] ? br_t[0] : br_t[1];
+            const double lo = br_t[0] > br_t[1] ? br_t[1] : br_t[0];
+            const double eps = 0.1 * (hi - lo);
+            const double m1 = hi - tn, m2 = tn - lo;
+            if ((m1 < m2 ? m1 : m2) < eps) {
+                if (insuf || tn >= hi || tn <= lo) {
+                    tn = (fabs(tn - hi) < fabs(tn - lo)) ? hi - eps : lo + eps;
+                    insuf = 0;
+                } else {
+                    insuf = 1;
+                }
+            } else {
+                insuf = 0;
+            }
+            t = tn;
+            phase = PH_ZOOM;
+            emit = true;
+        }
+    }
+
+    if (do_ls_end) {
+        __syncthreads();                      // bracket gradients written above are read back below
+        t = br_t[low];
+        loss = br_f[low];
+        float bl[EPT], gold[EPT];
+        load(BG[low], bl);
+        load(a.g, gold);
+        if (!have_d) { load(a.d, dv); have_d = true; }
+        load(a.x, xv);
+        have_x = true;
+        const float tf = (float)t;
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+            xv[i] = xv[i] + tf * dv[i];
+            yv[i] = bl[i] - gold[i];
+            sv[i] = dv[i] * tf;
+            gcur[i] = bl[i];
+        }
+        store(a.x, xv);
+        store(a.g, bl);
+        evals += ls_evals;
+        const double gmax = maxabs(bl, 1.f);
+        const double dmax = maxabs(sv, 1.f);
+        if (n_iter == o.max_iter || evals >= o.max_eval || gmax <= o.tol_grad || dmax <= o.tol_change ||
+            fabs(loss - prev_loss) < o.tol_change) {
+            finished = true;
+        } else {
+            do_start_iter = true;
+            have_ys = true;
+        }
+    }
+
+    if (do_start_iter) {
+        n_iter++;
+        if (n_iter == 1) {
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) dv[i] = -gcur[i];
+            H_diag = 1.0;
+        } else {
+            (void)have_ys;
+            const double ys = dot(yv, sv);
+            const int limit = o.history < a.hist_cap ? o.history : a.hist_cap;
+            if (ys > 1e-10) {
+                if (hist_count == limit) {          // shift history by one (limited memory)
+                    hist_start = (hist_start + 1) % a.hist_cap;
+                    hist_count--;
+                }
+                const int slot = (hist_start + hist_count) % a.hist_cap;
+                float* Ys = a.Y + ((size_t)b * a.hist_cap + slot) * Dp - off;
+                float* Ss = a.S + ((size_t)b * a.hist_cap + slot) * Dp - off;
+                store(Ys, yv);
+                store(Ss, sv);
+                hist_count++;
+                const double yy = dot(yv, yv);
+                H_diag = ys / yy;
+                if (tid == 0) { ro_s[slot] = 1.0 / ys; sp->ro[slot] = 1.0 / ys; }
+                __syncthreads();
+            }
+            float q[EPT];
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) q[i] = -gcur[i];
+            for (int k = hist_count - 1; k >= 0; --k) {
+                const int slot = (hist_start + k) % a.hist_cap;
+                const float* Ss = a.S + ((size_t)b * a.hist_cap + slot) * Dp - off;
+                const float* Ys = a.Y + ((size_t)b * a.hist_cap + slot) * Dp - off;
+                float sk[EPT], yk[EPT];
+                load(Ss, sk);
+                load(Ys, yk);
+                const double al = dot(sk, q) * ro_s[slot];
+                if (tid == 0) al_s[k] = al;
+                const float alf = (float)al;
+#pragma unroll
+                for (int i = 0; i < EPT; ++i) q[i] -= alf * yk[i];
+            }
+            __syncthreads();
+            const float hd = (float)H_diag;
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) q[i] *= hd;
+            for (int k = 0; k < hist_count; ++k) {
+                const int slot = (hist_start + k) % a.hist_cap;
+                const float* Ss = a.S + ((size_t)b * a.hist_cap + slot) * Dp - off;
+                const float* Ys = a.Y + ((size_t)b * a.hist_cap + slot) * Dp - off;
+                float sk[EPT], yk[EPT];
+                load(Ys, yk);
+                load(Ss, sk);
+                const double be = dot(yk, q) * ro_s[slot];
+                const float cf = (float)(al_s[k] - be);
+#pragma unroll
+                for (int i = 0; i < EPT; ++i) q[i] += cf * sk[i];
+            }
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) dv[i] = q[i];
+        }
+        have_d = true;
+        store(a.d, dv);
+        prev_loss = loss;
+        if (n_iter == 1) {
+            float p = 0.f;
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) p += fabsf(gcur[i]);
+            const double l1 = R.sum((double)p);
+            const double inv = 1.0 / l1;
+            t = (inv < 1.0 ? inv : 1.0) * o.lr;
+        } else {
+            t = o.lr;
+        }
+        gtd = dot(gcur, dv);
+        if (gtd > -o.tol_change) {
+            finished = true;
+        } else {
+            d_norm = maxabs(dv, 1.f);
+            max_ls = o.max_eval - evals;
+            ls_iter = 0;
+            ls_evals = 0;
+            t_prev = 0.0; f_prev = loss; gtd_prev = gtd;
+            store(a.gp, gcur);
+            phase = PH_BRACKET;
+            first_bracket = 1;
+            emit = true;
+        }
+    }
+
+    if (finished) {
+        phase = PH_DONE;
+        if (!have_x) load(a.x, xv);
+        store(a.trial, xv);
+    } else if (emit) {
+        if (!have_x) load(a.x, xv);
+        if (!have_d) load(a.d, dv);
+        const float tf = (float)t;
+        float tr[EPT];
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) tr[i] = xv[i] + tf * dv[i];
+        store(a.trial, tr);
+        ls_evals++;
+    }
+    if (tid == 0) {
+        sp->phase = phase; sp->n_iter = n_iter; sp->evals = evals; sp->ls_iter = ls_iter; sp->ls_evals = ls_evals;
+        sp->max_ls = max_ls; sp->first_bracket = first_bracket; sp->ls_done = ls_done; sp->insuf = insuf;
+        sp->low = low; sp->high = high; sp->hist_count = hist_count; sp->hist_start = hist_start;
+        sp->loss = loss; sp->prev_loss = prev_loss; sp->t = t; sp->gtd = gtd; sp->d_norm = d_norm; sp->H_diag = H_diag;
+        sp->t_prev = t_prev; sp->f_prev = f_prev; sp->gtd_prev = gtd_prev;
+        sp->br_t[0] = br_t[0]; sp->br_t[1] = br_t[1]; sp->br_f[0] = br_f[0]; sp->br_f[1] = br_f[1];
+        sp->br_gtd[0] = br_gtd[0]; sp->br_gtd[1] = br_gtd[1];
+    }
+}
+
+__global__ void lbfgs_init_kernel(LbfgsState* st, const float* __restrict__ trial, float* __restrict__ x, int B, int Dp) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (size_t)B * Dp) x[i] = trial[i];
+    if (i < (size_t)B) {
+        LbfgsState* s = st + i;
+        s->phase = PH_INIT; s->n_iter = 0; s->evals = 0; s->ls_iter = 0; s->ls_evals = 0; s->max_ls = 0;
+        s->first_bracket = 0; s->ls_done = 0; s->insuf = 0; s->low = 0; s->high = 1; s->hist_count = 0; s->hist_start = 0;
+        s->loss = 0; s->prev_loss = 0; s->t = 0; s->gtd = 0; s->d_norm = 0; s->H_diag = 1;
+        s->t_prev = 0; s->f_prev = 0; s->gtd_prev = 0;
+        s->br_t[0] = s->br_t[1] = 0; s->br_f[0] = s->br_f[1] = 0; s->br_gtd[0] = s->br_gtd[1] = 0;
+    }
+}
+
+__global__ void lbfgs_stats_kernel(const LbfgsState* st, gem_window_stats* out, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    out[i].n_iter = st[i].n_iter;
+    out[i].func_evals = st[i].evals;
+    out[i].final_loss = (float)st[i].loss;
+    out[i].status = st[i].phase == PH_DONE ? 1 : 0;
+}
+
+static AdvArgs make_args(gem_handle* h, const gem_lbfgs_opts& o) {
+    Workspace& w = h->ws;
+    AdvArgs a;
+    a.state = w.state; a.f = w.f; a.gnew = w.dz;
+    a.x = w.x; a.d = w.d; a.g = w.g; a.gp = w.gp; a.bg0 = w.bg0; a.bg1 = w.bg1; a.trial = w.trial; a.S = w.S; a.Y = w.Y;
+    a.Dp = h->Dp; a.hist_cap = w.hist_cap; a.o = o;
+    return a;
+}
+
+int launch_lbfgs_init(gem_handle* h, int B, const gem_lbfgs_opts& o, hipStream_t s) {
+    (void)o;
+    const size_t n = (size_t)B * h->Dp;
+    hipLaunchKernelGGL(lbfgs_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h->ws.state, h->ws.trial, h->ws.x, B,
+                       h->Dp);
+    GEM_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_lbfgs_advance(gem_handle* h, int B, const gem_lbfgs_opts& o, hipStream_t s) {
+    AdvArgs a = make_args(h, o);
+    Profile::Rec rec;
+    const bool prof = h->prof.on;
+    if (prof) {
+        GEM_HIP(hipEventCreate(&rec.a)); GEM_HIP(hipEventCreate(&rec.b));
+        rec.family = 2; rec.flops = 0;
+        GEM_HIP(hipEventRecord(rec.a, s));
+    }
+    const int ept = (h->Dp + 255) / 256;
+    if (ept <= 1) hipLaunchKernelGGL(lbfgs_advance_kernel<1>, dim3(B), dim3(256), 0, s, a);
+    else if (ept <= 2) hipLaunchKernelGGL(lbfgs_advance_kernel<2>, dim3(B), dim3(256), 0, s, a);
+    else if (ept <= 4) hipLaunchKernelGGL(lbfgs_advance_kernel<4>, dim3(B), dim3(256), 0, s, a);
+    else if (ept <= 8) hipLaunchKernelGGL(lbfgs_advance_kernel<8>, dim3(B), dim3(256), 0, s, a);
+    else if (ept <= 16) hipLaunchKernelGGL(lbfgs_advance_kernel<16>, dim3(B), dim3(256), 0, s, a);
+    else { set_error("latent_dim > 4096 is not supported by the L-BFGS kernel"); return 1; }
+    GEM_HIP(hipGetLastError());
+    if (prof) { GEM_HIP(hipEventRecord(rec.b, s)); h->prof.recs.push_back(rec); }
+    return 0;
+}
+
+int launch_lbfgs_stats(gem_handle* h, int B, gem_window_stats* out, hipStream_t s) {
+    hipLaunchKernelGGL(lbfgs_stats_kernel, dim3((B + 255) / 256), dim3(256), 0, s, h->ws.state, out, B);
+    GEM_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace gem

@@ -1,0 +1,187 @@
+"""Thin Python object over the C ABI: owns one `gem_handle`, hands torch device pointers to it.
+
+PyTorch is used for device memory and streams only; every number of the path is produced by the
+HIP kernels behind `libgem_hip.so`.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _capi
+from .camera import FisheyeCamera, DEFAULT_CALIBRATION
+from .skeleton import KINEMATIC_PARENTS, N_JOINTS
+from .vae import VAEShape, flatten_state_dict
+
+LOCAL_STAGE, GLOBAL_STAGE = _capi.STAGE_LOCAL, _capi.STAGE_GLOBAL
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def energy_weights(w3d, smooth, bone, vae, reproj):
+    return _capi.GemEnergyWeights(float(w3d), float(smooth), float(bone), float(vae), float(reproj))
+
+
+class WindowEngine:
+    """B independent windows per call; one engine per device."""
+
+    def __init__(self, shape=None, camera=None, max_windows=256, heat_size=(64, 64), device=None):
+        self.lib = _capi.load_library()
+        if not torch.cuda.is_available():
+            raise _capi.GemError("no HIP device visible: the window optimiser has no CPU path")
+        self.shape = shape or VAEShape()
+        self.camera = camera or FisheyeCamera.from_json(DEFAULT_CALIBRATION)
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self.max_windows = int(max_windows)
+        self.heat_size = tuple(heat_size)
+        cfg = _capi.GemConfig()
+        cfg.seq_len, cfg.n_joints, cfg.latent_dim = self.shape.seq_len, N_JOINTS, self.shape.latent_dim
+        cfg.n_hidden = len(self.shape.hidden)
+        for i, v in enumerate(self.shape.hidden):
+            cfg.hidden[i] = v
+        cfg.heat_h, cfg.heat_w = self.heat_size
+        cfg.n_poly = len(self.camera.poly_w2c)
+        for i, v in enumerate(self.camera.poly_w2c):
+            cfg.poly[i] = v
+        cfg.cx, cfg.cy = self.camera.cx, self.camera.cy
+        for i, v in enumerate(KINEMATIC_PARENTS):
+            cfg.parents[i] = v
+        cfg.max_windows, cfg.device = self.max_windows, self.device.index
+        self._h = C.c_void_p()
+        _capi.check(self.lib.gem_create(C.byref(cfg), C.byref(self._h)), self.lib)
+        self.T, self.D = self.shape.seq_len, self.shape.latent_dim
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.gem_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ weights
+    def load_vae(self, stage, state_dict):
+        blobs = flatten_state_dict(state_dict, self.shape)
+        n = len(blobs)
+        ptrs = (C.c_void_p * n)(*[b.ctypes.data_as(C.c_void_p) for b in blobs])
+        sizes = (C.c_int64 * n)(*[b.size for b in blobs])
+        _capi.check(self.lib.gem_load_vae(self._h, stage, n, ptrs, sizes), self.lib)
+
+    # ------------------------------------------------------------------ helpers
+    def _f32(self, a, shape=None):
+        t = torch.as_tensor(np.asarray(a) if not torch.is_tensor(a) else a)
+        t = t.to(device=self.device, dtype=torch.float32).contiguous()
+        if shape is not None:
+            t = t.reshape(shape)
+        return t
+
+    def _i32(self, a):
+        return torch.as_tensor(np.asarray(a) if not torch.is_tensor(a) else a).to(device=self.device, dtype=torch.int32).contiguous()
+
+    def _check_B(self, B):
+        if B > self.max_windows:
+            raise ValueError("B=%d exceeds max_windows=%d of this engine" % (B, self.max_windows))
+
+    def mean_bone_length(self, poses):
+        p = self._f32(poses).reshape(-1, N_JOINTS, 3)
+        out = torch.empty(N_JOINTS, device=self.device, dtype=torch.float32)
+        _capi.check(self.lib.gem_mean_bone_length(self._h, _ptr(p), p.shape[0], _ptr(out), _stream()), self.lib)
+        return out
+
+    def encode(self, stage, pose, eps=None):
+        pose = self._f32(pose).reshape(-1, self.T, N_JOINTS * 3)
+        B = pose.shape[0]
+        self._check_B(B)
+        eps_t = self._f32(eps).reshape(B, self.D) if eps is not None else None
+        mu, lv, z = (torch.empty(B, self.D, device=self.device) for _ in range(3))
+        _capi.check(self.lib.gem_encode(self._h, stage, B, _ptr(pose), _ptr(eps_t), _ptr(mu), _ptr(lv), _ptr(z), _stream()),
+                    self.lib)
+        return mu, lv, z
+
+    def decode(self, stage, z):
+        z = self._f32(z).reshape(-1, self.D)
+        B = z.shape[0]
+        self._check_B(B)
+        out = torch.empty(B, self.T, N_JOINTS, 3, device=self.device)
+        _capi.check(self.lib.gem_decode(self._h, stage, B, _ptr(z), _ptr(out), _stream()), self.lib)
+        return out
+
+    def energy_grad(self, stage, z, pose_init, mean_bone, weights, heat=None, frame0=None):
+        z = self._f32(z).reshape(-1, self.D)
+        B = z.shape[0]
+        self._check_B(B)
+        p0 = self._f32(pose_init).reshape(B, self.T, N_JOINTS, 3)
+        mb = self._f32(mean_bone).reshape(-1, N_JOINTS).expand(B, N_JOINTS).contiguous()
+        heat_t = self._f32(heat) if heat is not None else None
+        f0 = self._i32(frame0) if frame0 is not None else None
+        E = torch.empty(B, device=self.device, dtype=torch.float64)
+        parts = torch.empty(B, 5, device=self.device, dtype=torch.float64)
+        dz = torch.empty(B, self.D, device=self.device)
+        X = torch.empty(B, self.T, N_JOINTS, 3, device=self.device)
+        _capi.check(self.lib.gem_energy_grad(self._h, stage, B, _ptr(z), _ptr(p0), _ptr(heat_t), _ptr(f0), _ptr(mb),
+                                             C.byref(weights), _ptr(E), _ptr(parts), _ptr(dz), _ptr(X), _stream()), self.lib)
+        return E, parts, dz, X
+
+    def optimize_stage(self, stage, pose_in, mean_bone, eps, weights, heat=None, frame0=None, opts=None, want_stats=True):
+        p = self._f32(pose_in).reshape(-1, self.T, N_JOINTS, 3)
+        B = p.shape[0]
+        self._check_B(B)
+        mb = self._f32(mean_bone).reshape(-1, N_JOINTS).expand(B, N_JOINTS).contiguous()
+        eps_t = self._f32(eps).reshape(B, self.D)
+        heat_t = self._f32(heat) if heat is not None else None
+        f0 = self._i32(frame0) if frame0 is not None else None
+        opts = opts or _capi.default_lbfgs_opts()
+        out = torch.empty(B, self.T, N_JOINTS, 3, device=self.device)
+        stats = torch.zeros(B, 4, device=self.device, dtype=torch.int32) if want_stats else None
+        _capi.check(self.lib.gem_optimize_stage(self._h, stage, B, _ptr(p), _ptr(heat_t), _ptr(f0), _ptr(mb), _ptr(eps_t),
+                                                C.byref(weights), C.byref(opts), _ptr(out), _ptr(stats), _stream()), self.lib)
+        return out, stats
+
+    def optimize_windows(self, local_pose, cams, heat, frame0, mean_bone, eps_local, eps_global, w_local, w_global,
+                         opts=None, want_stats=True):
+        """All tensors must already live on the device (this is the timed call of bench.py).
+
+        local_pose [F,15,3] f32, cams [F,4,4] f64, heat [F,H,W,15] f32, frame0 [B] i32, mean_bone [B,15] f32,
+        eps_* [B,D] f32 -> (mid_local [B,T,15,3] f32, global [B,T,15,3] f64, stats [2B,4] i32 or None)."""
+        B = frame0.shape[0]
+        self._check_B(B)
+        for t, dt in ((local_pose, torch.float32), (cams, torch.float64), (heat, torch.float32), (frame0, torch.int32),
+                      (mean_bone, torch.float32), (eps_local, torch.float32), (eps_global, torch.float32)):
+            if t is not None and (t.dtype != dt or not t.is_cuda or not t.is_contiguous()):
+                raise TypeError("optimize_windows wants contiguous device tensors of the documented dtypes")
+        opts = opts or _capi.default_lbfgs_opts()
+        mid = torch.empty(B, self.T, N_JOINTS, 3, device=self.device)
+        glob = torch.empty(B, self.T, N_JOINTS, 3, device=self.device, dtype=torch.float64)
+        stats = torch.zeros(2 * B, 4, device=self.device, dtype=torch.int32) if want_stats else None
+        _capi.check(self.lib.gem_optimize_windows(self._h, B, _ptr(local_pose), _ptr(cams), _ptr(heat), _ptr(frame0),
+                                                  _ptr(mean_bone), _ptr(eps_local), _ptr(eps_global), C.byref(w_local),
+                                                  C.byref(w_global), C.byref(opts), _ptr(mid), _ptr(glob), _ptr(stats),
+                                                  _stream()), self.lib)
+        return mid, glob, stats
+
+    # ------------------------------------------------------------------ profiling hook (bench.py)
+    def profile_enable(self, on):
+        _capi.check(self.lib.gem_profile_enable(self._h, 1 if on else 0), self.lib)
+
+    def profile_read(self, family):
+        ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
+        _capi.check(self.lib.gem_profile_read(self._h, family, C.byref(ms), C.byref(n), C.byref(fl)), self.lib)
+        return ms.value, n.value, fl.value
+
+
+def stats_to_numpy(stats):
+    """[n,4] int32 tensor (n_iter, func_evals, final_loss bits, status) -> structured numpy."""
+    a = stats.cpu().numpy()
+    out = np.zeros(a.shape[0], dtype=[("n_iter", "i4"), ("func_evals", "i4"), ("final_loss", "f4"), ("status", "i4")])
+    out["n_iter"], out["func_evals"], out["status"] = a[:, 0], a[:, 1], a[:, 3]
+    out["final_loss"] = a[:, 2].copy().view(np.float32)
+    return out

@@ -1,0 +1,151 @@
+/*
+ * gem_hip.h -- C ABI of the MI355X (gfx950) window optimiser for GlobalEgoMocap's hot path.
+ *
+ * The reference has no FFI of its own: its boundary for this path is two Python call signatures
+ * (optimizer.py:311-314 `main`, optimizer.py:242-276 `optimize_pose_seq_pytorch_LBFGS`) plus the
+ * checkpoint / pickle / camera-json schemas.  This header is what a Python
+ * (ctypes) binding of those two calls binds to; `globalegomocap_amd/_capi.py` is that binding and
+ * INTEGRATION.md shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every entry point returns 0 on success, non-zero on failure; `gem_last_error()` gives the text
+ *     (thread-local).  Nothing is printed, nothing aborts.
+ *   - `d_*` arguments are DEVICE pointers owned by the caller (e.g. torch tensors); the library never
+ *     frees or keeps them beyond the call.  `h_*` are host pointers.
+ *   - `stream` is a hipStream_t passed as void*; all work of a call is enqueued on it, no call
+ *     synchronises the device (except gem_create / gem_load_vae / gem_destroy, which allocate).
+ *   - one handle per device; a handle is not thread-safe; no hidden RNG (eps is an input, D5).
+ *   - windows are independent: `B` windows per call, each T frames x J joints (T=10, J=15).
+ */
+#ifndef GEM_HIP_H
+#define GEM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GEM_MAX_HIDDEN 8
+#define GEM_MAX_POLY 16
+#define GEM_MAX_JOINTS 16
+
+typedef struct gem_handle gem_handle;
+
+/* Geometry of the path.  Replaces the constructor arguments of BodyPoseOptimizer
+ * (optimizer.py:36-71), ConvVAE (networks/models/SeqConvVAE.py:11-30) and
+ * FishEyeCameraCalibrated (utils/fisheye/FishEyeCalibrated.py:7-15). */
+typedef struct gem_config {
+    int32_t seq_len;                    /* T, frames per window (10) */
+    int32_t n_joints;                   /* J (15) */
+    int32_t latent_dim;                 /* D (2048) */
+    int32_t n_hidden;                   /* number of encoder conv blocks (5) */
+    int32_t hidden[GEM_MAX_HIDDEN];     /* encoder channel widths (64,64,128,256,512) */
+    int32_t heat_h, heat_w;             /* heat-map size (64,64) */
+    int32_t n_poly;                     /* number of polynomialW2C coefficients (11 or 14) */
+    double  poly[GEM_MAX_POLY];         /* rho(theta) = sum poly[i] theta^i */
+    double  cx, cy;                     /* image centre = intrinsic[0][2], intrinsic[1][2] */
+    int32_t parents[GEM_MAX_JOINTS];    /* kinematic parents (optimizer.py:34) */
+    int32_t max_windows;                /* capacity: largest B any call will pass */
+    int32_t device;                     /* HIP device ordinal */
+} gem_config;
+
+/* Energy weights = BodyPoseOptimizer.set_weights (optimizer.py:73-79); gmm_weight is accepted by the
+ * Python mirror and ignored exactly as the reference ignores it (D4). */
+typedef struct gem_energy_weights {
+    double w3d, smooth, bone, vae, reproj;
+} gem_energy_weights;
+
+/* torch.optim.LBFGS arguments as used at optimizer.py:261-262 (+ _strong_wolfe's constants). */
+typedef struct gem_lbfgs_opts {
+    double  lr;             /* 2 */
+    int32_t max_iter;       /* 25 */
+    int32_t max_eval;       /* max_iter*5/4 = 31 */
+    int32_t history;        /* 100 (never reached: at most max_iter-1 pairs) */
+    int32_t reserved;
+    double  tol_grad;       /* 1e-7 */
+    double  tol_change;     /* 1e-6 */
+    double  c1, c2;         /* 1e-4, 0.9 */
+    double  ls_tol_change;  /* 1e-9 */
+} gem_lbfgs_opts;
+
+typedef struct gem_window_stats {
+    int32_t n_iter;         /* state['n_iter'] */
+    int32_t func_evals;     /* state['func_evals'] */
+    float   final_loss;
+    int32_t status;         /* 0 = still running (bug), 1 = finished */
+} gem_window_stats;
+
+enum { GEM_STAGE_LOCAL = 0, GEM_STAGE_GLOBAL = 1 };
+
+const char* gem_last_error(void);
+int gem_version(void);
+
+/* BodyPoseOptimizer.__init__ minus checkpoint loading. */
+int  gem_create(const gem_config* cfg, gem_handle** out);
+void gem_destroy(gem_handle* h);
+
+/* network.load_state_dict(torch.load(path)['state_dict']) (optimizer.py:59-63).  `h_blobs[i]` is the
+ * i-th float32 tensor of the state_dict in the order of globalegomocap_amd.vae.VAEShape.schema(),
+ * `n_elem[i]` its element count (checked).  BatchNorm (eval) is folded into the convolutions and the
+ * weights are re-packed for the MFMA kernels inside. */
+int gem_load_vae(gem_handle* h, int stage, int n_blobs, const float* const* h_blobs, const int64_t* n_elem);
+
+/* mean_bone_length of a chunk (optimizer.py:42-43,89-94): d_pose [n_frames,J,3] f32 -> d_out [J] f32. */
+int gem_mean_bone_length(gem_handle* h, const float* d_pose, int n_frames, float* d_out, void* stream);
+
+/* ConvVAE.get_latent_space (SeqConvVAE.py:184-189): d_pose [B,T,J*3] f32, d_eps [B,D] f32 (may be
+ * NULL: z = mu).  Any of d_mu/d_logvar/d_z may be NULL. */
+int gem_encode(gem_handle* h, int stage, int B, const float* d_pose, const float* d_eps,
+               float* d_mu, float* d_logvar, float* d_z, void* stream);
+
+/* ConvVAE.decode_to_bodypose (SeqConvVAE.py:131-140): d_z [B,D] -> d_pose [B,T,J,3] f32. */
+int gem_decode(gem_handle* h, int stage, int B, const float* d_z, float* d_pose, void* stream);
+
+/* total_loss + backward at fixed z (optimizer.py:226-240, 264-268), for parity tests:
+ * d_pose_init [B,T,J,3] f32 (the stage's input pose), d_heat [n_frames,H,W,J] f32 (pickle layout,
+ * may be NULL when reproj == 0), d_frame0 [B] int32 first frame of each window, d_mean_bone [B,J] f32.
+ * Outputs (each may be NULL): d_energy [B] f64, d_parts [B,5] f64 (E_3d,E_smooth,E_bone,E_vae,E_reproj),
+ * d_dz [B,D] f32, d_pose [B,T,J,3] f32 (decoded pose). */
+int gem_energy_grad(gem_handle* h, int stage, int B, const float* d_z, const float* d_pose_init,
+                    const float* d_heat, const int32_t* d_frame0, const float* d_mean_bone,
+                    const gem_energy_weights* w, double* d_energy, double* d_parts, float* d_dz,
+                    float* d_pose, void* stream);
+
+/* BodyPoseOptimizer.optimize_pose_seq_pytorch_LBFGS for B windows at once (optimizer.py:242-276):
+ * encode -> L-BFGS/strong-Wolfe over z through decoder + energies -> decode.
+ * d_pose_in [B,T,J,3] f32, d_eps [B,D] f32, d_pose_out [B,T,J,3] f32, d_stats [B] (may be NULL). */
+int gem_optimize_stage(gem_handle* h, int stage, int B, const float* d_pose_in, const float* d_heat,
+                       const int32_t* d_frame0, const float* d_mean_bone, const float* d_eps,
+                       const gem_energy_weights* w, const gem_lbfgs_opts* opt, float* d_pose_out,
+                       gem_window_stats* d_stats, void* stream);
+
+/* The window loop body of main() (optimizer.py:370-423) for B windows at once: local stage,
+ * relative-global transform X_rel[t] = C0^-1 C_t X_loc[t] in float64 (utils/utils.py:99-112), global
+ * stage, X_glob = C0 X_rel (optimizer.py:302-308).
+ *   d_local_pose [n_frames,J,3] f32   estimated_local_skeleton, frames stored once
+ *   d_cams       [n_frames,4,4] f64   camera_pose_list
+ *   d_heat       [n_frames,H,W,J] f32 heatmap_list
+ *   d_frame0     [B] int32            first frame of each window
+ *   d_mean_bone  [B,J] f32
+ *   d_eps_local / d_eps_global [B,D] f32
+ * Outputs: d_mid_local [B,T,J,3] f32 (stage-A result, may be NULL), d_global [B,T,J,3] f64
+ * (refined global pose), d_stats [2*B] (local stats then global stats, may be NULL). */
+int gem_optimize_windows(gem_handle* h, int B, const float* d_local_pose, const double* d_cams,
+                         const float* d_heat, const int32_t* d_frame0, const float* d_mean_bone,
+                         const float* d_eps_local, const float* d_eps_global,
+                         const gem_energy_weights* w_local, const gem_energy_weights* w_global,
+                         const gem_lbfgs_opts* opt, float* d_mid_local, double* d_global,
+                         gem_window_stats* d_stats, void* stream);
+
+/* Timing hook for bench.py's roofline: average device time (ms) of the launches of the dominant
+ * kernel family since the last reset, measured with HIP events on the launch stream.
+ * family: 0 = decoder GEMMs (forward + backward-data), 1 = energy kernel, 2 = L-BFGS advance.
+ * `gem_profile_enable(h, 1)` turns event recording on (off by default: events cost launches). */
+int gem_profile_enable(gem_handle* h, int on);
+int gem_profile_read(gem_handle* h, int family, double* total_ms, int64_t* n_launches, double* flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GEM_HIP_H */

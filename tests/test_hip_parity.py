@@ -1,0 +1,242 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the committed golden
+vectors of the reference.  Run on a MI355X with `pytest -m gpu`."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from globalegomocap_amd import synth, vae as vae_schema
+from globalegomocap_amd.camera import FisheyeCamera, DEFAULT_CALIBRATION
+from oracle import np_oracle as O
+from helpers import TINY, FULL, oracle_camera, heat_from_centres, sd_from_npz
+
+pytestmark = pytest.mark.gpu
+
+W_LOCAL = (1e-6, 1e-5, 1e-2, 0.0, 1e-2)      # (w3d, smooth, bone, vae, reproj)   optimizer.py:355-358
+W_GLOBAL = (1e-2, 1e-3, 1e-2, 0.0, 0.0)      # optimizer.py:352-353
+W_ALL = (7e-3, 2e-2, 5e-2, 3e-3, 4e-2)
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("gpu tests need a HIP device")
+    return torch
+
+
+def _engine(shape, max_windows=16):
+    from globalegomocap_amd.engine import WindowEngine
+    return WindowEngine(shape, FisheyeCamera.from_json(DEFAULT_CALIBRATION), max_windows=max_windows)
+
+
+def _ew(w):
+    from globalegomocap_amd.engine import energy_weights
+    return energy_weights(*w)
+
+
+def test_library_is_the_hip_one(torch_cuda):
+    from globalegomocap_amd import _capi
+    lib = _capi.load_library()
+    assert lib.gem_version() == 1
+    assert os.path.basename(_capi.LIB_PATH) == "libgem_hip.so"
+
+
+def test_operators_against_reference_golden(torch_cuda, golden):
+    """encode / decode / energies / dL/dz of the tiny network vs the reference's own numbers."""
+    g = golden("ops_tiny")
+    sd = vae_schema.synthetic_state_dict(TINY, int(g["weights_seed"]))
+    eng = _engine(TINY)
+    eng.load_vae(0, sd)
+    pose = g["pose"]
+    mu, logvar, z = eng.encode(0, pose.reshape(1, 10, 45))
+    np.testing.assert_allclose(mu.cpu().numpy(), g["mu"], rtol=1e-4, atol=5e-6)
+    np.testing.assert_allclose(logvar.cpu().numpy(), g["logvar"], rtol=1e-4, atol=5e-6)
+    np.testing.assert_allclose(z.cpu().numpy(), g["mu"], rtol=1e-4, atol=5e-6)       # eps=None -> z = mu
+    X = eng.decode(0, g["z"])
+    np.testing.assert_allclose(X[0].cpu().numpy(), g["X"], rtol=1e-4, atol=5e-6)
+    mb = eng.mean_bone_length(pose)
+    np.testing.assert_allclose(mb.cpu().numpy(), g["mean_bone"], rtol=1e-5, atol=1e-6)
+    heat = heat_from_centres(g["heat_centres"])
+    for tag, w in (("local", W_LOCAL), ("global", W_GLOBAL), ("allterms", W_ALL)):
+        E, parts, dz, X2 = eng.energy_grad(0, g["z"], pose[None], mb, _ew(w), heat, np.zeros(1, np.int32))
+        parts = parts.cpu().numpy()[0]
+        ref_parts = g["parts_" + tag]
+        k = 5 if w[4] != 0 else 4
+        np.testing.assert_allclose(parts[:k], ref_parts[:k], rtol=5e-5, atol=1e-7)
+        ref_tot = float(g["total_" + tag])
+        assert abs(float(E[0]) - ref_tot) <= 5e-5 * abs(ref_tot) + 1e-8
+        ref = g["dz_" + tag]
+        assert np.abs(dz.cpu().numpy() - ref).max() <= 5e-4 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("shape,seed,B", [(TINY, 11, 5), (FULL, 5, 3)])
+def test_energy_and_gradient_against_oracle(torch_cuda, shape, seed, B):
+    sd = vae_schema.synthetic_state_dict(shape, seed)
+    eng = _engine(shape, max_windows=8)
+    eng.load_vae(1, sd)
+    vae = O.fold_vae(sd)
+    cam = oracle_camera()
+    seq = synth.make_sequence(n_frames=8 * (B - 1) + 10, seed=21)
+    est = np.asarray(seq["estimated_local_skeleton"], dtype=np.float32)
+    heat = np.asarray(seq["heatmap_list"], dtype=np.float32)
+    starts = (8 * np.arange(B)).astype(np.int32)
+    pose = np.stack([est[s:s + 10] for s in starts])
+    rng = np.random.default_rng(3)
+    mu, _ = O.encode(vae, pose.reshape(B, 10, 45))
+    z = (mu + 0.1 * rng.normal(size=mu.shape)).astype(np.float32)
+    mb = O.mean_bone_length(est)
+    # make the decoded pose land on the heat-maps for one window so that the reprojection term is alive
+    for w in (W_LOCAL, W_GLOBAL, W_ALL):
+        E, parts, dz, X = eng.energy_grad(1, z, pose, mb, _ew(w), heat, starts)
+        for b in range(B):
+            Xo, acts = O.decode(vae, z[b:b + 1], keep=True)
+            f, p, dX = O.energy_and_grad(Xo[0], pose[b], mb, O.Weights(*w), cam, heat[starts[b]:starts[b] + 10])
+            dzo = O.decode_backward(vae, dX[None], acts)[0]
+            np.testing.assert_allclose(X[b].cpu().numpy(), Xo[0], rtol=2e-4, atol=2e-5)
+            np.testing.assert_allclose(parts[b].cpu().numpy(), p, rtol=2e-4, atol=1e-6)
+            assert abs(float(E[b]) - f) <= 2e-4 * abs(f) + 1e-7
+            assert np.abs(dz[b].cpu().numpy() - dzo).max() <= 2e-3 * np.abs(dzo).max() + 1e-8
+
+
+def test_reprojection_term_alive_and_edge_samples(torch_cuda):
+    """Poses placed exactly under the heat-map peaks, at the image border and outside the image."""
+    sd = vae_schema.synthetic_state_dict(TINY, 11)
+    eng = _engine(TINY)
+    eng.load_vae(0, sd)
+    vae = O.fold_vae(sd)
+    cam = oracle_camera()
+    seq = synth.make_sequence(n_frames=10, seed=5, noise=0.0)
+    pose = np.asarray(seq["estimated_local_skeleton"], dtype=np.float32)
+    heat = np.asarray(seq["heatmap_list"], dtype=np.float32)
+    z = np.zeros((1, 32), np.float32)
+    X = O.decode(vae, z)[0]
+    # heat-maps centred on the *decoded* pose so that E_reproj ~ -150 and its gradient is non-trivial
+    from globalegomocap_amd.camera import FisheyeCamera
+    uv = FisheyeCamera.from_json(DEFAULT_CALIBRATION).project_numpy(X.reshape(-1, 3).astype(np.float64)).reshape(10, 15, 2)
+    ix, iy = synth.heatmap_coords(uv)
+    heat2 = synth.gaussian_heatmaps(ix + 0.3, iy - 0.2)
+    mb = O.mean_bone_length(pose)
+    E, parts, dz, Xg = eng.energy_grad(0, z, pose[None], mb, _ew(W_ALL), heat2, np.zeros(1, np.int32))
+    f, p, dX = O.energy_and_grad(X, pose, mb, O.Weights(*W_ALL), cam, heat2)
+    assert abs(p[4]) > 1.0            # the term is alive (mostly inside the image)
+    np.testing.assert_allclose(parts[0].cpu().numpy(), p, rtol=2e-4, atol=1e-6)
+    Xo, acts = O.decode(vae, z, keep=True)
+    dzo = O.decode_backward(vae, dX[None], acts)[0]
+    assert np.abs(dz[0].cpu().numpy() - dzo).max() <= 2e-3 * np.abs(dzo).max()
+
+
+def test_lbfgs_stage_against_reference_golden(torch_cuda, golden):
+    g = golden("lbfgs_tiny")
+    pose, heat = g["pose"], heat_from_centres(g["heat_centres"])
+    for tag, prefix, w in (("local", "local/", W_LOCAL), ("global", "global/", W_GLOBAL),
+                           ("globalstrong", "global/", (1.0, 0.1, 0.01, 0.0, 0.0))):
+        eng = _engine(TINY)
+        eng.load_vae(0, sd_from_npz(g, prefix))
+        mb = eng.mean_bone_length(pose.astype(np.float32))
+        out, stats = eng.optimize_stage(0, pose[None], mb, g[tag + "_eps"][None], _ew(w), heat, np.zeros(1, np.int32))
+        st = stats.cpu().numpy()[0]
+        ref_evals = len(g[tag + "_trace"])
+        assert st[3] == 1
+        assert abs(int(st[1]) - ref_evals) <= 3, (tag, st, ref_evals)
+        err = np.linalg.norm(out[0].cpu().numpy() - g[tag + "_out"], axis=-1).mean()
+        assert err < 0.5e-3, (tag, err)              # 0.5 mm
+        loss = np.array([st[2]], dtype=np.int32).view(np.float32)[0]
+        assert abs(loss - g[tag + "_trace"].min()) <= 2e-3 * abs(g[tag + "_trace"].min()) + 1e-6
+
+
+def test_lbfgs_stage_full_size_against_oracle_and_golden(torch_cuda, golden):
+    g = golden("lbfgs_full")
+    sd = vae_schema.synthetic_state_dict(FULL, int(g["weights_seed"]))
+    eng = _engine(FULL, max_windows=4)
+    eng.load_vae(0, sd)
+    pose, heat = g["pose"], heat_from_centres(g["heat_centres"])
+    mb = eng.mean_bone_length(pose.astype(np.float32))
+    # default weights: the reference stops at its first test (g.d > -1e-6); so must we
+    for tag, w in (("local", W_LOCAL), ("global", W_GLOBAL)):
+        out, stats = eng.optimize_stage(0, pose[None], mb, g[tag + "_eps"][None], _ew(w), heat, np.zeros(1, np.int32))
+        st = stats.cpu().numpy()[0]
+        assert st[1] == 1 and st[3] == 1
+        np.testing.assert_allclose(out[0].cpu().numpy(), g[tag + "_out"], rtol=2e-3, atol=2e-5)
+    # strong weights: a long run on a random-init network is chaotic; compare the achieved loss
+    for tag, w in (("localstrong", (1e-1, 1e-1, 1.0, 1e-3, 1e-2)), ("globalstrong", (1.0, 1e-1, 1.0, 0.0, 0.0))):
+        out, stats = eng.optimize_stage(0, pose[None], mb, g[tag + "_eps"][None], _ew(w), heat, np.zeros(1, np.int32))
+        st = stats.cpu().numpy()[0]
+        loss = np.array([st[2]], dtype=np.int32).view(np.float32)[0]
+        ref = g[tag + "_trace"]
+        assert st[3] == 1 and st[1] >= 20
+        assert abs(loss - ref.min()) <= 0.05 * abs(ref.min()), (tag, loss, ref.min())
+
+
+def test_batch_is_independent_of_its_neighbours(torch_cuda, golden):
+    """A window optimised alone and inside a ragged batch gives the same result (bitwise)."""
+    g = golden("lbfgs_tiny")
+    sd = sd_from_npz(g, "local/")
+    eng = _engine(TINY, max_windows=16)
+    eng.load_vae(0, sd)
+    seq = synth.make_sequence(n_frames=58, seed=9)
+    est = np.asarray(seq["estimated_local_skeleton"], dtype=np.float32)
+    heat = np.asarray(seq["heatmap_list"], dtype=np.float32)
+    starts = np.array([0, 8, 16, 24, 32, 40, 48], np.int32)        # last window ends at the last frame
+    pose = np.stack([est[s:s + 10] for s in starts])
+    mb = eng.mean_bone_length(est)
+    rng = np.random.default_rng(1)
+    eps = rng.normal(size=(7, 32)).astype(np.float32)
+    out_all, st_all = eng.optimize_stage(0, pose, mb, eps, _ew(W_LOCAL), heat, starts)
+    out_one, st_one = eng.optimize_stage(0, pose[6:7], mb, eps[6:7], _ew(W_LOCAL), heat, starts[6:7])
+    assert np.array_equal(out_all[6].cpu().numpy(), out_one[0].cpu().numpy())
+    assert np.array_equal(st_all[6].cpu().numpy(), st_one[0].cpu().numpy())
+    # B = 0 is a no-op
+    out0, st0 = eng.optimize_stage(0, pose[:0], mb, eps[:0], _ew(W_LOCAL), heat, starts[:0])
+    assert out0.shape[0] == 0
+
+
+def test_rigid_transforms_and_window_pipeline(torch_cuda, golden, tmp_path):
+    """main() mirror on the reference's golden pipeline run (tiny fitted VAEs, 100 frames, 12 windows)."""
+    import torch
+    from globalegomocap_amd import optimizer as gopt
+    g = golden("pipeline_tiny")
+    lt = golden("lbfgs_tiny")
+    data = synth.make_sequence(n_frames=100, seed=int(g["seq_seed"]))
+    d = tmp_path / "chunk0"
+    d.mkdir()
+    with open(d / "test_data.pkl", "wb") as f:
+        pickle.dump({k: data[k] for k in ("estimated_local_skeleton", "gt_global_skeleton", "camera_pose_list", "heatmap_list")}, f)
+    torch.manual_seed(int(g["eps_seed"]))
+    eps = torch.randn(24, 32)
+    res = gopt.main(str(d), DEFAULT_CALIBRATION, 0.0, 0.0, float(g["smooth"]), 0.01, float(g["weight_3d"]), 0.01,
+                    final_smooth=True, global_vae_path=sd_from_npz(lt, "global/"), local_vae_path=sd_from_npz(lt, "local/"),
+                    eps=eps, return_stats=True)
+    errors, est_seq, mid_local, opt_seq, gt_seq, stats = res
+    assert (stats["status"] == 1).all()
+    assert opt_seq.shape == (98, 15, 3)
+    np.testing.assert_allclose(np.asarray(est_seq), g["est_smooth"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(np.asarray(gt_seq), g["gt_smooth"], rtol=1e-9, atol=1e-12)
+    mid = np.linalg.norm(np.asarray(mid_local) - g["mid_local_smooth"], axis=-1).mean()
+    fin = np.linalg.norm(opt_seq - g["opt_smooth"], axis=-1).mean()
+    assert mid < 0.5e-3 and fin < 0.5e-3, (mid, fin)
+    # headline accuracy gate: |MPJPE_hip - MPJPE_reference| <= 0.5 mm on optimized_global_mpjpe
+    assert abs(errors["optimized_global_mpjpe"] - float(g["err_smooth/optimized_global_mpjpe"])) < 0.5e-3
+    for k in ("original_global_mpjpe", "original_camera_pos_error", "original_aligned_global_mpjpe",
+              "aligned_original_mpjpe", "bone_length_aligned_original_mpjpe"):
+        assert abs(errors[k] - float(g["err_smooth/" + k])) < 1e-9, k
+
+
+def test_single_window_interface(torch_cuda, golden):
+    """BodyPoseOptimizer.optimize_pose_seq_pytorch_LBFGS drop-in call, eps from the global torch RNG."""
+    import torch
+    from globalegomocap_amd.optimizer import BodyPoseOptimizer
+    g = golden("lbfgs_tiny")
+    pose, heat = g["pose"], heat_from_centres(g["heat_centres"])
+    bpo = BodyPoseOptimizer(DEFAULT_CALIBRATION, torch.from_numpy(pose).float(), sd_from_npz(g, "local/"), seq_len=10,
+                            network_seq_len=10, latent_dim=32)
+    bpo.set_weights(vae_weight=0.0, gmm_weight=0.0, smooth_weight=1e-5, bone_length_weight=1e-2, weight_3d=1e-6,
+                    reproj_weight=1e-2)
+    torch.manual_seed(1234)
+    out = bpo.optimize_pose_seq_pytorch_LBFGS(pose, heat, pose.copy())
+    assert out.dtype == np.float32 and out.shape == (10, 15, 3)
+    assert np.linalg.norm(out - g["local_out"], axis=-1).mean() < 0.5e-3
+    with pytest.raises(RuntimeError):
+        BodyPoseOptimizer(DEFAULT_CALIBRATION, torch.from_numpy(pose).float(), sd_from_npz(g, "local/"), seq_len=10,
+                          network_seq_len=10, latent_dim=2048)
