@@ -72,6 +72,10 @@ def load_library(path=None):
     if not os.path.exists(p):
         raise GemError("HIP library %s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(there is no CPU fallback for the optimiser)" % p)
+    # PyTorch-ROCm ships its own libamdhip64.so.7 / libhsa-runtime64; it must be the HIP runtime of the
+    # process (device pointers and streams come from torch), so make sure it is loaded first: the
+    # DT_NEEDED entry of libgem_hip.so then binds to that copy by soname.
+    import torch  # noqa: F401
     lib = C.CDLL(p)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)           # AttributeError here = header and library out of sync

@@ -401,6 +401,7 @@ int gem_energy_grad(gem_handle* h, int stage, int B, const float* d_z, const flo
                     const int32_t* d_frame0, const float* d_mean_bone, const gem_energy_weights* wt, double* d_energy,
                     double* d_parts, float* d_dz, float* d_pose, void* stream) {
     if (check_call(h, stage, B, "gem_energy_grad")) return 1;
+    if (B == 0) return 0;
     if (!wt || !d_z || !d_pose_init || !d_mean_bone) { set_error("gem_energy_grad: null argument"); return 1; }
     if (wt->reproj != 0.0 && (!d_heat || !d_frame0)) { set_error("gem_energy_grad: reproj weight != 0 needs heat-maps"); return 1; }
     hipStream_t s = (hipStream_t)stream;
@@ -420,6 +421,7 @@ int gem_optimize_stage(gem_handle* h, int stage, int B, const float* d_pose_in, 
                        const float* d_mean_bone, const float* d_eps, const gem_energy_weights* wt, const gem_lbfgs_opts* opt,
                        float* d_pose_out, gem_window_stats* d_stats, void* stream) {
     if (check_call(h, stage, B, "gem_optimize_stage")) return 1;
+    if (B == 0) return 0;
     if (!d_pose_in || !d_mean_bone || !wt || !opt || !d_pose_out) { set_error("gem_optimize_stage: null argument"); return 1; }
     return optimize_stage_impl(h, stage, B, d_pose_in, d_heat, d_frame0, d_mean_bone, d_eps, *wt, *opt, d_pose_out, d_stats,
                                (hipStream_t)stream);
@@ -430,6 +432,7 @@ int gem_optimize_windows(gem_handle* h, int B, const float* d_local_pose, const 
                          const gem_energy_weights* w_local, const gem_energy_weights* w_global, const gem_lbfgs_opts* opt,
                          float* d_mid_local, double* d_global, gem_window_stats* d_stats, void* stream) {
     if (check_call(h, 0, B, "gem_optimize_windows") || check_call(h, 1, B, "gem_optimize_windows")) return 1;
+    if (B == 0) return 0;
     if (!d_local_pose || !d_cams || !d_frame0 || !d_mean_bone || !w_local || !w_global || !opt || !d_global) {
         set_error("gem_optimize_windows: null argument"); return 1;
     }
