@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""Throughput of the window optimiser on MI355X: optimised windows per second.
+
+    python bench.py --gpus N --steps K --warmup W [--workload seq2k|w8192|<n_chunks>]
+
+One "step" = one pass of the hot path over one batch of windows: local stage -> float64
+relative-global transform -> global stage -> global pose (the loop body of the reference's `main()`,
+optimizer.py:370-423) for every window of the rank's synthetic sequence, inputs resident in HBM.
+Default workload = BASELINE.json configs[1]: one 2000-frame sequence = 20 chunks x 12 windows = 240
+windows per GPU, fp32 (weak scaling: every rank gets its own sequence; with N > 1 the refined poses are
+all-gathered over RCCL inside the step).
+
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` for the dominant kernel
+(the decoder_input products, timed with HIP events on the launch stream inside the timed region) and
+`cpu_baseline` (the PyTorch-CPU port of the reference timed on this box's host cores, rank 0, N=1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, spec
+CHUNK = 100                         # frames per chunk directory (process_test_data.py:177-184)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--workload", default="seq2k", help="seq2k (20 chunks, 240 windows) | w8192 | <number of chunks>")
+    p.add_argument("--fit-steps", type=int, default=600, help="Adam steps to fit the synthetic VAEs (untimed)")
+    p.add_argument("--cpu-windows", type=int, default=12, help="windows of the CPU baseline sample (0 = skip)")
+    p.add_argument("--no-profile", action="store_true", help="no HIP-event timing of the dominant kernel")
+    return p.parse_args()
+
+
+def fit_weights(shape, seed, device, steps, relative):
+    """Untimed: synthetic well-conditioned VAE in the reference's checkpoint schema."""
+    from globalegomocap_amd import synth
+    from globalegomocap_amd.vae_torch import fit_vae
+    win = synth.make_training_windows(4096, shape.seq_len, seed)
+    if relative:        # relative-global poses drift with the camera (4 mm / frame along x)
+        win = win.reshape(-1, shape.seq_len, 15, 3).copy()
+        win[..., 0] += (0.004 * np.arange(shape.seq_len))[None, :, None]
+        win = win.reshape(-1, shape.seq_len, 45)
+    sd, err = fit_vae(shape, win, steps=steps, seed=seed, device=device)
+    return sd, err
+
+
+def cpu_baseline(sd_local, sd_global, cam, seqd, starts, mean_bone, eps_l, eps_g, w_local, w_global, n_windows):
+    """The reference's algorithm on the host cores (oracle/torch_port.py), first n_windows windows."""
+    import torch
+    from oracle import torch_port as TP
+    from oracle import np_oracle as O
+    nthreads = torch.get_num_threads()
+    nets = [TP.vae_from_state_dict(sd_local), TP.vae_from_state_dict(sd_global)]
+    est, cams = seqd["est_local_np"], seqd["cams_np"]
+    heat = seqd["heat"][: int(starts[n_windows - 1]) + 10].cpu().numpy()
+    opts = []
+    for net, w in zip(nets, (w_local, w_global)):
+        o = TP.WindowOptimizerPort(net, cam.poly_w2c, cam.cx, cam.cy, est[:CHUNK])
+        o.mean_bone = torch.as_tensor(mean_bone)
+        o.set_weights(*w)
+        opts.append(o)
+    out = []
+    t0 = time.perf_counter()
+    for i in range(n_windows):
+        s = int(starts[i])
+        loc, cs, hs = est[s:s + 10], cams[s:s + 10], heat[s:s + 10]
+        a, _ = opts[0].optimize(loc, hs, eps_l[i])
+        rel = O.relative_global(a, cs)
+        b, _ = opts[1].optimize(rel.astype(np.float32), hs, eps_g[i])
+        out.append(O.to_global(b, cs))
+    dt = time.perf_counter() - t0
+    return np.asarray(out), dt, nthreads
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)       # RCCL over xGMI
+
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    if world > 1:
+        dist.barrier()
+    from globalegomocap_amd import synth, vae as vae_schema
+    from globalegomocap_amd.camera import FisheyeCamera, DEFAULT_CALIBRATION
+    from globalegomocap_amd.engine import WindowEngine, energy_weights, stats_to_numpy, LOCAL_STAGE, GLOBAL_STAGE
+    from globalegomocap_amd.sequence import window_starts, merge_batches, final_smooth
+    from globalegomocap_amd.errors import mpjpe
+
+    n_chunks = {"seq2k": 20, "w8192": 683}.get(a.workload) or int(a.workload)
+    shape = vae_schema.VAEShape()
+    cam = FisheyeCamera.from_json(DEFAULT_CALIBRATION)
+
+    # ---- untimed setup: weights (same on every rank), the rank's own sequence, window table
+    sd_local, err_l = fit_weights(shape, 101, device, a.fit_steps, relative=False)
+    sd_global, err_g = fit_weights(shape, 102, device, a.fit_steps, relative=True)
+    n_frames = n_chunks * CHUNK
+    seqd = synth.make_sequence_device(n_frames, seed=1000 + rank, device=device, camera=cam)
+    starts = np.concatenate([c * CHUNK + window_starts(CHUNK) for c in range(n_chunks)]).astype(np.int32)
+    chunk_of = np.repeat(np.arange(n_chunks), len(window_starts(CHUNK)))
+    B = len(starts)
+    eng = WindowEngine(shape, cam, max_windows=B)
+    eng.load_vae(LOCAL_STAGE, sd_local)
+    eng.load_vae(GLOBAL_STAGE, sd_global)
+    mb = torch.stack([eng.mean_bone_length(seqd["est_local"][c * CHUNK:(c + 1) * CHUNK]) for c in range(n_chunks)])
+    mb_w = mb[torch.as_tensor(chunk_of, device=device)].contiguous()
+    g = torch.Generator().manual_seed(4321 + rank)
+    eps = torch.randn(2 * B, shape.latent_dim, generator=g).reshape(B, 2, -1)
+    eps_l, eps_g = eps[:, 0].contiguous().to(device), eps[:, 1].contiguous().to(device)
+    f0 = torch.as_tensor(starts, device=device)
+    # CLI defaults of optimize_whole_sequence.py:14-19 through main()'s two set_weights calls (optimizer.py:352-358)
+    wl = (0.01 / 10000, 0.001 / 100, 0.01, 0.0, 0.01)
+    wg = (0.01, 0.001, 0.01, 0.0, 0.0)
+    w_local, w_global = energy_weights(*wl), energy_weights(*wg)
+    gathered = [torch.empty(B, 10, 15, 3, device=device, dtype=torch.float64) for _ in range(world)] if world > 1 else None
+
+    def step():
+        mid, glob, stats = eng.optimize_windows(seqd["est_local"], seqd["cams"], seqd["heat"], f0, mb_w, eps_l, eps_g,
+                                                w_local, w_global, want_stats=True)
+        if world > 1:
+            dist.all_gather(gathered, glob)          # refined global poses of every shard
+        return mid, glob, stats
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    profile = not a.no_profile
+    eng.profile_enable(profile)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        mid, glob, stats = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    eng.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        st = stats_to_numpy(stats)
+        assert (st["status"] == 1).all(), "a window did not finish"
+        evals = st["func_evals"].reshape(2, B)
+        glob_np = glob.cpu().numpy()
+        # accuracy on this rank's sequence: merged + final-smoothed chunks vs ground truth (metres)
+        per = len(window_starts(CHUNK))
+        opt_seq, gt_seq, est_seq = [], [], []
+        for c in range(n_chunks):
+            opt_seq.append(final_smooth(merge_batches(glob_np[c * per:(c + 1) * per])))
+            n_out = opt_seq[-1].shape[0]
+            gt_seq.append(seqd["gt_global"][c * CHUNK:c * CHUNK + n_out])
+            homo = np.concatenate([seqd["est_local_np"][c * CHUNK:c * CHUNK + n_out], np.ones((n_out, 15, 1))], -1)
+            est_seq.append(np.einsum("nij,nkj->nki", seqd["cams_np"][c * CHUNK:c * CHUNK + n_out], homo)[..., :3])
+        mp_opt, mp_in = mpjpe(np.concatenate(opt_seq), np.concatenate(gt_seq)), mpjpe(np.concatenate(est_seq), np.concatenate(gt_seq))
+        roof = None
+        if profile:
+            ms, n, fl = eng.profile_read(0)
+            if n:
+                achieved = fl / (ms * 1e-3) / 1e12
+                roof = {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(achieved / PEAK_F32_MATRIX_TFLOPS, 4), "traffic": None,
+                        "kernel": "gemm_f32_kernel<1,EPI_BIAS,*,*,1> (decoder_input forward + backward-data)",
+                        "launches": int(n), "avg_us": round(ms * 1e3 / n, 2),
+                        "flop_per_launch": fl / n}
+        cpu = None
+        if world == 1 and a.cpu_windows > 0:
+            nw = min(a.cpu_windows, B)
+            ref, dt, nthreads = cpu_baseline(sd_local, sd_global, cam, seqd, starts, mb_w[0].cpu().numpy(), eps_l.cpu().numpy(),
+                                             eps_g.cpu().numpy(), wl, wg, nw)
+            diff = float(np.linalg.norm(ref - glob_np[:nw], axis=-1).mean())
+            gtw = np.stack([seqd["gt_global"][s:s + 10] for s in starts[:nw]])
+            cpu = {"value": round(nw / dt, 4), "unit": "windows/s", "cores": int(nthreads), "kind": "port",
+                   "sample": "first %d windows of the same sequence, same weights and eps, torch %s CPU, "
+                             "autograd incl. frozen-VAE weight grads + torch.optim.LBFGS" % (nw, torch.__version__),
+                   "mpjpe_port_mm": round(mpjpe(ref, gtw) * 1000, 4), "mpjpe_hip_mm": round(mpjpe(glob_np[:nw], gtw) * 1000, 4),
+                   "mean_joint_diff_hip_vs_port_mm": round(diff * 1000, 4)}
+        total_windows = B * world * a.steps
+        line = {
+            "metric": "optimised windows/sec (10-frame, 15-joint)",
+            "value": round(total_windows / elapsed, 2),
+            "unit": "windows/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1] shape: %d-frame sequence per GPU = %d chunks x %d windows = %d windows, "
+                                   "fp32, local+global stage, L-BFGS max_iter 25 / max_eval 31" % (n_frames, n_chunks, per, B),
+                       "windows_per_gpu": B, "latent_dim": shape.latent_dim, "parallelism": "window-shards x%d" % world,
+                       "vae": "synthetic, fitted %d Adam steps (recon %.1f / %.1f mm)" % (a.fit_steps, err_l * 1e3, err_g * 1e3)},
+            "evals_per_stage": {"local_mean": float(evals[0].mean()), "global_mean": float(evals[1].mean()),
+                                "min": int(evals.min()), "max": int(evals.max())},
+            "mpjpe_mm": {"input": round(mp_in * 1e3, 3), "optimised": round(mp_opt * 1e3, 3)},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -155,6 +155,8 @@ int gem_create(const gem_config* cfg, gem_handle** out) {
     if (dev_alloc(w.allocs, &w.parts, (size_t)B * 5)) return 1;
     if (dev_alloc(w.allocs, &w.pose_a, rows * h->C)) return 1;
     if (dev_alloc(w.allocs, &w.pose_b, rows * h->C)) return 1;
+    w.splitk_elems = (size_t)8 << 20;      // 32 MB: split-K is only used while a layer has < 640 output tiles
+    if (dev_alloc(w.allocs, &w.splitk, w.splitk_elems)) return 1;
     std::vector<int> parents(cfg->parents, cfg->parents + cfg->n_joints);
     std::vector<int> children((size_t)GEM_MAX_JOINTS * GEM_MAX_JOINTS, -1);
     for (int j = 0; j < cfg->n_joints; ++j) {

@@ -74,6 +74,8 @@ struct Workspace {
     // pipeline scratch
     float* pose_a = nullptr;            // [B,T,J,3] gathered local poses / stage outputs
     float* pose_b = nullptr;
+    float* splitk = nullptr;            // partial slabs of the split-K GEMM launches
+    size_t splitk_elems = 0;
     std::vector<void*> allocs;
 };
 

@@ -14,11 +14,14 @@
 // 16-byte pad per row so the ds_read_b128 fragment reads of 32 different rows spread over the banks).
 // The MFMA k-pairing is permuted (step s pairs k=s with k=16+s) so each lane's 16 A and 16 B values of
 // a K-step are four contiguous 16-byte LDS reads; a sum over k does not care about the pairing.
+#include <cstdlib>
+
 #include "gem_internal.h"
 
 namespace gem {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));    // native vector: keeps staged tiles in VGPRs (a float4 struct array went to scratch)
 
 constexpr int BK = 32;
 constexpr int LDS_LD = BK + 4;
@@ -28,7 +31,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                                                        const float* __restrict__ W,
                                                        const float* __restrict__ bias,
                                                        const float* __restrict__ aux, float* __restrict__ C,
-                                                       int ldc, int M, int N, int K, int T) {
+                                                       int ldc, int M, int N, int K, int T, int tiles_per_slice,
+                                                       size_t slab_stride) {
     constexpr int BM = 64 * RM, BN = 64 * RN;
     constexpr int A_LD4 = BM * 8 / 256;   // float4 loads per thread for the A tile
     constexpr int B_LD4 = BN * 8 / 256;
@@ -40,49 +44,50 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int kTiles = K / BK;
-    const int nTiles = TAPS * kTiles;
+    // split-K: blockIdx.z owns k-tiles [kt_begin, kt_end) of the TAPS*K/BK tiles and writes a raw partial slab
+    const bool split = gridDim.z > 1;
+    const int kt_begin = blockIdx.z * tiles_per_slice;
+    const int kt_end = min(TAPS * kTiles, kt_begin + tiles_per_slice);
+    if (split) C += (size_t)blockIdx.z * slab_stride;
 
-    // ---- per-thread global load coordinates
-    int a_row[A_LD4], a_t[A_LD4];
+    // ---- per-thread global load coordinates (branch-free: out-of-range rows read row 0 and are zeroed)
     const int c4 = (tid & 7) * 4;
+    const int lrow = tid >> 3;
+    int a_row[A_LD4], a_t[A_LD4];
 #pragma unroll
     for (int i = 0; i < A_LD4; ++i) {
-        int r = m0 + (tid >> 3) + 32 * i;
-        a_row[i] = r;
-        a_t[i] = (TAPS == 3) ? (r % T) : 0;
+        a_row[i] = m0 + lrow + 32 * i;
+        a_t[i] = (TAPS == 3) ? (a_row[i] % T) : 0;
     }
-    float4 ra[A_LD4], rb[B_LD4];
+    f32x4 ra[A_LD4], rb[B_LD4];
+    bool a_ok[A_LD4];
 
-    auto load_tile = [&](int kt) {
-        const int tap = (TAPS == 3) ? kt / kTiles : 0;
-        const int k0 = (kt - tap * kTiles) * BK + c4;
-#pragma unroll
-        for (int i = 0; i < A_LD4; ++i) {
-            const int r = a_row[i];
-            bool ok = r < M;
-            int src = r;
-            if (TAPS == 3) {
-                const int tt = a_t[i] + tap - 1;
-                ok = ok && tt >= 0 && tt < T;
-                src = r + tap - 1;
-            }
-            ra[i] = ok ? *reinterpret_cast<const float4*>(A + (size_t)src * lda + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        const float* Wt = W + (size_t)tap * N * K;
-#pragma unroll
-        for (int i = 0; i < B_LD4; ++i) {
-            const int n = n0 + (tid >> 3) + 32 * i;
-            rb[i] = *reinterpret_cast<const float4*>(Wt + (size_t)n * K + k0);
-        }
-    };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < A_LD4; ++i)
-            *reinterpret_cast<float4*>(lds + buf * BUF + ((tid >> 3) + 32 * i) * LDS_LD + c4) = ra[i];
-#pragma unroll
-        for (int i = 0; i < B_LD4; ++i)
-            *reinterpret_cast<float4*>(lds + buf * BUF + (BM + (tid >> 3) + 32 * i) * LDS_LD + c4) = rb[i];
-    };
+#define GEM_LOAD_TILE(kt_)                                                                                   \
+    {                                                                                                        \
+        const int tap_ = (TAPS == 3) ? (kt_) / kTiles : 0;                                                   \
+        const int k0_ = ((kt_) - tap_ * kTiles) * BK + c4;                                                   \
+        _Pragma("unroll") for (int i = 0; i < A_LD4; ++i) {                                                  \
+            bool ok_ = a_row[i] < M;                                                                         \
+            if (TAPS == 3) {                                                                                 \
+                const int tt_ = a_t[i] + tap_ - 1;                                                           \
+                ok_ = ok_ && tt_ >= 0 && tt_ < T;                                                            \
+            }                                                                                                \
+            const int src_ = ok_ ? a_row[i] + ((TAPS == 3) ? tap_ - 1 : 0) : 0;                              \
+            ra[i] = *reinterpret_cast<const f32x4*>(A + (size_t)src_ * lda + k0_);                           \
+            a_ok[i] = ok_;  /* zeroing happens at the LDS store, after the MFMAs: no wait on the load here */ \
+        }                                                                                                    \
+        const float* Wt_ = W + (size_t)tap_ * N * K;                                                         \
+        _Pragma("unroll") for (int i = 0; i < B_LD4; ++i)                                                    \
+            rb[i] = *reinterpret_cast<const f32x4*>(Wt_ + (size_t)(n0 + lrow + 32 * i) * K + k0_);          \
+    }
+#define GEM_STORE_TILE(buf_)                                                                                 \
+    {                                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < A_LD4; ++i)                                                    \
+            *reinterpret_cast<f32x4*>(lds + (buf_) * BUF + (lrow + 32 * i) * LDS_LD + c4) =                  \
+                a_ok[i] ? ra[i] : f32x4{0.f, 0.f, 0.f, 0.f};                                                 \
+        _Pragma("unroll") for (int i = 0; i < B_LD4; ++i)                                                    \
+            *reinterpret_cast<f32x4*>(lds + (buf_) * BUF + (BM + lrow + 32 * i) * LDS_LD + c4) = rb[i];      \
+    }
 
     f32x16 acc[RM][RN];
 #pragma unroll
@@ -93,21 +98,25 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int fr = lane & 31, fh = lane >> 5;
-    load_tile(0);
-    store_tile(0);
+    // 64x64 tiles: ONE LDS buffer (18 KB) so that up to 7 workgroups share a CU and hide each other's
+    // barriers; 128x128 tiles: two buffers, one barrier per K-step.
+    constexpr bool DBUF = (RM * RN > 1);
+    GEM_LOAD_TILE(kt_begin);
+    GEM_STORE_TILE(0);
     __syncthreads();
     int cur = 0;
-    for (int kt = 0; kt < nTiles; ++kt) {
-        if (kt + 1 < nTiles) load_tile(kt + 1);
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const bool more = kt + 1 < kt_end;
+        if (more) GEM_LOAD_TILE(kt + 1);
         const float* as = lds + cur * BUF + (wm * 32 * RM + fr) * LDS_LD + fh * 16;
         const float* bs = lds + cur * BUF + (BM + wn * 32 * RN + fr) * LDS_LD + fh * 16;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float4 av[RM], bv[RN];
+            f32x4 av[RM], bv[RN];
 #pragma unroll
-            for (int i = 0; i < RM; ++i) av[i] = *reinterpret_cast<const float4*>(as + i * 32 * LDS_LD + 4 * q);
+            for (int i = 0; i < RM; ++i) av[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LDS_LD + 4 * q);
 #pragma unroll
-            for (int j = 0; j < RN; ++j) bv[j] = *reinterpret_cast<const float4*>(bs + j * 32 * LDS_LD + 4 * q);
+            for (int j = 0; j < RN; ++j) bv[j] = *reinterpret_cast<const f32x4*>(bs + j * 32 * LDS_LD + 4 * q);
 #pragma unroll
             for (int i = 0; i < RM; ++i)
 #pragma unroll
@@ -118,10 +127,18 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, bv[j].w, acc[i][j], 0, 0, 0);
                 }
         }
-        if (kt + 1 < nTiles) store_tile(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
+        if (DBUF) {
+            if (more) GEM_STORE_TILE(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        } else {
+            __syncthreads();                    // every wave has read the tile
+            if (more) GEM_STORE_TILE(0);
+            __syncthreads();
+        }
     }
+#undef GEM_LOAD_TILE
+#undef GEM_STORE_TILE
 
     // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
@@ -130,43 +147,115 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         for (int j = 0; j < RN; ++j) {
             const int col = n0 + wn * 32 * RN + j * 32 + fr;
             float bv = 0.f;
-            if (EPI == EPI_BIAS || EPI == EPI_BIAS_LRELU) bv = bias[col];
+            if ((EPI == EPI_BIAS || EPI == EPI_BIAS_LRELU) && !split) bv = bias[col];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = m0 + wm * 32 * RM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
                 if (row < M) {
                     float v = acc[i][j][e] + bv;
-                    if (EPI == EPI_BIAS_LRELU) v = v > 0.f ? v : v * LEAKY_SLOPE;
-                    if (EPI == EPI_MASK) v *= (aux[(size_t)row * ldc + col] > 0.f) ? 1.f : LEAKY_SLOPE;
+                    if (EPI == EPI_BIAS_LRELU && !split) v = v > 0.f ? v : v * LEAKY_SLOPE;
+                    if (EPI == EPI_MASK && !split) v *= (aux[(size_t)row * ldc + col] > 0.f) ? 1.f : LEAKY_SLOPE;
                     C[(size_t)row * ldc + col] = v;
                 }
             }
         }
 }
 
+// sums the split-K slabs and applies the epilogue: C = epi(sum_z slab[z] + bias)
+template <int EPI>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int nslab, size_t slab_stride,
+                                                            const float* __restrict__ bias, const float* __restrict__ aux,
+                                                            float* __restrict__ C, int M, int N, int ldc) {
+    const int n4 = N / 4;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)M * n4) return;
+    const int row = (int)(i / n4), c = (int)(i - (size_t)row * n4) * 4;
+    const size_t off = (size_t)row * ldc + c;
+    f32x4 v = *reinterpret_cast<const f32x4*>(slabs + off);
+    for (int z = 1; z < nslab; ++z) v += *reinterpret_cast<const f32x4*>(slabs + (size_t)z * slab_stride + off);
+    if (EPI == EPI_BIAS || EPI == EPI_BIAS_LRELU) v += *reinterpret_cast<const f32x4*>(bias + c);
+    if (EPI == EPI_BIAS_LRELU) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : v[q] * LEAKY_SLOPE;
+    }
+    if (EPI == EPI_MASK) {
+        const f32x4 m = *reinterpret_cast<const f32x4*>(aux + off);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] *= m[q] > 0.f ? 1.f : LEAKY_SLOPE;
+    }
+    *reinterpret_cast<f32x4*>(C + off) = v;
+}
+
+// How many K slices.  The dispatcher packs a CU with as many workgroups as fit (7 of these), so a grid of
+// 1280 small workgroups lands on 183 of the 256 CUs; the launch below therefore also pads the LDS request
+// so that exactly ceil(workgroups/256) fit per CU.  Pick the slice count whose workgroup total fills those
+// slots best (workgroups / (256 * per_cu)), preferring >= 2 per CU and fewer slices.
+constexpr int N_CU = 256;
+constexpr int LDS_PER_CU = 160 * 1024;
+static int pick_splitk(const gem_handle* h, long blocks, int n_tiles, size_t slab_elems) {
+    if (!h->ws.splitk || blocks >= 3 * N_CU) return 1;
+    int best = 1;
+    double best_score = -1.0;
+    for (int sk = 1; sk <= 8; ++sk) {
+        if (sk > 1 && (n_tiles / sk < 6 || (size_t)sk * slab_elems > h->ws.splitk_elems)) break;
+        const long wgs = blocks * sk;
+        const long per_cu = (wgs + N_CU - 1) / N_CU;
+        double score = (double)wgs / (double)(per_cu * N_CU);
+        if (per_cu < 2) score *= 0.6;             // one workgroup per CU cannot hide its own barriers
+        score -= 0.01 * sk;                        // slabs cost a reduce pass
+        if (score > best_score) { best_score = score; best = sk; }
+    }
+    return best;
+}
+
 template <int TAPS, int EPI, int RM, int RN, int TAG>
-static int launch_one(const Layer& L, const float* A, int lda, const float* aux, float* C, int ldc, int M, int T, hipStream_t s) {
+static int launch_one(gem_handle* h, const Layer& L, const float* A, int lda, const float* aux, float* C, int ldc, int M, int T,
+                      hipStream_t s) {
     constexpr int BM = 64 * RM, BN = 64 * RN;
-    const size_t shmem = 2 * (size_t)(BM + BN) * LDS_LD * sizeof(float);
+    size_t shmem = (RM * RN > 1 ? 2 : 1) * (size_t)(BM + BN) * LDS_LD * sizeof(float);
     auto k = gemm_f32_kernel<TAPS, EPI, RM, RN, TAG>;
     static bool attr_set = false;
     if (!attr_set) {
-        if (shmem > 48 * 1024)
-            GEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        GEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_PER_CU));
         attr_set = true;
     }
-    dim3 grid(L.N / BN, (M + BM - 1) / BM);
-    hipLaunchKernelGGL(k, grid, dim3(256), shmem, s, A, lda, L.w, L.bias, aux, C, ldc, M, L.N, L.K, T);
+    const int n_tiles = TAPS * (L.K / BK);
+    dim3 grid(L.N / BN, (M + BM - 1) / BM, 1);
+    const size_t slab = (size_t)M * ldc;
+    const int sk = pick_splitk(h, (long)grid.x * grid.y, n_tiles, slab);
+    const int per = (n_tiles + sk - 1) / sk;
+    grid.z = (n_tiles + per - 1) / per;
+    // occupancy cap = even spread: LDS request sized so that only ceil(workgroups/256) fit on a CU
+    const long wgs = (long)grid.x * grid.y * grid.z;
+    const long per_cu = (wgs + N_CU - 1) / N_CU;
+    if (per_cu <= 8) {
+        const size_t want = ((size_t)LDS_PER_CU / per_cu) & ~(size_t)1023;
+        if (want > shmem) shmem = want;
+    }
+    if (grid.z == 1) {
+        hipLaunchKernelGGL(k, grid, dim3(256), shmem, s, A, lda, L.w, L.bias, aux, C, ldc, M, L.N, L.K, T, n_tiles, (size_t)0);
+        GEM_HIP(hipGetLastError());
+        return 0;
+    }
+    hipLaunchKernelGGL(k, grid, dim3(256), shmem, s, A, lda, L.w, L.bias, aux, h->ws.splitk, ldc, M, L.N, L.K, T, per, slab);
+    GEM_HIP(hipGetLastError());
+    const size_t n4 = (size_t)M * (L.N / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel<EPI>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, h->ws.splitk, (int)grid.z, slab,
+                       L.bias, aux, C, M, L.N, ldc);
     GEM_HIP(hipGetLastError());
     return 0;
 }
 
 template <int TAPS, int EPI, int TAG>
-static int launch_tile(const Layer& L, const float* A, int lda, const float* aux, float* C, int ldc, int M, int T, hipStream_t s) {
+static int launch_tile(gem_handle* h, const Layer& L, const float* A, int lda, const float* aux, float* C, int ldc, int M, int T,
+                       hipStream_t s) {
     // 128x128 tiles only when they still fill the chip (>= 2 workgroups per CU) and divide N
     const long big_blocks = (long)((M + 127) / 128) * (L.N / 128);
-    if (L.N % 128 == 0 && big_blocks >= 512) return launch_one<TAPS, EPI, 2, 2, TAG>(L, A, lda, aux, C, ldc, M, T, s);
-    return launch_one<TAPS, EPI, 1, 1, TAG>(L, A, lda, aux, C, ldc, M, T, s);
+    static const char* force = getenv("GEM_FORCE_TILE");       // developer override: "1" = 64x64, "2" = 128x128
+    if (force && force[0] == '1') return launch_one<TAPS, EPI, 1, 1, TAG>(h, L, A, lda, aux, C, ldc, M, T, s);
+    if (force && force[0] == '2' && L.N % 128 == 0) return launch_one<TAPS, EPI, 2, 2, TAG>(h, L, A, lda, aux, C, ldc, M, T, s);
+    if (L.N % 128 == 0 && big_blocks >= 512) return launch_one<TAPS, EPI, 2, 2, TAG>(h, L, A, lda, aux, C, ldc, M, T, s);
+    return launch_one<TAPS, EPI, 1, 1, TAG>(h, L, A, lda, aux, C, ldc, M, T, s);
 }
 
 int launch_gemm(gem_handle* h, const Layer& L, int epi, const float* A, int lda, const float* aux, float* C, int ldc, int M,
@@ -188,15 +277,15 @@ int launch_gemm(gem_handle* h, const Layer& L, int epi, const float* A, int lda,
     int rc = 1;
     if (L.taps == 1) {
         // TAG 1 = the decoder_input products (forward and backward-data): the dominant kernel gets its own symbol
-        if (family == 0 && epi == EPI_BIAS) rc = launch_tile<1, EPI_BIAS, 1>(L, A, lda, aux, C, ldc, M, T, s);
-        else if (epi == EPI_BIAS) rc = launch_tile<1, EPI_BIAS, 0>(L, A, lda, aux, C, ldc, M, T, s);
-        else if (epi == EPI_NONE) rc = launch_tile<1, EPI_NONE, 0>(L, A, lda, aux, C, ldc, M, T, s);
+        if (family == 0 && epi == EPI_BIAS) rc = launch_tile<1, EPI_BIAS, 1>(h, L, A, lda, aux, C, ldc, M, T, s);
+        else if (epi == EPI_BIAS) rc = launch_tile<1, EPI_BIAS, 0>(h, L, A, lda, aux, C, ldc, M, T, s);
+        else if (epi == EPI_NONE) rc = launch_tile<1, EPI_NONE, 0>(h, L, A, lda, aux, C, ldc, M, T, s);
         else set_error("launch_gemm: unsupported epilogue for a linear layer");
     } else if (L.taps == 3) {
-        if (epi == EPI_BIAS) rc = launch_tile<3, EPI_BIAS, 0>(L, A, lda, aux, C, ldc, M, T, s);
-        else if (epi == EPI_BIAS_LRELU) rc = launch_tile<3, EPI_BIAS_LRELU, 0>(L, A, lda, aux, C, ldc, M, T, s);
-        else if (epi == EPI_MASK) rc = launch_tile<3, EPI_MASK, 0>(L, A, lda, aux, C, ldc, M, T, s);
-        else if (epi == EPI_NONE) rc = launch_tile<3, EPI_NONE, 0>(L, A, lda, aux, C, ldc, M, T, s);
+        if (epi == EPI_BIAS) rc = launch_tile<3, EPI_BIAS, 0>(h, L, A, lda, aux, C, ldc, M, T, s);
+        else if (epi == EPI_BIAS_LRELU) rc = launch_tile<3, EPI_BIAS_LRELU, 0>(h, L, A, lda, aux, C, ldc, M, T, s);
+        else if (epi == EPI_MASK) rc = launch_tile<3, EPI_MASK, 0>(h, L, A, lda, aux, C, ldc, M, T, s);
+        else if (epi == EPI_NONE) rc = launch_tile<3, EPI_NONE, 0>(h, L, A, lda, aux, C, ldc, M, T, s);
     } else {
         set_error("launch_gemm: taps must be 1 or 3");
     }

@@ -96,3 +96,31 @@ def make_training_windows(n_windows, seq_len, seed):
     for i in range(n_windows):
         out[i] = make_motion(seq_len, rng, t0=rng.uniform(0.0, 10.0)).reshape(seq_len, -1)
     return out
+
+
+def make_sequence_device(n_frames, seed, device, camera=None, noise=0.02, sigma=1.5, block=200):
+    """Same content as `make_sequence`, with the big arrays created directly in HBM (torch is used as
+    an allocator / elementwise engine here; this is input synthesis, not the measured path).
+
+    Returns dict: est_local f32 [F,15,3], cams f64 [F,4,4], heat f32 [F,64,64,15] (device tensors) and
+    gt_global / est_local_np / cams_np (host float64) for the metrics."""
+    import torch
+    seq = make_sequence(n_frames, seed, camera, noise, sigma, with_heatmaps=False)
+    est = np.asarray(seq["estimated_local_skeleton"])
+    cams = np.asarray(seq["camera_pose_list"])
+    cen = torch.as_tensor(seq["heatmap_centres"], dtype=torch.float32, device=device)      # [F,15,2]
+    heat = torch.empty(n_frames, HEATMAP_SIZE, HEATMAP_SIZE, N_JOINTS, dtype=torch.float32, device=device)
+    ys = torch.arange(HEATMAP_SIZE, dtype=torch.float32, device=device)[None, :, None, None]
+    xs = torch.arange(HEATMAP_SIZE, dtype=torch.float32, device=device)[None, None, :, None]
+    for a in range(0, n_frames, block):
+        c = cen[a:a + block]
+        d2 = (xs - c[:, None, None, :, 0]) ** 2 + (ys - c[:, None, None, :, 1]) ** 2
+        heat[a:a + block] = torch.exp(-d2 / (2.0 * sigma * sigma))
+    return {
+        "est_local": torch.as_tensor(est, dtype=torch.float32, device=device).contiguous(),
+        "cams": torch.as_tensor(cams, dtype=torch.float64, device=device).contiguous(),
+        "heat": heat,
+        "gt_global": np.asarray(seq["gt_global_skeleton"]),
+        "est_local_np": est,
+        "cams_np": cams,
+    }

@@ -1,0 +1,96 @@
+// Stand-alone timing + correctness harness for csrc/gemm_f32.hip (developer tool, not shipped).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o /tmp/gemm_bench tools/gemm_bench.hip && /tmp/gemm_bench
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <vector>
+#include "../globalegomocap_amd/csrc/gemm_f32.hip"
+
+namespace gem {
+void set_error(const std::string& m) { fprintf(stderr, "error: %s\n", m.c_str()); }
+bool hip_ok(hipError_t e, const char* what) { if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", what, hipGetErrorString(e)); return false; } return true; }
+}
+using namespace gem;
+
+__global__ void ref_kernel(const float* A, int lda, const float* W, const float* bias, const float* aux, float* C, int ldc,
+                           int M, int N, int K, int T, int taps, int epi) {
+    int col = blockIdx.x * blockDim.x + threadIdx.x, row = blockIdx.y;
+    if (col >= N || row >= M) return;
+    double acc = 0;
+    for (int tap = 0; tap < taps; ++tap) {
+        int src = row, ok = 1;
+        if (taps == 3) { int tt = row % T + tap - 1; ok = tt >= 0 && tt < T; src = row + tap - 1; }
+        if (!ok) continue;
+        for (int k = 0; k < K; ++k) acc += (double)A[(size_t)src * lda + k] * W[((size_t)tap * N + col) * K + k];
+    }
+    float v = (float)acc;
+    if (epi == EPI_BIAS || epi == EPI_BIAS_LRELU) v += bias[col];
+    if (epi == EPI_BIAS_LRELU) v = v > 0 ? v : v * LEAKY_SLOPE;
+    if (epi == EPI_MASK) v *= aux[(size_t)row * ldc + col] > 0 ? 1.f : LEAKY_SLOPE;
+    C[(size_t)row * ldc + col] = v;
+}
+
+static float* dev_rand(size_t n, unsigned seed, float scale) {
+    std::vector<float> h(n);
+    srand(seed);
+    for (size_t i = 0; i < n; ++i) h[i] = scale * ((rand() / (float)RAND_MAX) * 2.f - 1.f);
+    float* d; hipMalloc(&d, n * sizeof(float)); hipMemcpy(d, h.data(), n * sizeof(float), hipMemcpyHostToDevice);
+    return d;
+}
+
+int main(int argc, char** argv) {
+    int B = argc > 1 ? atoi(argv[1]) : 240;
+    int iters = argc > 2 ? atoi(argv[2]) : 50;
+    struct Case { const char* name; int M, N, K, taps, epi, family; };
+    const int T = 10;
+    Case cases[] = {
+        {"dec_in fwd  [B,2048]x[2048,5120]", B, 5120, 2048, 1, EPI_BIAS, 0},
+        {"dec_in bwd  [B,5120]x[5120,2048]", B, 2048, 5120, 1, EPI_BIAS, 0},
+        {"conv1 fwd   [10B,3x512]->256", B * T, 256, 512, 3, EPI_BIAS_LRELU, -1},
+        {"conv1 bwd   [10B,3x256]->512", B * T, 512, 256, 3, EPI_NONE, -1},
+        {"conv2 fwd   [10B,3x256]->128", B * T, 128, 256, 3, EPI_BIAS_LRELU, -1},
+        {"conv2 bwd   [10B,3x128]->256", B * T, 256, 128, 3, EPI_MASK, -1},
+        {"conv3 fwd   [10B,3x128]->64", B * T, 64, 128, 3, EPI_BIAS_LRELU, -1},
+        {"conv5 fwd   [10B,3x64]->64", B * T, 64, 64, 3, EPI_BIAS_LRELU, -1},
+        {"conv6 fwd   [10B,3x64]->64(45)", B * T, 64, 64, 3, EPI_BIAS, -1},
+        {"fc enc      [B,5120]x[5120,4096]", B, 4096, 5120, 1, EPI_BIAS, -1},
+    };
+    gem_handle h;
+    h.prof.on = false;
+    h.ws.splitk_elems = (size_t)8 << 20;
+    hipMalloc(&h.ws.splitk, h.ws.splitk_elems * 4);
+    if (getenv("NO_SPLITK")) h.ws.splitk = nullptr;
+    hipStream_t s; hipStreamCreate(&s);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    double total_us = 0;
+    for (auto& c : cases) {
+        Layer L; L.taps = c.taps; L.K = c.K; L.N = c.N;
+        L.w = dev_rand((size_t)c.taps * c.N * c.K, 1, 0.05f);
+        L.bias = dev_rand(c.N, 2, 0.1f);
+        float* A = dev_rand((size_t)c.M * c.K, 3, 1.f);
+        float* aux = dev_rand((size_t)c.M * c.N, 4, 1.f);
+        float *C, *R;
+        hipMalloc(&C, (size_t)c.M * c.N * 4); hipMalloc(&R, (size_t)c.M * c.N * 4);
+        hipMemset(C, 0, (size_t)c.M * c.N * 4);
+        if (launch_gemm(&h, L, c.epi, A, c.K, aux, C, c.N, c.M, T, s, c.family)) return 1;
+        hipLaunchKernelGGL(ref_kernel, dim3((c.N + 63) / 64, c.M), dim3(64), 0, s, A, c.K, L.w, L.bias, aux, R, c.N, c.M, c.N, c.K, T, c.taps, c.epi);
+        hipStreamSynchronize(s);
+        std::vector<float> hc((size_t)c.M * c.N), hr((size_t)c.M * c.N);
+        hipMemcpy(hc.data(), C, hc.size() * 4, hipMemcpyDeviceToHost);
+        hipMemcpy(hr.data(), R, hr.size() * 4, hipMemcpyDeviceToHost);
+        double maxerr = 0, maxref = 0;
+        for (size_t i = 0; i < hc.size(); ++i) { maxerr = fmax(maxerr, fabs(hc[i] - hr[i])); maxref = fmax(maxref, fabs(hr[i])); }
+        for (int i = 0; i < 5; ++i) launch_gemm(&h, L, c.epi, A, c.K, aux, C, c.N, c.M, T, s, c.family);
+        hipEventRecord(e0, s);
+        for (int i = 0; i < iters; ++i) launch_gemm(&h, L, c.epi, A, c.K, aux, C, c.N, c.M, T, s, c.family);
+        hipEventRecord(e1, s);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        double us = ms * 1e3 / iters, fl = 2.0 * c.M * c.N * (double)c.K * c.taps;
+        printf("%-36s M=%6d  %8.1f us  %7.2f TF/s   relerr %.2e\n", c.name, c.M, us, fl / us * 1e-6, maxerr / maxref);
+        total_us += us;
+        hipFree(L.w); hipFree(L.bias); hipFree(A); hipFree(aux); hipFree(C); hipFree(R);
+    }
+    printf("sum %.1f us\n", total_us);
+    return 0;
+}
