@@ -12,7 +12,7 @@
 // (157 TFLOP/s peak on MI355X).  Each wave owns RM x RN tiles of 32x32; a workgroup is 2x2 waves.
 // K is walked in steps of 32 through a double-buffered LDS image [rows][32+4] (k contiguous, one
 // 16-byte pad per row so the ds_read_b128 fragment reads of 32 different rows spread over the banks).
-// The MFMA k-pairing is permuted (step s pairs k=s with k=16+s) so each lane's 16 A and 16 B values of
+// The MFMA k-pairing is permuted (step s pairs k=s with k=BK/2+s) so each lane's 16 A and 16 B values of
 // a K-step are four contiguous 16-byte LDS reads; a sum over k does not care about the pairing.
 #include <cstdlib>
 
@@ -23,10 +23,9 @@ namespace gem {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));    // native vector: keeps staged tiles in VGPRs (a float4 struct array went to scratch)
 
-constexpr int BK = 32;
-constexpr int LDS_LD = BK + 4;
+constexpr int BK_MIN = 32;      // K padding granularity
 
-template <int TAPS, int EPI, int RM, int RN, int TAG>
+template <int TAPS, int EPI, int RM, int RN, int TAG, int BK>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, int lda,
                                                        const float* __restrict__ W,
                                                        const float* __restrict__ bias,
@@ -34,8 +33,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                                                        int ldc, int M, int N, int K, int T, int tiles_per_slice,
                                                        size_t slab_stride) {
     constexpr int BM = 64 * RM, BN = 64 * RN;
-    constexpr int A_LD4 = BM * 8 / 256;   // float4 loads per thread for the A tile
-    constexpr int B_LD4 = BN * 8 / 256;
+    constexpr int LDS_LD = BK + 4;
+    constexpr int TPR = BK / 4;             // threads per tile row (one float4 each)
+    constexpr int RPP = 256 / TPR;          // tile rows per pass of the 256 threads
+    constexpr int A_LD4 = BM / RPP;         // float4 loads per thread for the A tile
+    constexpr int B_LD4 = BN / RPP;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int BUF = (BM + BN) * LDS_LD;      // floats per LDS buffer: A tile then B tile
 
@@ -51,12 +53,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     if (split) C += (size_t)blockIdx.z * slab_stride;
 
     // ---- per-thread global load coordinates (branch-free: out-of-range rows read row 0 and are zeroed)
-    const int c4 = (tid & 7) * 4;
-    const int lrow = tid >> 3;
+    const int c4 = (tid % TPR) * 4;
+    const int lrow = tid / TPR;
     int a_row[A_LD4], a_t[A_LD4];
 #pragma unroll
     for (int i = 0; i < A_LD4; ++i) {
-        a_row[i] = m0 + lrow + 32 * i;
+        a_row[i] = m0 + lrow + RPP * i;
         a_t[i] = (TAPS == 3) ? (a_row[i] % T) : 0;
     }
     f32x4 ra[A_LD4], rb[B_LD4];
@@ -78,15 +80,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         }                                                                                                    \
         const float* Wt_ = W + (size_t)tap_ * N * K;                                                         \
         _Pragma("unroll") for (int i = 0; i < B_LD4; ++i)                                                    \
-            rb[i] = *reinterpret_cast<const f32x4*>(Wt_ + (size_t)(n0 + lrow + 32 * i) * K + k0_);          \
+            rb[i] = *reinterpret_cast<const f32x4*>(Wt_ + (size_t)(n0 + lrow + RPP * i) * K + k0_);          \
     }
 #define GEM_STORE_TILE(buf_)                                                                                 \
     {                                                                                                        \
         _Pragma("unroll") for (int i = 0; i < A_LD4; ++i)                                                    \
-            *reinterpret_cast<f32x4*>(lds + (buf_) * BUF + (lrow + 32 * i) * LDS_LD + c4) =                  \
+            *reinterpret_cast<f32x4*>(lds + (buf_) * BUF + (lrow + RPP * i) * LDS_LD + c4) =                  \
                 a_ok[i] ? ra[i] : f32x4{0.f, 0.f, 0.f, 0.f};                                                 \
         _Pragma("unroll") for (int i = 0; i < B_LD4; ++i)                                                    \
-            *reinterpret_cast<f32x4*>(lds + (buf_) * BUF + (BM + lrow + 32 * i) * LDS_LD + c4) = rb[i];      \
+            *reinterpret_cast<f32x4*>(lds + (buf_) * BUF + (BM + lrow + RPP * i) * LDS_LD + c4) = rb[i];      \
     }
 
     f32x16 acc[RM][RN];
@@ -108,10 +110,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const bool more = kt + 1 < kt_end;
         if (more) GEM_LOAD_TILE(kt + 1);
-        const float* as = lds + cur * BUF + (wm * 32 * RM + fr) * LDS_LD + fh * 16;
-        const float* bs = lds + cur * BUF + (BM + wn * 32 * RN + fr) * LDS_LD + fh * 16;
+        const float* as = lds + cur * BUF + (wm * 32 * RM + fr) * LDS_LD + fh * (BK / 2);
+        const float* bs = lds + cur * BUF + (BM + wn * 32 * RN + fr) * LDS_LD + fh * (BK / 2);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < BK / 8; ++q) {
             f32x4 av[RM], bv[RN];
 #pragma unroll
             for (int i = 0; i < RM; ++i) av[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LDS_LD + 4 * q);
@@ -208,12 +210,12 @@ static int pick_splitk(const gem_handle* h, long blocks, int n_tiles, size_t sla
     return best;
 }
 
-template <int TAPS, int EPI, int RM, int RN, int TAG>
+template <int TAPS, int EPI, int RM, int RN, int TAG, int BK>
 static int launch_one(gem_handle* h, const Layer& L, const float* A, int lda, const float* aux, float* C, int ldc, int M, int T,
                       hipStream_t s) {
     constexpr int BM = 64 * RM, BN = 64 * RN;
-    size_t shmem = (RM * RN > 1 ? 2 : 1) * (size_t)(BM + BN) * LDS_LD * sizeof(float);
-    auto k = gemm_f32_kernel<TAPS, EPI, RM, RN, TAG>;
+    size_t shmem = (RM * RN > 1 ? 2 : 1) * (size_t)(BM + BN) * (BK + 4) * sizeof(float);
+    auto k = gemm_f32_kernel<TAPS, EPI, RM, RN, TAG, BK>;
     static bool attr_set = false;
     if (!attr_set) {
         GEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_PER_CU));
@@ -251,16 +253,17 @@ static int launch_tile(gem_handle* h, const Layer& L, const float* A, int lda, c
                        hipStream_t s) {
     // 128x128 tiles only when they still fill the chip (>= 2 workgroups per CU) and divide N
     const long big_blocks = (long)((M + 127) / 128) * (L.N / 128);
-    static const char* force = getenv("GEM_FORCE_TILE");       // developer override: "1" = 64x64, "2" = 128x128
-    if (force && force[0] == '1') return launch_one<TAPS, EPI, 1, 1, TAG>(h, L, A, lda, aux, C, ldc, M, T, s);
-    if (force && force[0] == '2' && L.N % 128 == 0) return launch_one<TAPS, EPI, 2, 2, TAG>(h, L, A, lda, aux, C, ldc, M, T, s);
-    if (L.N % 128 == 0 && big_blocks >= 512) return launch_one<TAPS, EPI, 2, 2, TAG>(h, L, A, lda, aux, C, ldc, M, T, s);
-    return launch_one<TAPS, EPI, 1, 1, TAG>(h, L, A, lda, aux, C, ldc, M, T, s);
+    static const char* force = getenv("GEM_FORCE_TILE");       // developer override: "1" = 64x64, "2" = 128x128, "3" = 64x64 BK64
+    if (force && force[0] == '1') return launch_one<TAPS, EPI, 1, 1, TAG, 32>(h, L, A, lda, aux, C, ldc, M, T, s);
+    if (force && force[0] == '2' && L.N % 128 == 0) return launch_one<TAPS, EPI, 2, 2, TAG, 32>(h, L, A, lda, aux, C, ldc, M, T, s);
+    if (force && force[0] == '3' && L.K % 64 == 0) return launch_one<TAPS, EPI, 1, 1, TAG, 64>(h, L, A, lda, aux, C, ldc, M, T, s);
+    if (L.N % 128 == 0 && big_blocks >= 512) return launch_one<TAPS, EPI, 2, 2, TAG, 32>(h, L, A, lda, aux, C, ldc, M, T, s);
+    return launch_one<TAPS, EPI, 1, 1, TAG, 32>(h, L, A, lda, aux, C, ldc, M, T, s);
 }
 
 int launch_gemm(gem_handle* h, const Layer& L, int epi, const float* A, int lda, const float* aux, float* C, int ldc, int M,
                 int T, hipStream_t s, int family) {
-    if (L.K % BK != 0 || L.N % 64 != 0 || lda % 4 != 0) {
+    if (L.K % BK_MIN != 0 || L.N % 64 != 0 || lda % 4 != 0) {
         set_error("launch_gemm: dimensions must be padded (K%32, N%64, lda%4)");
         return 1;
     }

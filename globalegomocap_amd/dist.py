@@ -1,0 +1,53 @@
+"""Window sharding across the GPUs of one node.
+
+Windows are independent (there is no exchange step inside the optimisation), so
+the only collective is one all-gather of the refined global poses; inputs (heat-maps above all) are
+never scattered from a root: every rank loads or synthesises the frames of its own contiguous window
+range.  One process per GPU, `torch.distributed` with backend "nccl" (= RCCL over xGMI) on the GPU box,
+"gloo" in the CPU tests.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_windows, rank, world):
+    """Contiguous [lo, hi) range of rank `rank`: sizes differ by at most one, lower ranks get the extra."""
+    base, extra = divmod(n_windows, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def frame_span(starts, lo, hi, seq_len):
+    """Frames [f0, f1) that the windows [lo, hi) touch: what a rank has to hold in HBM."""
+    if hi <= lo:
+        return 0, 0
+    return int(starts[lo]), int(starts[hi - 1]) + seq_len
+
+
+def all_gather_windows(local, n_windows, group=None):
+    """local [n_local, ...] (any float dtype, same trailing shape on every rank) -> [n_windows, ...] on
+    every rank, in window order.  Shards may be ragged by one window; they are padded for the collective."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    sizes = [shard_range(n_windows, r, world) for r in range(world)]
+    cap = max(hi - lo for lo, hi in sizes)
+    lo, hi = sizes[rank]
+    if local.shape[0] != hi - lo:
+        raise ValueError("rank %d holds %d windows, its shard is %d" % (rank, local.shape[0], hi - lo))
+    buf = torch.zeros((cap,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    buf[: hi - lo] = local
+    out = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf, group=group)
+    return torch.cat([o[: h - l] for o, (l, h) in zip(out, sizes)], dim=0)
+
+
+def optimize_sharded(run_shard, starts, seq_len=10, group=None):
+    """Run `run_shard(lo, hi, f0, f1)` (-> tensor [hi-lo, T, 15, 3]) on this rank's window range and
+    all-gather the refined poses.  `starts` [n_windows] first frame of each window (same on all ranks)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n = len(starts)
+    lo, hi = shard_range(n, rank, world)
+    f0, f1 = frame_span(np.asarray(starts), lo, hi, seq_len)
+    local = run_shard(lo, hi, f0, f1)
+    return all_gather_windows(local, n, group)

@@ -67,8 +67,22 @@ def make_cameras(n_frames, step=0.004):
     return cams
 
 
-def make_sequence(n_frames=100, seed=1, camera=None, noise=0.02, sigma=1.5, with_heatmaps=True):
-    """Synthetic `test_data.pkl` content (numpy float64 poses/cams, float32 heat-maps)."""
+def jitter_cameras(cams, rng, rot_deg, trans_m):
+    """SLAM-like estimation noise: an independent small rotation (axis-angle, sigma rot_deg) and
+    translation offset (sigma trans_m) per frame.  The optimiser is given these noisy cameras while the
+    ground truth uses the true ones, like OpenVSLAM trajectories vs mocap in the reference's data."""
+    from scipy.spatial.transform import Rotation
+    n = cams.shape[0]
+    out = cams.copy()
+    R = Rotation.from_rotvec(rng.normal(0.0, np.deg2rad(rot_deg), size=(n, 3))).as_matrix()
+    out[:, :3, :3] = R @ cams[:, :3, :3]
+    out[:, :3, 3] = cams[:, :3, 3] + rng.normal(0.0, trans_m, size=(n, 3))
+    return out
+
+
+def make_sequence(n_frames=100, seed=1, camera=None, noise=0.02, sigma=1.5, with_heatmaps=True, cam_jitter=None):
+    """Synthetic `test_data.pkl` content (numpy float64 poses/cams, float32 heat-maps).
+    cam_jitter=(rot_deg, trans_m) adds SLAM-like noise to `camera_pose_list` (not to the ground truth)."""
     cam = camera or FisheyeCamera.from_json(DEFAULT_CALIBRATION)
     rng = np.random.default_rng(seed)
     clean = make_motion(n_frames, rng)
@@ -76,6 +90,8 @@ def make_sequence(n_frames=100, seed=1, camera=None, noise=0.02, sigma=1.5, with
     cams = make_cameras(n_frames)
     homo = np.concatenate([clean, np.ones(clean.shape[:2] + (1,))], axis=-1)
     gt_global = np.einsum("nij,nkj->nki", cams, homo)[..., :3]
+    if cam_jitter is not None:
+        cams = jitter_cameras(cams, rng, *cam_jitter)
     out = {
         "estimated_local_skeleton": [p for p in est],
         "gt_global_skeleton": [p for p in gt_global],
@@ -98,14 +114,14 @@ def make_training_windows(n_windows, seq_len, seed):
     return out
 
 
-def make_sequence_device(n_frames, seed, device, camera=None, noise=0.02, sigma=1.5, block=200):
+def make_sequence_device(n_frames, seed, device, camera=None, noise=0.02, sigma=1.5, block=200, cam_jitter=None):
     """Same content as `make_sequence`, with the big arrays created directly in HBM (torch is used as
     an allocator / elementwise engine here; this is input synthesis, not the measured path).
 
     Returns dict: est_local f32 [F,15,3], cams f64 [F,4,4], heat f32 [F,64,64,15] (device tensors) and
     gt_global / est_local_np / cams_np (host float64) for the metrics."""
     import torch
-    seq = make_sequence(n_frames, seed, camera, noise, sigma, with_heatmaps=False)
+    seq = make_sequence(n_frames, seed, camera, noise, sigma, with_heatmaps=False, cam_jitter=cam_jitter)
     est = np.asarray(seq["estimated_local_skeleton"])
     cams = np.asarray(seq["camera_pose_list"])
     cen = torch.as_tensor(seq["heatmap_centres"], dtype=torch.float32, device=device)      # [F,15,2]

@@ -1,0 +1,80 @@
+"""world_size-2 gloo tests of the sharding + all-gather path (CPU)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from globalegomocap_amd.dist import shard_range, frame_span, all_gather_windows, optimize_sharded
+from globalegomocap_amd.sequence import window_starts, merge_batches
+
+
+def test_shard_ranges_cover_everything_once():
+    for n in (0, 1, 7, 12, 240, 241, 65536):
+        for world in (1, 2, 3, 8):
+            r = [shard_range(n, k, world) for k in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
+            sizes = [hi - lo for lo, hi in r]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_frame_span_is_contiguous_and_minimal():
+    starts = np.concatenate([c * 100 + window_starts(100) for c in range(3)])
+    lo, hi = shard_range(len(starts), 1, 2)
+    f0, f1 = frame_span(starts, lo, hi, 10)
+    assert f0 == starts[lo] and f1 == starts[hi - 1] + 10
+    assert frame_span(starts, 5, 5, 10) == (0, 0)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_windows, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        starts = np.concatenate([c * 100 + window_starts(100) for c in range(2)])[:n_windows]
+        full = torch.arange(n_windows * 10 * 15 * 3, dtype=torch.float64).reshape(n_windows, 10, 15, 3)
+
+        def run_shard(lo, hi, f0, f1):
+            # stand-in for WindowEngine.optimize_windows on this rank's frames: returns its rows of `full`
+            assert (f0, f1) == frame_span(starts, lo, hi, 10)
+            return full[lo:hi].clone()
+
+        out = optimize_sharded(run_shard, starts)
+        ok = torch.equal(out, full)
+        # ragged float32 shard through the raw gather as well
+        lo, hi = shard_range(n_windows, rank, world)
+        g32 = all_gather_windows(full[lo:hi].float(), n_windows)
+        ok = ok and torch.equal(g32, full.float())
+        merged = merge_batches(out[:12].numpy())
+        q.put((rank, bool(ok), merged.shape))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_windows", [24, 23, 1])
+def test_two_rank_gather_reassembles_window_order(n_windows):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_windows, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, shape in res:
+        assert ok, rank
+        if n_windows >= 12:
+            assert shape == (98, 15, 3)
