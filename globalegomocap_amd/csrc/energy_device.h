@@ -1,0 +1,166 @@
+// Energy terms + analytic gradient of ONE window, executed by ONE wavefront (64 lanes).
+// Shared by the stand-alone energy kernel (energy.hip) and the fused decoder-tail kernel (tail.hip).
+// Reference: optimizer.py:139-149,172-177,202-213,226-240; utils/fisheye/FishEyeCalibrated.py:96-129.
+#pragma once
+#include "gem_internal.h"
+
+namespace gem {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+constexpr int MAXT = 16;               // frames per window supported by the LDS carve
+constexpr int MAXJ = GEM_MAX_JOINTS;
+constexpr int ENERGY_SCRATCH = MAXT * MAXJ * 3;     // floats per scratch array
+
+// BLOCK_SYNC: the workgroup is this one wavefront (plain __syncthreads); otherwise several wavefronts of
+// a workgroup each run their own window, and only the wavefront's own LDS traffic has to be ordered.
+template <bool BLOCK_SYNC>
+__device__ __forceinline__ void energy_sync() {
+    if (BLOCK_SYNC) {
+        __syncthreads();
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+}
+
+// xsrc: decoded pose rows [T][ldx] (global or LDS); xs/gs/bs/as: LDS scratch of ENERGY_SCRATCH floats each;
+// gdst: gradient rows [T][ldg], columns [J*3, gcols) are zero-filled.
+template <bool BLOCK_SYNC>
+__device__ __forceinline__ void energy_window(const EnergyArgs& a, int b, int lane, const float* xsrc, int ldx, float* xs,
+                                              float* gs, float* bs, float* as, float* gdst, int ldg, int gcols) {
+    const int T = a.T, J = a.J, JC = J * 3, n = T * JC;
+    const float* x0 = a.X0 + (size_t)b * n;
+
+    double e3d = 0, esm = 0, ebone = 0, evae = 0, erep = 0;
+    for (int e = lane; e < n; e += 64) {
+        const int t = e / JC, c = e - t * JC;
+        const float x = xsrc[t * ldx + c];
+        xs[e] = x;
+        const float d = x - x0[e];
+        e3d += (double)(d * d);
+        evae += (double)(x * x);
+        gs[e] = 2.f * a.w3d * d + 2.f * a.wv * x;
+    }
+    energy_sync<BLOCK_SYNC>();
+    // smoothness: acceleration a_t (t = 1..T-2) then gather
+    for (int e = lane; e < n; e += 64) {
+        const int t = e / JC;
+        float acc = 0.f;
+        if (t >= 1 && t <= T - 2) {
+            acc = xs[e - JC] - 2.f * xs[e] + xs[e + JC];
+            esm += (double)(acc * acc);
+        }
+        as[e] = acc;
+    }
+    // bone length: per (t, joint)
+    for (int p = lane; p < T * J; p += 64) {
+        const int t = p / J, j = p - t * J;
+        const int par = a.parents[j];
+        const float* xj = xs + (t * J + j) * 3;
+        const float* xp = xs + (t * J + par) * 3;
+        const float bx = xj[0] - xp[0], by = xj[1] - xp[1], bz = xj[2] - xp[2];
+        const float len = sqrtf(bx * bx + by * by + bz * bz);
+        const float diff = len - a.mean_bone[(size_t)b * J + j];
+        ebone += (double)(diff * diff);
+        const float coef = len > 0.f ? 2.f * a.wb * diff / len : 0.f;     // d|v|/dv := 0 at v = 0 (torch)
+        float* o = bs + (t * J + j) * 3;
+        o[0] = coef * bx; o[1] = coef * by; o[2] = coef * bz;
+    }
+    energy_sync<BLOCK_SYNC>();
+    for (int e = lane; e < n; e += 64) {
+        const int t = e / JC;
+        float g = gs[e];
+        const float w2 = 2.f * a.ws;
+        if (t >= 1 && t <= T - 2) g -= 2.f * w2 * as[e];
+        if (t >= 2) g += w2 * as[e - JC];
+        if (t <= T - 3) g += w2 * as[e + JC];
+        gs[e] = g;
+    }
+    energy_sync<BLOCK_SYNC>();
+    for (int p = lane; p < T * J; p += 64) {
+        const int t = p / J, j = p - t * J;
+        float gx = bs[p * 3 + 0], gy = bs[p * 3 + 1], gz = bs[p * 3 + 2];
+        const int* ch = a.children + j * MAXJ;
+        for (int q = 0; q < MAXJ && ch[q] >= 0; ++q) {
+            const float* o = bs + (t * J + ch[q]) * 3;
+            gx -= o[0]; gy -= o[1]; gz -= o[2];
+        }
+        // reprojection (only joints of frames whose heat-map exists)
+        if (a.wr != 0.f) {
+            const float x = xs[p * 3 + 0], y = xs[p * 3 + 1], z = xs[p * 3 + 2];
+            const float zz = -z;
+            const float nn = sqrtf(x * x + y * y);
+            // nn == 0 is rejected by the reference ("norm is zero!"); here it yields inf/nan in f, which
+            // the host wrapper turns into the same exception.
+            const float inv = 1.f / nn;
+            const float theta = atanf(zz / nn);
+            float rho = a.poly[0], drho = 0.f, ti = 1.f;
+            for (int i = 1; i < a.n_poly; ++i) {
+                drho += (float)i * a.poly[i] * ti;
+                ti *= theta;
+                rho += ti * a.poly[i];
+            }
+            const float ux = x * inv, uy = y * inv;
+            const float u = ux * rho + a.cx, v = uy * rho + a.cy;
+            // optimizer.py:143-147 + grid_sample(align_corners=True) un-normalisation
+            const float gxn = ((u - 128.f) - 512.f) / 512.f, gyn = (v - 512.f) / 512.f;
+            const float ix = ((gxn + 1.f) / 2.f) * (float)(a.W - 1);
+            const float iy = ((gyn + 1.f) / 2.f) * (float)(a.H - 1);
+            const float fx0 = floorf(ix), fy0 = floorf(iy);
+            const float fx = ix - fx0, fy = iy - fy0;
+            float nw = 0.f, ne = 0.f, sw = 0.f, se = 0.f;
+            // a projection that is not finite (or far outside) samples nothing, like zeros padding
+            if (fx0 >= -1.f && fx0 < (float)a.W && fy0 >= -1.f && fy0 < (float)a.H) {
+                const int x0i = (int)fx0, y0i = (int)fy0;
+                const float* hm = a.heat + ((size_t)(a.frame0[b] + t) * a.H * a.W) * J + j;
+                const bool xl = x0i >= 0, xr = x0i + 1 < a.W, yt = y0i >= 0, yb = y0i + 1 < a.H;
+                if (yt && xl) nw = hm[((size_t)y0i * a.W + x0i) * J];
+                if (yt && xr) ne = hm[((size_t)y0i * a.W + x0i + 1) * J];
+                if (yb && xl) sw = hm[((size_t)(y0i + 1) * a.W + x0i) * J];
+                if (yb && xr) se = hm[((size_t)(y0i + 1) * a.W + x0i + 1) * J];
+            }
+            const float gxw = 1.f - fx, gyw = 1.f - fy;
+            const float val = nw * gxw * gyw + ne * fx * gyw + sw * gxw * fy + se * fx * fy;
+            erep -= (double)val;
+            const float dix = (ne - nw) * gyw + (se - sw) * fy;
+            const float diy = (sw - nw) * gxw + (se - ne) * fx;
+            const float gu = -a.wr * dix * ((float)(a.W - 1) / 1024.f);
+            const float gv = -a.wr * diy * ((float)(a.H - 1) / 1024.f);
+            const float r2 = nn * nn + zz * zz;
+            const float dth_dn = -zz / r2, dth_dz = -nn / r2;
+            const float i3 = inv * inv * inv;
+            const float dudx = rho * (inv - x * x * i3) + ux * drho * dth_dn * ux;
+            const float dudy = rho * (-x * y * i3) + ux * drho * dth_dn * uy;
+            const float dudz = ux * drho * dth_dz;
+            const float dvdx = rho * (-x * y * i3) + uy * drho * dth_dn * ux;
+            const float dvdy = rho * (inv - y * y * i3) + uy * drho * dth_dn * uy;
+            const float dvdz = uy * drho * dth_dz;
+            gx += gu * dudx + gv * dvdx;
+            gy += gu * dudy + gv * dvdy;
+            gz += gu * dudz + gv * dvdz;
+        }
+        gs[p * 3 + 0] += gx; gs[p * 3 + 1] += gy; gs[p * 3 + 2] += gz;
+    }
+    energy_sync<BLOCK_SYNC>();
+    // gradient rows, zero-padded
+    for (int i = lane; i < T * gcols; i += 64) {
+        const int t = i / gcols, c = i - t * gcols;
+        gdst[t * ldg + c] = c < JC ? gs[t * JC + c] : 0.f;
+    }
+    e3d = wave_sum(e3d); esm = wave_sum(esm); ebone = wave_sum(ebone); evae = wave_sum(evae); erep = wave_sum(erep);
+    if (lane == 0) {
+        if (a.parts) {
+            double* p = a.parts + (size_t)b * 5;
+            p[0] = e3d; p[1] = esm; p[2] = ebone; p[3] = evae; p[4] = erep;
+        }
+        a.f[b] = a.dw3d * e3d + a.dws * esm + a.dwb * ebone + a.dwv * evae + a.dwr * erep;
+    }
+}
+
+}  // namespace gem

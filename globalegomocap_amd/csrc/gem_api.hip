@@ -2,6 +2,7 @@
 // evaluation rounds.  Host code only: weight folding / packing, workspace management and kernel
 // sequencing; all arithmetic of the path runs in the HIP kernels of gemm_f32.hip, energy.hip, lbfgs.hip.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 
@@ -81,6 +82,14 @@ static int make_conv_layers(StageNet& net, const FoldedConv& f, Layer* fwd, Laye
     for (int o = 0; o < f.co; ++o) bf[o] = (float)f.bias[o];
     fwd->taps = 3; fwd->K = Kp; fwd->N = Np;
     if (upload(net.allocs, &fwd->w, wf) || upload(net.allocs, &fwd->bias, bf)) return 1;
+    auto to_w4 = [](const std::vector<float>& w, int N, int K) {      // [tap][N][K] -> [tap][K/4][N][4]
+        std::vector<float> o(w.size());
+        for (int t = 0; t < 3; ++t)
+            for (int n = 0; n < N; ++n)
+                for (int k = 0; k < K; ++k) o[(((size_t)t * (K / 4) + k / 4) * N + n) * 4 + (k & 3)] = w[((size_t)t * N + n) * K + k];
+        return o;
+    };
+    if (bwd && upload(net.allocs, &fwd->w4, to_w4(wf, Np, Kp))) return 1;
     if (bwd) {
         // adjoint: dIn[r] = sum_tap' dOut[r + tap' - 1] . taps[2-tap']^T   ->  W[tap'][n=ci][k=co]
         std::vector<float> wb((size_t)3 * Kp * Np, 0.f);
@@ -88,7 +97,7 @@ static int make_conv_layers(StageNet& net, const FoldedConv& f, Layer* fwd, Laye
             for (int i = 0; i < f.ci; ++i)
                 for (int o = 0; o < f.co; ++o) wb[((size_t)k * Kp + i) * Np + o] = (float)f.taps[((size_t)(2 - k) * f.ci + i) * f.co + o];
         bwd->taps = 3; bwd->K = Np; bwd->N = Kp;
-        if (upload(net.allocs, &bwd->w, wb)) return 1;
+        if (upload(net.allocs, &bwd->w, wb) || upload(net.allocs, &bwd->w4, to_w4(wb, Kp, Np))) return 1;
         bwd->bias = nullptr;
     }
     return 0;
@@ -264,6 +273,13 @@ int gem_load_vae(gem_handle* h, int stage, int n_blobs, const float* const* blob
         if (add_dec(c.hidden[i], c.hidden[i - 1], true, true)) return 1;
     if (add_dec(c.hidden[0], c.hidden[0], true, true)) return 1;
     if (add_dec(c.hidden[0], C, false, false)) return 1;
+    // fuse as many trailing decoder convs as fit the LDS of one CU (tail.hip); GEM_NO_TAIL=1 disables it
+    net.tail_start = -1;
+    if (!getenv("GEM_NO_TAIL"))
+        for (int st = 1; st < (int)net.dec.size(); ++st) {
+            const size_t bytes = plan_tail(net.dec, st, T, h->J, nullptr);
+            if (bytes && bytes <= 160 * 1024) { net.tail_start = st; net.tail_lds = bytes; break; }
+        }
     net.loaded = true;
     return 0;
 }
@@ -310,12 +326,12 @@ static int decoder_forward(gem_handle* h, int stage, int B, const float* zp, hip
     return 0;
 }
 
-static int decoder_backward(gem_handle* h, int stage, int B, hipStream_t s) {
+// backward-data from decoder conv `from` down to the latent; gin = gradient w.r.t. the output of conv `from`
+static int decoder_backward(gem_handle* h, int stage, int B, hipStream_t s, int from, const float* gin) {
     StageNet& net = h->net[stage];
     Workspace& w = h->ws;
     const int rows = B * h->T;
-    const float* gin = w.dXp;
-    for (int i = (int)net.dec.size() - 1; i >= 0; --i) {
+    for (int i = from; i >= 0; --i) {
         const Layer& L = net.dec_bwd[i];
         const float* aux = i > 0 ? w.dec_act[i - 1] : nullptr;      // LeakyReLU' from the sign of the stored activation
         if (launch_gemm(h, L, i > 0 ? EPI_MASK : EPI_NONE, gin, L.K, aux, w.dec_grad[i], L.N, rows, h->T, s, -1)) return 1;
@@ -340,9 +356,34 @@ static EnergyArgs energy_args(gem_handle* h, const float* X0, const float* heat,
 }
 
 static int evaluate(gem_handle* h, int stage, int B, const float* zp, const EnergyArgs& ea, hipStream_t s) {
-    if (decoder_forward(h, stage, B, zp, s)) return 1;
-    if (launch_energy(h, ea, B, s)) return 1;
-    return decoder_backward(h, stage, B, s);
+    StageNet& net = h->net[stage];
+    Workspace& w = h->ws;
+    if (net.tail_start < 1) {
+        if (decoder_forward(h, stage, B, zp, s)) return 1;
+        if (launch_energy(h, ea, B, s)) return 1;
+        return decoder_backward(h, stage, B, s, (int)net.dec.size() - 1, w.dXp);
+    }
+    // wide layers as batched GEMMs, the narrow tail + energy + its adjoints in one kernel
+    const int st = net.tail_start, rows = B * h->T;
+    if (launch_gemm(h, net.dec_in, EPI_BIAS, zp, h->Dp, nullptr, w.h0, net.dec_in.N, B, h->T, s, 0)) return 1;
+    const float* in = w.h0;
+    for (int i = 0; i < st; ++i) {
+        if (launch_gemm(h, net.dec[i], EPI_BIAS_LRELU, in, net.dec[i].K, nullptr, w.dec_act[i], net.dec[i].N, rows, h->T, s, -1)) return 1;
+        in = w.dec_act[i];
+    }
+    TailArgs ta;
+    plan_tail(net.dec, st, h->T, h->J, &ta);
+    ta.B = B; ta.forward_only = 0;
+    for (int i = 0; i < ta.n; ++i) {
+        const Layer& f = net.dec[st + i];
+        const Layer& g = net.dec_bwd[st + i];
+        ta.fwd[i] = TailLayerDev{f.w4, f.bias, f.K, f.N};
+        ta.bwd[i] = TailLayerDev{g.w4, nullptr, g.K, g.N};
+    }
+    ta.a_in = w.dec_act[st - 1]; ta.g_out = w.dec_grad[st]; ta.Xp = w.dec_act.back();
+    ta.e = ea;
+    if (launch_tail(h, ta, net.tail_lds, s)) return 1;
+    return decoder_backward(h, stage, B, s, st - 1, w.dec_grad[st]);
 }
 
 static int optimize_stage_impl(gem_handle* h, int stage, int B, const float* d_pose_in, const float* d_heat,

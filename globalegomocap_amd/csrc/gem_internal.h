@@ -29,6 +29,7 @@ struct Layer {
     int K = 0, N = 0;      // padded
     float* w = nullptr;    // device, [taps][N][K], k contiguous
     float* bias = nullptr; // device, [N] (forward layers only)
+    float* w4 = nullptr;   // device, [taps][K/4][N][4]: layout of the fused decoder-tail kernel (conv layers only)
 };
 
 struct StageNet {
@@ -39,6 +40,8 @@ struct StageNet {
     std::vector<Layer> dec;        // decoder convs, last one without activation
     Layer dec_in_bwd;              // backward-data twins (no bias)
     std::vector<Layer> dec_bwd;    // dec_bwd[i] is the adjoint of dec[i]
+    int tail_start = -1;           // decoder convs [tail_start, end) run in the fused tail kernel (-1: none)
+    size_t tail_lds = 0;
     std::vector<void*> allocs;
 };
 
@@ -131,6 +134,21 @@ struct EnergyArgs {
     const int* children;
 };
 int launch_energy(gem_handle* h, const EnergyArgs& a, int B, hipStream_t s);
+
+// fused decoder tail (tail.hip)
+constexpr int TAIL_MAX_LAYERS = 6;
+struct TailLayerDev { const float* w4; const float* bias; int K, N; };
+struct TailArgs {
+    int n, B, G, forward_only, escr;
+    TailLayerDev fwd[TAIL_MAX_LAYERS], bwd[TAIL_MAX_LAYERS];
+    const float* a_in;       // [B*T, K0] input activation of the first fused layer
+    float* g_out;            // [B*T, K0] gradient w.r.t. its pre-activation
+    float* Xp;               // [B*T, 64] decoded pose
+    int off_act[TAIL_MAX_LAYERS + 1], ld_act[TAIL_MAX_LAYERS + 1], off_g[2], ld_g, off_red, off_escr;   // LDS plan (floats)
+    EnergyArgs e;
+};
+size_t plan_tail(const std::vector<Layer>& dec, int start, int T, int J, TailArgs* out);
+int launch_tail(gem_handle* h, const TailArgs& a, size_t lds_bytes, hipStream_t s);
 int launch_mean_bone(gem_handle* h, const float* pose, int n_frames, float* out, hipStream_t s);
 int launch_gather_windows(const float* frames, const int32_t* frame0, float* out, int B, int T, int JC, hipStream_t s);
 int launch_relative_global(const float* local, const double* cams, const int32_t* frame0, float* rel, int B, int T, int J,
