@@ -55,16 +55,19 @@ __device__ __forceinline__ double cubic_interpolate(double x1, double f1, double
     return (lo + hi) / 2.0;
 }
 
+// Block-wide reductions with ONE barrier each: partials go to alternating 4-entry LDS slots, so the next
+// reduction cannot overwrite values a slow wave has not read yet (a slot is reused two barriers later).
 struct BlockRed {
-    double* red;
+    double* red;      // [2][4]
+    int parity;
     __device__ __forceinline__ double sum(double v) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+        double* r = red + 4 * parity;
+        parity ^= 1;
+        if ((threadIdx.x & 63) == 0) r[threadIdx.x >> 6] = v;
         __syncthreads();
-        const double r = red[0] + red[1] + red[2] + red[3];
-        __syncthreads();
-        return r;
+        return r[0] + r[1] + r[2] + r[3];
     }
     __device__ __forceinline__ double max(double v) {
 #pragma unroll
@@ -72,25 +75,26 @@ struct BlockRed {
             const double w = __shfl_xor(v, o, 64);
             v = (w > v || w != w) ? w : v;       // NaN wins, like torch's max
         }
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+        double* r = red + 4 * parity;
+        parity ^= 1;
+        if ((threadIdx.x & 63) == 0) r[threadIdx.x >> 6] = v;
         __syncthreads();
-        double r = red[0];
-        for (int i = 1; i < 4; ++i) r = (red[i] > r || red[i] != red[i]) ? red[i] : r;
-        __syncthreads();
-        return r;
+        double m = r[0];
+        for (int i = 1; i < 4; ++i) m = (r[i] > m || r[i] != r[i]) ? r[i] : m;
+        return m;
     }
 };
 
 template <int EPT>
 __global__ __launch_bounds__(256) void lbfgs_advance_kernel(AdvArgs a) {
-    __shared__ double red[4];
+    __shared__ double red[8];
     __shared__ double ro_s[MAX_HIST];
     __shared__ double al_s[MAX_HIST];
     const int b = blockIdx.x, tid = threadIdx.x;
     LbfgsState* sp = a.state + b;
     int phase = sp->phase;
     if (phase == PH_DONE) return;
-    BlockRed R{red};
+    BlockRed R{red, 0};
     const gem_lbfgs_opts& o = a.o;
     const int Dp = a.Dp;
     const size_t off = (size_t)b * Dp;
@@ -309,34 +313,38 @@ __global__ __launch_bounds__(256) void lbfgs_advance_kernel(AdvArgs a) {
             float q[EPT];
 #pragma unroll
             for (int i = 0; i < EPT; ++i) q[i] = -gcur[i];
+            // two-loop recursion; the (s, y) pair of the next step is in flight during each reduction
+            auto pair_ptr = [&](const float* base, int k) {
+                const int slot = (hist_start + k) % a.hist_cap;
+                return base + ((size_t)b * a.hist_cap + slot) * Dp - off;
+            };
+            float sk[EPT], yk[EPT], sn[EPT], yn[EPT];
+            if (hist_count > 0) { load(pair_ptr(a.S, hist_count - 1), sk); load(pair_ptr(a.Y, hist_count - 1), yk); }
             for (int k = hist_count - 1; k >= 0; --k) {
                 const int slot = (hist_start + k) % a.hist_cap;
-                const float* Ss = a.S + ((size_t)b * a.hist_cap + slot) * Dp - off;
-                const float* Ys = a.Y + ((size_t)b * a.hist_cap + slot) * Dp - off;
-                float sk[EPT], yk[EPT];
-                load(Ss, sk);
-                load(Ys, yk);
+                const int kn = k > 0 ? k - 1 : 0;
+                load(pair_ptr(a.S, kn), sn);
+                load(pair_ptr(a.Y, kn), yn);
                 const double al = dot(sk, q) * ro_s[slot];
                 if (tid == 0) al_s[k] = al;
                 const float alf = (float)al;
 #pragma unroll
-                for (int i = 0; i < EPT; ++i) q[i] -= alf * yk[i];
+                for (int i = 0; i < EPT; ++i) { q[i] -= alf * yk[i]; sk[i] = sn[i]; yk[i] = yn[i]; }
             }
             __syncthreads();
             const float hd = (float)H_diag;
 #pragma unroll
             for (int i = 0; i < EPT; ++i) q[i] *= hd;
+            // after the first loop sk/yk hold pair 0 again (kn = 0 on its last step)
             for (int k = 0; k < hist_count; ++k) {
                 const int slot = (hist_start + k) % a.hist_cap;
-                const float* Ss = a.S + ((size_t)b * a.hist_cap + slot) * Dp - off;
-                const float* Ys = a.Y + ((size_t)b * a.hist_cap + slot) * Dp - off;
-                float sk[EPT], yk[EPT];
-                load(Ys, yk);
-                load(Ss, sk);
+                const int kn = k + 1 < hist_count ? k + 1 : k;
+                load(pair_ptr(a.S, kn), sn);
+                load(pair_ptr(a.Y, kn), yn);
                 const double be = dot(yk, q) * ro_s[slot];
                 const float cf = (float)(al_s[k] - be);
 #pragma unroll
-                for (int i = 0; i < EPT; ++i) q[i] += cf * sk[i];
+                for (int i = 0; i < EPT; ++i) { q[i] += cf * sk[i]; sk[i] = sn[i]; yk[i] = yn[i]; }
             }
 #pragma unroll
             for (int i = 0; i < EPT; ++i) dv[i] = q[i];
