@@ -240,3 +240,77 @@ def test_single_window_interface(torch_cuda, golden):
     with pytest.raises(RuntimeError):
         BodyPoseOptimizer(DEFAULT_CALIBRATION, torch.from_numpy(pose).float(), sd_from_npz(g, "local/"), seq_len=10,
                           network_seq_len=10, latent_dim=2048)
+
+
+def test_window_pipeline_with_rotating_cameras_against_oracle(torch_cuda, golden):
+    """gem_optimize_windows (both stages + fp64 rigid transforms) on SLAM-like jittered cameras."""
+    import torch
+    from globalegomocap_amd.engine import WindowEngine, stats_to_numpy
+    from globalegomocap_amd.sequence import window_starts
+    lt = golden("lbfgs_tiny")
+    sd_l, sd_g = sd_from_npz(lt, "local/"), sd_from_npz(lt, "global/")
+    data = synth.make_sequence(n_frames=34, seed=13, cam_jitter=(1.0, 0.004))
+    est = np.asarray(data["estimated_local_skeleton"])
+    cams = np.asarray(data["camera_pose_list"])
+    heat = np.asarray(data["heatmap_list"], dtype=np.float32)
+    starts = window_starts(34)                       # 0, 8, 16, 24
+    B = len(starts)
+    eng = _engine(TINY, max_windows=8)
+    eng.load_vae(0, sd_l)
+    eng.load_vae(1, sd_g)
+    dev = eng.device
+    rng = np.random.default_rng(5)
+    eps = rng.normal(size=(2 * B, 32)).astype(np.float32)
+    w_l, w_g = (1e-4, 1e-3, 1e-2, 0.0, 1e-2), (1.0, 0.1, 1e-2, 0.0, 0.0)
+    pose_d = torch.as_tensor(est, dtype=torch.float32, device=dev).contiguous()
+    mb = eng.mean_bone_length(pose_d).reshape(1, 15).expand(B, 15).contiguous()
+    e3 = torch.as_tensor(eps.reshape(B, 2, 32))
+    mid, glob, stats = eng.optimize_windows(pose_d, torch.as_tensor(cams, dtype=torch.float64, device=dev).contiguous(),
+                                            torch.as_tensor(heat, device=dev).contiguous(),
+                                            torch.as_tensor(starts, dtype=torch.int32, device=dev), mb,
+                                            e3[:, 0].contiguous().to(dev), e3[:, 1].contiguous().to(dev), _ew(w_l), _ew(w_g))
+    st = stats_to_numpy(stats)
+    assert (st["status"] == 1).all()
+    ref = O.optimize_sequence(data, O.fold_vae(sd_l), O.fold_vae(sd_g), oracle_camera(), eps, O.Weights(*w_l), O.Weights(*w_g))
+    from globalegomocap_amd.sequence import merge_batches
+    got_opt, got_mid = merge_batches(glob.cpu().numpy()), merge_batches(mid.cpu().numpy())
+    d_mid = np.linalg.norm(got_mid - ref["mid_local"], axis=-1).mean()
+    d_opt = np.linalg.norm(got_opt - ref["opt"], axis=-1).mean()
+    assert d_mid < 1e-3 and d_opt < 1e-3, (d_mid, d_opt)
+    gt = ref["gt"]
+    assert abs(np.linalg.norm(got_opt - gt, axis=-1).mean() - np.linalg.norm(ref["opt"] - gt, axis=-1).mean()) < 0.5e-3
+
+
+def test_full_size_batch_properties_at_baseline_size(torch_cuda):
+    """BASELINE configs[1] size (240 windows, D=2048): size-independent properties of the batched optimiser."""
+    import torch
+    from globalegomocap_amd.engine import stats_to_numpy
+    from globalegomocap_amd.sequence import window_starts
+    sd = vae_schema.synthetic_state_dict(FULL, 5)
+    n_chunks, B = 20, 240
+    eng = _engine(FULL, max_windows=B)
+    eng.load_vae(0, sd)
+    seq = synth.make_sequence_device(n_chunks * 100, seed=77, device=eng.device)
+    starts = np.concatenate([c * 100 + window_starts(100) for c in range(n_chunks)]).astype(np.int32)
+    est = seq["est_local_np"].astype(np.float32)
+    pose = np.stack([est[s:s + 10] for s in starts])
+    mb = eng.mean_bone_length(est[:100])
+    rng = np.random.default_rng(9)
+    eps = rng.normal(size=(B, 2048)).astype(np.float32)
+    w = _ew((1e-1, 1e-1, 1.0, 1e-3, 1e-2))                     # strong weights: the random-init net iterates
+    mu, lv, z0 = eng.encode(0, pose.reshape(B, 10, 45), eps)
+    E0, _, _, _ = eng.energy_grad(0, z0, pose, mb, w, seq["heat"], starts)
+    out, stats = eng.optimize_stage(0, pose, mb, eps, w, seq["heat"], starts)
+    st = stats_to_numpy(stats)
+    assert (st["status"] == 1).all()
+    assert (st["func_evals"] <= 32).all() and (st["n_iter"] <= 25).all() and (st["func_evals"] >= 1).all()
+    # Armijo: the accepted loss never exceeds the loss at z0
+    assert (st["final_loss"] <= E0.cpu().numpy().astype(np.float32) * (1 + 1e-6) + 1e-6).all()
+    assert st["func_evals"].mean() > 20
+    # determinism and permutation equivariance (windows are independent): bitwise
+    out2, stats2 = eng.optimize_stage(0, pose, mb, eps, w, seq["heat"], starts)
+    assert torch.equal(out, out2) and torch.equal(stats, stats2)
+    perm = rng.permutation(B)
+    out3, stats3 = eng.optimize_stage(0, pose[perm], mb, eps[perm], w, seq["heat"], starts[perm])
+    assert torch.equal(out3, out[torch.as_tensor(perm, device=out.device)])
+    assert np.isfinite(out.cpu().numpy()).all()

@@ -169,3 +169,25 @@ def test_sequence_pipeline_matches_reference_main(golden):
     assert mid < 0.5e-3 and fin < 0.5e-3, (mid, fin)
     mpjpe = np.linalg.norm(res["opt"] - res["gt"], axis=-1).mean()
     assert abs(mpjpe - float(g["err_smooth/optimized_global_mpjpe"])) < 0.5e-3
+
+
+def test_torch_port_cpu_baseline_matches_reference(golden):
+    """The PyTorch-CPU port that bench.py times as `cpu_baseline` reproduces the reference's stage."""
+    import torch
+    from oracle import torch_port as TP
+    from globalegomocap_amd.camera import FisheyeCamera
+    torch.set_num_threads(1)
+    g = golden("lbfgs_tiny")
+    cam = FisheyeCamera.from_json(DEFAULT_CALIBRATION)
+    pose, heat = g["pose"], heat_from_centres(g["heat_centres"])
+    for tag, prefix, w in (("local", "local/", (1e-6, 1e-5, 1e-2, 0.0, 1e-2)), ("global", "global/", (1e-2, 1e-3, 1e-2, 0.0, 0.0))):
+        net = TP.vae_from_state_dict(sd_from_npz(g, prefix))
+        opt = TP.WindowOptimizerPort(net, cam.poly_w2c, cam.cx, cam.cy, pose)
+        opt.set_weights(*w)
+        out, st = opt.optimize(pose, heat, g[tag + "_eps"])
+        ref = g[tag + "_trace"]
+        got = np.array([t[0] for t in st["trace"]])
+        assert len(got) == len(ref)
+        np.testing.assert_allclose(got[:4], ref[:4], rtol=1e-4, atol=1e-8)
+        np.testing.assert_allclose(got[:8], ref[:8], rtol=5e-3, atol=1e-7)
+        assert np.linalg.norm(out - g[tag + "_out"], axis=-1).mean() < 0.5e-3
