@@ -97,9 +97,11 @@ __global__ __launch_bounds__(64) void energy_kernel(EnergyArgs a) {
     __shared__ float gs[ENERGY_SCRATCH];      // gradient accumulator
     __shared__ float bs[ENERGY_SCRATCH];      // coef * bone vector of joint j (for the parent gather)
     __shared__ float as[ENERGY_SCRATCH];      // accelerations
-    const int b = blockIdx.x;
-    energy_window<true>(a, b, threadIdx.x, a.Xp + (size_t)b * a.T * PAD, PAD, xs, gs, bs, as, a.dXp + (size_t)b * a.T * PAD, PAD,
-                        PAD);
+    const int slot = blockIdx.x;
+    if (a.n_dev && slot >= *a.n_dev) return;
+    const int b = a.perm ? a.perm[slot] : slot;
+    energy_window<true>(a, b, threadIdx.x, a.Xp + (size_t)slot * a.T * PAD, PAD, xs, gs, bs, as, a.dXp + (size_t)slot * a.T * PAD,
+                        PAD, PAD);
 }
 
 int launch_energy(gem_handle* h, const EnergyArgs& a, int B, hipStream_t s) {

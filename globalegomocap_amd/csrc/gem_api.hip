@@ -164,6 +164,9 @@ int gem_create(const gem_config* cfg, gem_handle** out) {
     if (dev_alloc(w.allocs, &w.parts, (size_t)B * 5)) return 1;
     if (dev_alloc(w.allocs, &w.pose_a, rows * h->C)) return 1;
     if (dev_alloc(w.allocs, &w.pose_b, rows * h->C)) return 1;
+    if (dev_alloc(w.allocs, &w.n_log, (size_t)N_LOG)) return 1;
+    if (dev_alloc(w.allocs, &w.perm, (size_t)B) || dev_alloc(w.allocs, &w.slot_of, (size_t)B) || dev_alloc(w.allocs, &w.n_active, 2))
+        return 1;
     w.splitk_elems = (size_t)8 << 20;      // 32 MB: split-K is only used while a layer has < 640 output tiles
     if (dev_alloc(w.allocs, &w.splitk, w.splitk_elems)) return 1;
     std::vector<int> parents(cfg->parents, cfg->parents + cfg->n_joints);
@@ -316,7 +319,7 @@ static int decoder_forward(gem_handle* h, int stage, int B, const float* zp, hip
     StageNet& net = h->net[stage];
     Workspace& w = h->ws;
     const int rows = B * h->T;
-    if (launch_gemm(h, net.dec_in, EPI_BIAS, zp, h->Dp, nullptr, w.h0, net.dec_in.N, B, h->T, s, 0)) return 1;
+    if (launch_gemm(h, net.dec_in, EPI_BIAS, zp, h->Dp, nullptr, w.h0, net.dec_in.N, B, h->T, s, 0, w.dyn ? w.perm : nullptr)) return 1;
     const float* in = w.h0;
     for (size_t i = 0; i < net.dec.size(); ++i) {
         const int epi = (i + 1 < net.dec.size()) ? EPI_BIAS_LRELU : EPI_BIAS;
@@ -352,6 +355,8 @@ static EnergyArgs energy_args(gem_handle* h, const float* X0, const float* heat,
     for (int i = 0; i < GEM_MAX_POLY; ++i) a.poly[i] = i < h->cfg.n_poly ? (float)h->cfg.poly[i] : 0.f;
     a.cx = (float)h->cfg.cx; a.cy = (float)h->cfg.cy;
     a.parents = h->d_parents; a.children = h->d_children;
+    a.n_dev = w.dyn ? w.n_active : nullptr;
+    a.perm = w.dyn ? w.perm : nullptr;
     return a;
 }
 
@@ -365,7 +370,7 @@ static int evaluate(gem_handle* h, int stage, int B, const float* zp, const Ener
     }
     // wide layers as batched GEMMs, the narrow tail + energy + its adjoints in one kernel
     const int st = net.tail_start, rows = B * h->T;
-    if (launch_gemm(h, net.dec_in, EPI_BIAS, zp, h->Dp, nullptr, w.h0, net.dec_in.N, B, h->T, s, 0)) return 1;
+    if (launch_gemm(h, net.dec_in, EPI_BIAS, zp, h->Dp, nullptr, w.h0, net.dec_in.N, B, h->T, s, 0, w.dyn ? w.perm : nullptr)) return 1;
     const float* in = w.h0;
     for (int i = 0; i < st; ++i) {
         if (launch_gemm(h, net.dec[i], EPI_BIAS_LRELU, in, net.dec[i].K, nullptr, w.dec_act[i], net.dec[i].N, rows, h->T, s, -1)) return 1;
@@ -380,7 +385,7 @@ static int evaluate(gem_handle* h, int stage, int B, const float* zp, const Ener
         ta.fwd[i] = TailLayerDev{f.w4, f.bias, f.K, f.N};
         ta.bwd[i] = TailLayerDev{g.w4, nullptr, g.K, g.N};
     }
-    ta.a_in = w.dec_act[st - 1]; ta.g_out = w.dec_grad[st]; ta.Xp = w.dec_act.back();
+    ta.a_in = w.dec_act[st - 1]; ta.g_out = w.dec_grad[st]; ta.Xp = w.dyn ? nullptr : w.dec_act.back();     // the pose is only read back outside the rounds
     ta.e = ea;
     if (launch_tail(h, ta, net.tail_lds, s)) return 1;
     return decoder_backward(h, stage, B, s, st - 1, w.dec_grad[st]);
@@ -399,12 +404,22 @@ static int optimize_stage_impl(gem_handle* h, int stage, int B, const float* d_p
     if (encoder_forward(h, stage, B, d_pose_in, s)) return 1;
     if (launch_reparam(w.mulv, d_eps, nullptr, nullptr, nullptr, w.trial, B, h->D, h->Dp, s)) return 1;
     if (launch_lbfgs_init(h, B, opt, s)) return 1;
+    // Rounds run on the windows that are still iterating: after every advance they are re-packed to the front
+    // (perm / n_active on the device) and the kernels of the next round read their row count from there.
+    static const bool no_compact = getenv("GEM_NO_COMPACT") != nullptr;
+    if (!no_compact) {
+        if (launch_compact(h, B, 1, s)) return 1;
+        w.dyn = true;
+    }
     const EnergyArgs ea = energy_args(h, d_pose_in, d_heat, d_frame0, d_mean_bone, wt);
     const int rounds = opt.max_eval + 1;          // upper bound on evaluations per window (see lbfgs.hip)
-    for (int r = 0; r < rounds; ++r) {
-        if (evaluate(h, stage, B, w.trial, ea, s)) return 1;
-        if (launch_lbfgs_advance(h, B, opt, s)) return 1;
+    int rc = 0;
+    for (int r = 0; r < rounds && !rc; ++r) {
+        rc = evaluate(h, stage, B, w.trial, ea, s) || launch_lbfgs_advance(h, B, opt, s);
+        if (!rc && w.dyn) rc = launch_compact(h, B, 0, s);
     }
+    w.dyn = false;
+    if (rc) return 1;
     // every window is finished now: trial == x*
     if (decoder_forward(h, stage, B, w.trial, s)) return 1;
     if (launch_unpack_pose(w.dec_act.back(), d_pose_out, B * h->T, h->C, s)) return 1;
@@ -506,10 +521,18 @@ int gem_profile_read(gem_handle* h, int family, double* total_ms, int64_t* n_lau
     GEM_HIP(hipSetDevice(h->cfg.device));
     Profile& p = h->prof;
     // fold finished event pairs into the totals (caller has synchronised the stream)
+    std::vector<int> nlog;
     for (auto& r : p.recs) {
         float ms = 0.f;
         GEM_HIP(hipEventSynchronize(r.b));
         GEM_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+        if (r.log_idx >= 0) {          // compacted round: FLOPs of the rows that were actually active
+            if (nlog.empty()) {
+                nlog.resize(N_LOG);
+                GEM_HIP(hipMemcpy(nlog.data(), h->ws.n_log, (size_t)N_LOG * sizeof(int), hipMemcpyDeviceToHost));
+            }
+            if (h->ws.log_pos - r.log_idx <= N_LOG) r.flops = r.flops_per_window * nlog[r.log_idx % N_LOG];
+        }
         p.total_ms[r.family] += ms;
         p.n[r.family] += 1;
         p.flops[r.family] += r.flops;

@@ -13,6 +13,7 @@ constexpr int PAD = 64;                    // every feature dimension is zero-pa
 constexpr float LEAKY_SLOPE = 0.01f;       // torch.nn.LeakyReLU default (SeqConvVAE.py:38,77,90)
 constexpr double BN_EPS = 1e-5;            // torch.nn.BatchNorm1d default
 constexpr int MAX_HIST = 128;              // capacity of the per-window (s,y) ring
+constexpr int N_LOG = 1 << 16;             // ring of active-window counts kept for the profiling hook
 
 inline int pad64(int x) { return (x + PAD - 1) / PAD * PAD; }
 
@@ -79,12 +80,19 @@ struct Workspace {
     float* pose_b = nullptr;
     float* splitk = nullptr;            // partial slabs of the split-K GEMM launches
     size_t splitk_elems = 0;
+    // active-window compaction (lbfgs.hip compact_kernel): windows still iterating occupy slots [0, n_active)
+    int* perm = nullptr;                // [B] slot -> window
+    int* slot_of = nullptr;             // [B] window -> slot
+    int* n_active = nullptr;            // [2] = {n_active, n_active*T}
+    bool dyn = false;                   // rounds in flight: GEMM / energy launches read their row count from n_active
+    int* n_log = nullptr;               // [N_LOG] n_active after every compaction (profiling: true row counts)
+    long log_pos = 0, cur_log = -1;
     std::vector<void*> allocs;
 };
 
 struct Profile {
     bool on = false;
-    struct Rec { hipEvent_t a, b; int family; double flops; };
+    struct Rec { hipEvent_t a, b; int family; double flops; long log_idx = -1; double flops_per_window = 0; };
     std::vector<Rec> recs;
     double total_ms[3] = {0, 0, 0};
     int64_t n[3] = {0, 0, 0};
@@ -107,7 +115,7 @@ namespace gem {
 
 // ---- kernel launchers (each enqueues on `s`, returns 0/1) -------------------------------------------
 int launch_gemm(gem_handle* h, const Layer& L, int epi, const float* A, int lda, const float* aux, float* Cout, int ldc,
-                int M, int T, hipStream_t s, int family);
+                int M, int T, hipStream_t s, int family, const int* row_map = nullptr);
 
 int launch_pack_pose(const float* src, float* dst, int rows, int C, hipStream_t s);      // [rows,C] -> [rows,64]
 int launch_unpack_pose(const float* src, float* dst, int rows, int C, hipStream_t s);    // [rows,64] -> [rows,C]
@@ -132,6 +140,8 @@ struct EnergyArgs {
     float cx, cy;
     const int* parents;
     const int* children;
+    const int* n_dev;         // device count of active slots (nullptr: all B)
+    const int* perm;          // slot -> window (nullptr: identity); X / dX rows are slot-ordered, the rest window-ordered
 };
 int launch_energy(gem_handle* h, const EnergyArgs& a, int B, hipStream_t s);
 
@@ -159,5 +169,6 @@ int launch_to_global(const float* rel, const double* cams, const int32_t* frame0
 int launch_lbfgs_init(gem_handle* h, int B, const gem_lbfgs_opts& o, hipStream_t s);
 int launch_lbfgs_advance(gem_handle* h, int B, const gem_lbfgs_opts& o, hipStream_t s);
 int launch_lbfgs_stats(gem_handle* h, int B, gem_window_stats* out, hipStream_t s);
+int launch_compact(gem_handle* h, int B, int force_all, hipStream_t s);
 
 }  // namespace gem

@@ -31,7 +31,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                                                        const float* __restrict__ bias,
                                                        const float* __restrict__ aux, float* __restrict__ C,
                                                        int ldc, int M, int N, int K, int T, int tiles_per_slice,
-                                                       size_t slab_stride) {
+                                                       size_t slab_stride, const int* __restrict__ m_dev,
+                                                       const int* __restrict__ row_map) {
     constexpr int BM = 64 * RM, BN = 64 * RN;
     constexpr int LDS_LD = BK + 4;
     constexpr int TPR = BK / 4;             // threads per tile row (one float4 each)
@@ -45,6 +46,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    if (m_dev) M = *m_dev;                 // rows in use this round (active windows are compacted to the front)
+    if (m0 >= M) return;
     const int kTiles = K / BK;
     // split-K: blockIdx.z owns k-tiles [kt_begin, kt_end) of the TAPS*K/BK tiles and writes a raw partial slab
     const bool split = gridDim.z > 1;
@@ -55,11 +58,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     // ---- per-thread global load coordinates (branch-free: out-of-range rows read row 0 and are zeroed)
     const int c4 = (tid % TPR) * 4;
     const int lrow = tid / TPR;
-    int a_row[A_LD4], a_t[A_LD4];
+    int a_row[A_LD4], a_t[A_LD4], a_src[A_LD4];
 #pragma unroll
     for (int i = 0; i < A_LD4; ++i) {
         a_row[i] = m0 + lrow + RPP * i;
         a_t[i] = (TAPS == 3) ? (a_row[i] % T) : 0;
+        a_src[i] = (TAPS == 1 && row_map && a_row[i] < M) ? row_map[a_row[i]] : a_row[i];    // gathered A rows (linear only)
     }
     f32x4 ra[A_LD4], rb[B_LD4];
     bool a_ok[A_LD4];
@@ -74,7 +78,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                 const int tt_ = a_t[i] + tap_ - 1;                                                           \
                 ok_ = ok_ && tt_ >= 0 && tt_ < T;                                                            \
             }                                                                                                \
-            const int src_ = ok_ ? a_row[i] + ((TAPS == 3) ? tap_ - 1 : 0) : 0;                              \
+            const int src_ = ok_ ? a_src[i] + ((TAPS == 3) ? tap_ - 1 : 0) : 0;                               \
             ra[i] = *reinterpret_cast<const f32x4*>(A + (size_t)src_ * lda + k0_);                           \
             a_ok[i] = ok_;  /* zeroing happens at the LDS store, after the MFMAs: no wait on the load here */ \
         }                                                                                                    \
@@ -167,7 +171,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 template <int EPI>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int nslab, size_t slab_stride,
                                                             const float* __restrict__ bias, const float* __restrict__ aux,
-                                                            float* __restrict__ C, int M, int N, int ldc) {
+                                                            float* __restrict__ C, int M, int N, int ldc,
+                                                            const int* __restrict__ m_dev) {
+    if (m_dev) M = *m_dev;
     const int n4 = N / 4;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)M * n4) return;
@@ -212,7 +218,9 @@ static int pick_splitk(const gem_handle* h, long blocks, int n_tiles, size_t sla
 
 template <int TAPS, int EPI, int RM, int RN, int TAG, int BK>
 static int launch_one(gem_handle* h, const Layer& L, const float* A, int lda, const float* aux, float* C, int ldc, int M, int T,
-                      hipStream_t s) {
+                      hipStream_t s, const int* row_map) {
+    // during the evaluation rounds the row count lives on the device: {n_active, n_active*T}
+    const int* m_dev = h->ws.dyn ? h->ws.n_active + (TAPS == 3 ? 1 : 0) : nullptr;
     constexpr int BM = 64 * RM, BN = 64 * RN;
     size_t shmem = (RM * RN > 1 ? 2 : 1) * (size_t)(BM + BN) * (BK + 4) * sizeof(float);
     auto k = gemm_f32_kernel<TAPS, EPI, RM, RN, TAG, BK>;
@@ -235,34 +243,36 @@ static int launch_one(gem_handle* h, const Layer& L, const float* A, int lda, co
         if (want > shmem) shmem = want;
     }
     if (grid.z == 1) {
-        hipLaunchKernelGGL(k, grid, dim3(256), shmem, s, A, lda, L.w, L.bias, aux, C, ldc, M, L.N, L.K, T, n_tiles, (size_t)0);
+        hipLaunchKernelGGL(k, grid, dim3(256), shmem, s, A, lda, L.w, L.bias, aux, C, ldc, M, L.N, L.K, T, n_tiles, (size_t)0, m_dev,
+                           row_map);
         GEM_HIP(hipGetLastError());
         return 0;
     }
-    hipLaunchKernelGGL(k, grid, dim3(256), shmem, s, A, lda, L.w, L.bias, aux, h->ws.splitk, ldc, M, L.N, L.K, T, per, slab);
+    hipLaunchKernelGGL(k, grid, dim3(256), shmem, s, A, lda, L.w, L.bias, aux, h->ws.splitk, ldc, M, L.N, L.K, T, per, slab, m_dev,
+                       row_map);
     GEM_HIP(hipGetLastError());
     const size_t n4 = (size_t)M * (L.N / 4);
     hipLaunchKernelGGL(splitk_reduce_kernel<EPI>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, h->ws.splitk, (int)grid.z, slab,
-                       L.bias, aux, C, M, L.N, ldc);
+                       L.bias, aux, C, M, L.N, ldc, m_dev);
     GEM_HIP(hipGetLastError());
     return 0;
 }
 
 template <int TAPS, int EPI, int TAG>
 static int launch_tile(gem_handle* h, const Layer& L, const float* A, int lda, const float* aux, float* C, int ldc, int M, int T,
-                       hipStream_t s) {
+                       hipStream_t s, const int* row_map) {
     // 128x128 tiles only when they still fill the chip (>= 2 workgroups per CU) and divide N
     const long big_blocks = (long)((M + 127) / 128) * (L.N / 128);
     static const char* force = getenv("GEM_FORCE_TILE");       // developer override: "1" = 64x64, "2" = 128x128, "3" = 64x64 BK64
-    if (force && force[0] == '1') return launch_one<TAPS, EPI, 1, 1, TAG, 32>(h, L, A, lda, aux, C, ldc, M, T, s);
-    if (force && force[0] == '2' && L.N % 128 == 0) return launch_one<TAPS, EPI, 2, 2, TAG, 32>(h, L, A, lda, aux, C, ldc, M, T, s);
-    if (force && force[0] == '3' && L.K % 64 == 0) return launch_one<TAPS, EPI, 1, 1, TAG, 64>(h, L, A, lda, aux, C, ldc, M, T, s);
-    if (L.N % 128 == 0 && big_blocks >= 512) return launch_one<TAPS, EPI, 2, 2, TAG, 32>(h, L, A, lda, aux, C, ldc, M, T, s);
-    return launch_one<TAPS, EPI, 1, 1, TAG, 32>(h, L, A, lda, aux, C, ldc, M, T, s);
+    if (force && force[0] == '1') return launch_one<TAPS, EPI, 1, 1, TAG, 32>(h, L, A, lda, aux, C, ldc, M, T, s, row_map);
+    if (force && force[0] == '2' && L.N % 128 == 0) return launch_one<TAPS, EPI, 2, 2, TAG, 32>(h, L, A, lda, aux, C, ldc, M, T, s, row_map);
+    if (force && force[0] == '3' && L.K % 64 == 0) return launch_one<TAPS, EPI, 1, 1, TAG, 64>(h, L, A, lda, aux, C, ldc, M, T, s, row_map);
+    if (L.N % 128 == 0 && big_blocks >= 512) return launch_one<TAPS, EPI, 2, 2, TAG, 32>(h, L, A, lda, aux, C, ldc, M, T, s, row_map);
+    return launch_one<TAPS, EPI, 1, 1, TAG, 32>(h, L, A, lda, aux, C, ldc, M, T, s, row_map);
 }
 
 int launch_gemm(gem_handle* h, const Layer& L, int epi, const float* A, int lda, const float* aux, float* C, int ldc, int M,
-                int T, hipStream_t s, int family) {
+                int T, hipStream_t s, int family, const int* row_map) {
     if (L.K % BK_MIN != 0 || L.N % 64 != 0 || lda % 4 != 0) {
         set_error("launch_gemm: dimensions must be padded (K%32, N%64, lda%4)");
         return 1;
@@ -275,20 +285,24 @@ int launch_gemm(gem_handle* h, const Layer& L, int epi, const float* A, int lda,
         GEM_HIP(hipEventCreate(&rec.b));
         rec.family = family;
         rec.flops = 2.0 * M * (double)L.N * L.K * L.taps;
+        if (h->ws.dyn && L.taps == 1) {      // rows = active windows of this round, known only on the device
+            rec.log_idx = h->ws.cur_log;
+            rec.flops_per_window = 2.0 * (double)L.N * L.K;
+        }
         GEM_HIP(hipEventRecord(rec.a, s));
     }
     int rc = 1;
     if (L.taps == 1) {
         // TAG 1 = the decoder_input products (forward and backward-data): the dominant kernel gets its own symbol
-        if (family == 0 && epi == EPI_BIAS) rc = launch_tile<1, EPI_BIAS, 1>(h, L, A, lda, aux, C, ldc, M, T, s);
-        else if (epi == EPI_BIAS) rc = launch_tile<1, EPI_BIAS, 0>(h, L, A, lda, aux, C, ldc, M, T, s);
-        else if (epi == EPI_NONE) rc = launch_tile<1, EPI_NONE, 0>(h, L, A, lda, aux, C, ldc, M, T, s);
+        if (family == 0 && epi == EPI_BIAS) rc = launch_tile<1, EPI_BIAS, 1>(h, L, A, lda, aux, C, ldc, M, T, s, row_map);
+        else if (epi == EPI_BIAS) rc = launch_tile<1, EPI_BIAS, 0>(h, L, A, lda, aux, C, ldc, M, T, s, row_map);
+        else if (epi == EPI_NONE) rc = launch_tile<1, EPI_NONE, 0>(h, L, A, lda, aux, C, ldc, M, T, s, row_map);
         else set_error("launch_gemm: unsupported epilogue for a linear layer");
     } else if (L.taps == 3) {
-        if (epi == EPI_BIAS) rc = launch_tile<3, EPI_BIAS, 0>(h, L, A, lda, aux, C, ldc, M, T, s);
-        else if (epi == EPI_BIAS_LRELU) rc = launch_tile<3, EPI_BIAS_LRELU, 0>(h, L, A, lda, aux, C, ldc, M, T, s);
-        else if (epi == EPI_MASK) rc = launch_tile<3, EPI_MASK, 0>(h, L, A, lda, aux, C, ldc, M, T, s);
-        else if (epi == EPI_NONE) rc = launch_tile<3, EPI_NONE, 0>(h, L, A, lda, aux, C, ldc, M, T, s);
+        if (epi == EPI_BIAS) rc = launch_tile<3, EPI_BIAS, 0>(h, L, A, lda, aux, C, ldc, M, T, s, row_map);
+        else if (epi == EPI_BIAS_LRELU) rc = launch_tile<3, EPI_BIAS_LRELU, 0>(h, L, A, lda, aux, C, ldc, M, T, s, row_map);
+        else if (epi == EPI_MASK) rc = launch_tile<3, EPI_MASK, 0>(h, L, A, lda, aux, C, ldc, M, T, s, row_map);
+        else if (epi == EPI_NONE) rc = launch_tile<3, EPI_NONE, 0>(h, L, A, lda, aux, C, ldc, M, T, s, row_map);
     } else {
         set_error("launch_gemm: taps must be 1 or 3");
     }

@@ -28,6 +28,7 @@ struct AdvArgs {
     const double* f;
     const float* gnew;
     float *x, *d, *g, *gp, *bg0, *bg1, *trial, *S, *Y;
+    const int* slot_of;       // window -> slot of its gradient row (nullptr: identity)
     int Dp, hist_cap;
     gem_lbfgs_opts o;
 };
@@ -110,12 +111,13 @@ __global__ __launch_bounds__(256) void lbfgs_advance_kernel(AdvArgs a) {
     __syncthreads();
 
     const double f_new = a.f[b];
+    const float* gsrc = a.gnew + (size_t)(a.slot_of ? a.slot_of[b] : b) * Dp;
     float gn[EPT], xv[EPT], dv[EPT], gcur[EPT], yv[EPT], sv[EPT];
     bool have_x = false, have_d = false;
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
         const int e = tid + 256 * i;
-        gn[i] = e < Dp ? a.gnew[off + e] : 0.f;
+        gn[i] = e < Dp ? gsrc[e] : 0.f;
         xv[i] = dv[i] = gcur[i] = yv[i] = sv[i] = 0.f;
     }
     auto load = [&](const float* p, float (&v)[EPT]) {
@@ -430,6 +432,7 @@ static AdvArgs make_args(gem_handle* h, const gem_lbfgs_opts& o) {
     AdvArgs a;
     a.state = w.state; a.f = w.f; a.gnew = w.dz;
     a.x = w.x; a.d = w.d; a.g = w.g; a.gp = w.gp; a.bg0 = w.bg0; a.bg1 = w.bg1; a.trial = w.trial; a.S = w.S; a.Y = w.Y;
+    a.slot_of = w.dyn ? w.slot_of : nullptr;
     a.Dp = h->Dp; a.hist_cap = w.hist_cap; a.o = o;
     return a;
 }
@@ -461,6 +464,46 @@ int launch_lbfgs_advance(gem_handle* h, int B, const gem_lbfgs_opts& o, hipStrea
     else { set_error("latent_dim > 4096 is not supported by the L-BFGS kernel"); return 1; }
     GEM_HIP(hipGetLastError());
     if (prof) { GEM_HIP(hipEventRecord(rec.b, s)); h->prof.recs.push_back(rec); }
+    return 0;
+}
+
+// Stable partition of the windows: those still iterating first (slots [0, n)), finished ones behind.
+// One 1024-thread block; B is at most a few thousand.
+__global__ __launch_bounds__(1024) void compact_kernel(const LbfgsState* __restrict__ st, int B, int T, int* __restrict__ perm,
+                                                       int* __restrict__ slot_of, int* __restrict__ n_active, int force_all,
+                                                       int* __restrict__ log_slot) {
+    __shared__ int wsum[16];
+    __shared__ int base_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int start = 0; start < B; start += 1024) {
+            const int b = start + tid;
+            const bool active = b < B && (force_all || st[b].phase != PH_DONE);
+            const bool flag = b < B && (active == (pass == 0));
+            const unsigned long long m = __ballot(flag);
+            const int prefix = __popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) wsum[wave] = __popcll(m);
+            __syncthreads();
+            int woff = 0, total = 0;
+            for (int i = 0; i < 16; ++i) { if (i < wave) woff += wsum[i]; total += wsum[i]; }
+            const int base = base_s;
+            if (flag) { const int sl = base + woff + prefix; perm[sl] = b; slot_of[b] = sl; }
+            __syncthreads();
+            if (tid == 0) base_s = base + total;
+            __syncthreads();
+        }
+        if (pass == 0 && tid == 0) { n_active[0] = base_s; n_active[1] = base_s * T; *log_slot = base_s; }
+    }
+}
+
+int launch_compact(gem_handle* h, int B, int force_all, hipStream_t s) {
+    Workspace& w = h->ws;
+    hipLaunchKernelGGL(compact_kernel, dim3(1), dim3(1024), 0, s, w.state, B, h->T, w.perm, w.slot_of, w.n_active, force_all,
+                       w.n_log + (w.log_pos % N_LOG));
+    GEM_HIP(hipGetLastError());
+    w.cur_log = w.log_pos++;
     return 0;
 }
 

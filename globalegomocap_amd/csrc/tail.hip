@@ -126,8 +126,10 @@ __global__ __launch_bounds__(256) void decoder_tail_kernel(TailArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 31, fh = lane >> 5;
     const int T = a.e.T;
-    const int w0 = blockIdx.x * a.G;                         // first window of this workgroup
-    const int nwin = min(a.G, a.B - w0);
+    const int w0 = blockIdx.x * a.G;                         // first slot of this workgroup
+    const int B = a.e.n_dev ? *a.e.n_dev : a.B;              // active slots this round
+    if (w0 >= B) return;
+    const int nwin = min(a.G, B - w0);
     const int R = nwin * T;                                  // valid rows
     const size_t row0 = (size_t)w0 * T;
     float* red = lds + a.off_red;
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(256) void decoder_tail_kernel(TailArgs a) {
     float* g_nxt = lds + a.off_g[1];
     if (wave < nwin) {
         float* scr = lds + a.off_escr + wave * 4 * a.escr;
-        energy_window<false>(a.e, w0 + wave, lane, lds + a.off_act[a.n] + wave * T * a.ld_act[a.n], a.ld_act[a.n], scr, scr + a.escr,
+        energy_window<false>(a.e, a.e.perm ? a.e.perm[w0 + wave] : w0 + wave, lane, lds + a.off_act[a.n] + wave * T * a.ld_act[a.n], a.ld_act[a.n], scr, scr + a.escr,
                              scr + 2 * a.escr, scr + 3 * a.escr, g_cur + wave * T * a.ld_g, a.ld_g, a.fwd[a.n - 1].N);
     }
     __syncthreads();
