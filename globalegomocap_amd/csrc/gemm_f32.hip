@@ -111,18 +111,25 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     GEM_STORE_TILE(0);
     __syncthreads();
     int cur = 0;
+#ifndef GEM_ABLATE
+#define GEM_ABLATE 0
+#endif
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const bool more = kt + 1 < kt_end;
-        if (more) GEM_LOAD_TILE(kt + 1);
+        if (more && GEM_ABLATE < 1) GEM_LOAD_TILE(kt + 1);
         const float* as = lds + cur * BUF + (wm * 32 * RM + fr) * LDS_LD + fh * (BK / 2);
         const float* bs = lds + cur * BUF + (BM + wn * 32 * RN + fr) * LDS_LD + fh * (BK / 2);
 #pragma unroll
         for (int q = 0; q < BK / 8; ++q) {
             f32x4 av[RM], bv[RN];
 #pragma unroll
-            for (int i = 0; i < RM; ++i) av[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LDS_LD + 4 * q);
+            for (int i = 0; i < RM; ++i) av[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LDS_LD + 4 * (GEM_ABLATE >= 3 ? 0 : q));
 #pragma unroll
-            for (int j = 0; j < RN; ++j) bv[j] = *reinterpret_cast<const f32x4*>(bs + j * 32 * LDS_LD + 4 * q);
+            for (int j = 0; j < RN; ++j) bv[j] = *reinterpret_cast<const f32x4*>(bs + j * 32 * LDS_LD + 4 * (GEM_ABLATE >= 3 ? 0 : q));
+            if (GEM_ABLATE >= 3) {      // keep the operands opaque so the loads are not re-issued per q
+#pragma unroll
+                for (int i = 0; i < RM; ++i) asm volatile("" : "+v"(av[i]));
+            }
 #pragma unroll
             for (int i = 0; i < RM; ++i)
 #pragma unroll
@@ -133,6 +140,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, bv[j].w, acc[i][j], 0, 0, 0);
                 }
         }
+        if (GEM_ABLATE >= 2) continue;          // ablation build: MFMA + LDS reads only
         if (DBUF) {
             if (more) GEM_STORE_TILE(cur ^ 1);
             __syncthreads();

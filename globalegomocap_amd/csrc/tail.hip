@@ -27,8 +27,26 @@ namespace gem {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// B fragments of the first (tile, k-block) a wave will need in layer L: issued before the barrier that ends the
+// previous layer, so that their L2 latency overlaps the epilogue / barrier / energy phase.
+__device__ __forceinline__ void tail_prefetch_first(const TailLayerDev L, f32x4 (&dst)[4]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 31, fh = lane >> 5;
+    const int ntiles = L.N / 32;
+    const int ksplit = ntiles >= 4 ? 1 : 4 / ntiles;
+    const int kpart = ksplit > 1 ? wave / ntiles : 0;
+    const int kb = L.K / 32, nblk = 3 * kb;
+    const int blk0 = kpart * nblk / ksplit;
+    const int tile = ksplit > 1 ? wave % ntiles : wave;
+    const int tap = blk0 / kb, k0 = (blk0 - tap * kb) * 32;
+    const f32x4* p = reinterpret_cast<const f32x4*>(L.w4) + (size_t)tap * (L.K / 4) * L.N + (size_t)(k0 / 4 + fh) * L.N + tile * 32 + fr;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dst[c] = p[(size_t)(2 * c) * L.N];
+}
+
+// bpre: in = fragments from tail_prefetch_first(L); out = the same for `next` (if any), issued before the epilogue
 template <typename Epi>
-__device__ __forceinline__ void tail_gemm(const float* in, int ld_in, const TailLayerDev& L, int T, int R, float* red, Epi epi) {
+__device__ __forceinline__ void tail_gemm(const float* in, int ld_in, const TailLayerDev L, const TailLayerDev next, bool has_next,
+                                          int T, int R, float* red, f32x4 (&bpre)[4], Epi epi) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 31, fh = lane >> 5;
     const int ntiles = L.N / 32;
     const int ksplit = ntiles >= 4 ? 1 : 4 / ntiles;          // ntiles is even (N is a multiple of 64)
@@ -76,7 +94,13 @@ __device__ __forceinline__ void tail_gemm(const float* in, int ld_in, const Tail
         }
         // two register sets for both operands, loads issued one block (16 MFMAs = 1024 cycles) ahead of use
         f32x4 b0[4], b1[4], a0[4], a1[4];
-        TAIL_LOAD_B(blk0, b0);
+        const bool first_tile = tile == (ksplit > 1 ? wave % ntiles : wave);
+        if (first_tile) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) b0[c] = bpre[c];
+        } else {
+            TAIL_LOAD_B(blk0, b0);
+        }
         TAIL_LOAD_A(blk0, a0);
         // Branch-free pair loop (a conditional prefetch makes hipcc fall back to vmcnt(0) at the join) with
         // sched_barriers (otherwise both prefetches are hoisted to the loop top and waited for together).
@@ -96,6 +120,7 @@ __device__ __forceinline__ void tail_gemm(const float* in, int ld_in, const Tail
             __builtin_amdgcn_sched_barrier(0);
         }
         if ((blk1 - blk0) & 1) TAIL_COMPUTE(a0, b0);
+        if (has_next && tile + tile_step >= ntiles) tail_prefetch_first(next, bpre);     // last tile of this wave
 #undef TAIL_LOAD_A
 #undef TAIL_LOAD_B
 #undef TAIL_COMPUTE
@@ -122,7 +147,7 @@ __device__ __forceinline__ void tail_gemm(const float* in, int ld_in, const Tail
     }
 }
 
-__global__ __launch_bounds__(256) void decoder_tail_kernel(TailArgs a) {
+__global__ __launch_bounds__(256, 1) void decoder_tail_kernel(TailArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 31, fh = lane >> 5;
     const int T = a.e.T;
@@ -148,13 +173,18 @@ __global__ __launch_bounds__(256) void decoder_tail_kernel(TailArgs a) {
     __syncthreads();
 
     // ---- forward layers
+    f32x4 bpre[4];
+    tail_prefetch_first(a.fwd[0], bpre);
     for (int i = 0; i < a.n; ++i) {
         const bool last = (i + 1 == a.n);
         float* out = lds + a.off_act[i + 1];
         const int ldo = a.ld_act[i + 1];
         const float* bias = a.fwd[i].bias;
         float* Xp = last ? a.Xp : nullptr;
-        tail_gemm(lds + a.off_act[i], a.ld_act[i], a.fwd[i], T, R, red, [&](const f32x16& acc, int n0) {
+        // (by value: taking the address of a kernel-argument member would put the whole struct in scratch)
+        const TailLayerDev nxt = !last ? a.fwd[i + 1] : a.bwd[a.n - 1];
+        tail_gemm(lds + a.off_act[i], a.ld_act[i], a.fwd[i], nxt, !last || !a.forward_only, T, R, red, bpre,
+                  [&](const f32x16& acc, int n0) {
             const int col = n0 + fr;
             const float bv = bias[col];
 #pragma unroll
@@ -187,7 +217,7 @@ __global__ __launch_bounds__(256) void decoder_tail_kernel(TailArgs a) {
         const int ldg = a.ld_g;
         float* gout = a.g_out;
         const int K0 = a.fwd[0].K;
-        tail_gemm(g_cur, a.ld_g, a.bwd[i], T, R, red, [&](const f32x16& acc, int n0) {
+        tail_gemm(g_cur, a.ld_g, a.bwd[i], a.bwd[i > 0 ? i - 1 : 0], i > 0, T, R, red, bpre, [&](const f32x16& acc, int n0) {
             const int col = n0 + fr;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {

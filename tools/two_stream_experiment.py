@@ -1,0 +1,46 @@
+"""Developer experiment: does running two half-batches on two HIP streams beat one full batch?"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import bench
+from globalegomocap_amd import synth, vae as V
+from globalegomocap_amd.camera import FisheyeCamera, DEFAULT_CALIBRATION
+from globalegomocap_amd.engine import WindowEngine, energy_weights
+from globalegomocap_amd.sequence import window_starts
+
+dev = torch.device("cuda")
+shape = V.VAEShape(); cam = FisheyeCamera.from_json(DEFAULT_CALIBRATION)
+sd_l, _ = bench.fit_weights(shape, 101, dev, 2000, False)
+sd_g, _ = bench.fit_weights(shape, 102, dev, 2000, True)
+seq = synth.make_sequence_device(2000, 1000, dev, cam, cam_jitter=bench.CAM_JITTER)
+starts = np.concatenate([c * 100 + window_starts(100) for c in range(20)]).astype(np.int32)
+B = len(starts)
+g = torch.Generator().manual_seed(4321)
+eps = torch.randn(2 * B, 2048, generator=g).reshape(B, 2, -1)
+wl, wg = energy_weights(1e-6, 1e-5, 0.01, 0, 0.01), energy_weights(0.01, 0.001, 0.01, 0, 0)
+
+def make(n_parts):
+    parts = []
+    for p in range(n_parts):
+        lo, hi = p * B // n_parts, (p + 1) * B // n_parts
+        e = WindowEngine(shape, cam, max_windows=hi - lo)
+        e.load_vae(0, sd_l); e.load_vae(1, sd_g)
+        mb = e.mean_bone_length(seq["est_local"][:100]).reshape(1, 15).expand(hi - lo, 15).contiguous()
+        parts.append(dict(e=e, f0=torch.as_tensor(starts[lo:hi], device=dev), mb=mb, el=eps[lo:hi, 0].contiguous().to(dev),
+                          eg=eps[lo:hi, 1].contiguous().to(dev), s=torch.cuda.Stream()))
+    return parts
+
+def run(parts, steps):
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(steps):
+        for p in parts:
+            with torch.cuda.stream(p["s"]):
+                p["e"].optimize_windows(seq["est_local"], seq["cams"], seq["heat"], p["f0"], p["mb"], p["el"], p["eg"], wl, wg, want_stats=False)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / steps * 1e3
+
+for n in (1, 2, 3, 4):
+    parts = make(n)
+    run(parts, 2)
+    ms = run(parts, 8)
+    print("streams %d: %.2f ms/step  %.0f windows/s" % (n, ms, B / ms * 1e3), flush=True)
