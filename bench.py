@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, spec
+PEAK_BF16_MATRIX_TFLOPS = 2500.0    # dense bf16 MFMA, spec
 CHUNK = 100                         # frames per chunk directory (process_test_data.py:177-184)
 LATENT_GAIN = float(os.environ.get("GEM_BENCH_LATENT_GAIN", "8"))   # latent gauge of the synthetic VAEs (see vae_torch.fit_vae)
 PROFILE_STEPS = 2
@@ -41,6 +42,8 @@ def parse():
     p.add_argument("--fit-steps", type=int, default=2000, help="Adam steps to fit the synthetic VAEs (untimed)")
     p.add_argument("--cpu-windows", type=int, default=12, help="windows of the CPU baseline sample (0 = skip)")
     p.add_argument("--no-profile", action="store_true", help="no HIP-event timing of the dominant kernel")
+    p.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "bf16"],
+                   help="arithmetic of the wide decoder/encoder products (f32 = BASELINE configs[1])")
     p.add_argument("--weights-cache", default=None, help="torch file to load/store the fitted synthetic VAEs (keeps the "
                    "fitting kernels out of a rocprof trace)")
     return p.parse_args()
@@ -133,6 +136,7 @@ def main():
     eng = WindowEngine(shape, cam, max_windows=B)
     eng.load_vae(LOCAL_STAGE, sd_local)
     eng.load_vae(GLOBAL_STAGE, sd_global)
+    eng.set_precision(a.precision)
     mb = torch.stack([eng.mean_bone_length(seqd["est_local"][c * CHUNK:(c + 1) * CHUNK]) for c in range(n_chunks)])
     mb_w = mb[torch.as_tensor(chunk_of, device=device)].contiguous()
     g = torch.Generator().manual_seed(4321 + rank)
@@ -202,8 +206,10 @@ def main():
             ms, n, fl = eng.profile_read(0)
             if n:
                 achieved = fl / (ms * 1e-3) / 1e12
-                roof = {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(achieved / PEAK_F32_MATRIX_TFLOPS, 4), "traffic": traffic,
+                # bf16x3 issues three bf16 MFMAs per algorithmic product
+                peak = {"f32": PEAK_F32_MATRIX_TFLOPS, "bf16x3": PEAK_BF16_MATRIX_TFLOPS / 3, "bf16": PEAK_BF16_MATRIX_TFLOPS}[a.precision]
+                roof = {"bound": "mfma", "achieved": round(achieved, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
+                        "frac": round(achieved / peak, 4), "traffic": traffic if a.precision == "f32" else None,
                         "kernel": "gemm_f32_kernel<1,EPI_BIAS,*,*,1> (decoder_input forward + backward-data)",
                         "launches": int(n), "avg_us": round(ms * 1e3 / n, 2),
                         "flop_per_launch": fl / n}
@@ -227,7 +233,8 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": {"f32": "f32", "bf16x3": "f32 via 3x bf16 split MFMA (wide products), f32 elsewhere",
+                      "bf16": "bf16 wide products / f32 accumulate, tail and energies"}[a.precision], "data": "synthetic",
             "config": {"workload": "BASELINE configs[1] shape: %d-frame sequence per GPU = %d chunks x %d windows = %d windows, "
                                    "fp32, local+global stage, L-BFGS max_iter 25 / max_eval 31" % (n_frames, n_chunks, per, B),
                        "windows_per_gpu": B, "latent_dim": shape.latent_dim, "parallelism": "window-shards x%d" % world,

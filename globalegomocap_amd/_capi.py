@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "_lib", "libgem_hip.so")
 
 GEM_MAX_HIDDEN, GEM_MAX_POLY, GEM_MAX_JOINTS = 8, 16, 16
 STAGE_LOCAL, STAGE_GLOBAL = 0, 1
+PRECISION = {"f32": 0, "bf16x3": 1, "bf16": 2}
 
 
 class GemError(RuntimeError):
@@ -47,6 +48,7 @@ SIGNATURES = {
     "gem_version": (C.c_int, []),
     "gem_create": (C.c_int, [C.POINTER(GemConfig), C.POINTER(_P)]),
     "gem_destroy": (None, [_P]),
+    "gem_set_precision": (C.c_int, [_P, C.c_int]),
     "gem_load_vae": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P), C.POINTER(C.c_int64)]),
     "gem_mean_bone_length": (C.c_int, [_P, _P, C.c_int, _P, _P]),
     "gem_encode": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),

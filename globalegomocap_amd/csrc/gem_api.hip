@@ -39,6 +39,27 @@ static int upload(std::vector<void*>& owner, T** p, const std::vector<T>& v) {
     return 0;
 }
 
+static uint16_t host_f2bf(float x) {
+    uint32_t u;
+    std::memcpy(&u, &x, 4);
+    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+static float host_bf2f(uint16_t b) {
+    const uint32_t u = (uint32_t)b << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+// bf16 hi / lo images of a packed fp32 weight array (same [taps][N][K] layout)
+static int upload_bf16(std::vector<void*>& owner, Layer* L, const std::vector<float>& w) {
+    std::vector<uint16_t> hi(w.size()), lo(w.size());
+    for (size_t i = 0; i < w.size(); ++i) {
+        hi[i] = host_f2bf(w[i]);
+        lo[i] = host_f2bf(w[i] - host_bf2f(hi[i]));
+    }
+    return upload(owner, &L->wb_hi, hi) || upload(owner, &L->wb_lo, lo);
+}
+
 // taps[k][ci][co] in double, BatchNorm folded
 struct FoldedConv {
     int ci, co;
@@ -81,7 +102,7 @@ static int make_conv_layers(StageNet& net, const FoldedConv& f, Layer* fwd, Laye
             for (int o = 0; o < f.co; ++o) wf[((size_t)k * Np + o) * Kp + i] = (float)f.taps[((size_t)k * f.ci + i) * f.co + o];
     for (int o = 0; o < f.co; ++o) bf[o] = (float)f.bias[o];
     fwd->taps = 3; fwd->K = Kp; fwd->N = Np;
-    if (upload(net.allocs, &fwd->w, wf) || upload(net.allocs, &fwd->bias, bf)) return 1;
+    if (upload(net.allocs, &fwd->w, wf) || upload(net.allocs, &fwd->bias, bf) || upload_bf16(net.allocs, fwd, wf)) return 1;
     auto to_w4 = [](const std::vector<float>& w, int N, int K) {      // [tap][N][K] -> [tap][K/4][N][4]
         std::vector<float> o(w.size());
         for (int t = 0; t < 3; ++t)
@@ -97,7 +118,8 @@ static int make_conv_layers(StageNet& net, const FoldedConv& f, Layer* fwd, Laye
             for (int i = 0; i < f.ci; ++i)
                 for (int o = 0; o < f.co; ++o) wb[((size_t)k * Kp + i) * Np + o] = (float)f.taps[((size_t)(2 - k) * f.ci + i) * f.co + o];
         bwd->taps = 3; bwd->K = Np; bwd->N = Kp;
-        if (upload(net.allocs, &bwd->w, wb) || upload(net.allocs, &bwd->w4, to_w4(wb, Kp, Np))) return 1;
+        if (upload(net.allocs, &bwd->w, wb) || upload(net.allocs, &bwd->w4, to_w4(wb, Kp, Np)) || upload_bf16(net.allocs, bwd, wb))
+            return 1;
         bwd->bias = nullptr;
     }
     return 0;
@@ -242,7 +264,7 @@ int gem_load_vae(gem_handle* h, int stage, int n_blobs, const float* const* blob
       }
       bi += 4;
       net.fc.taps = 1; net.fc.K = Kp; net.fc.N = 2 * Dp;
-      if (upload(net.allocs, &net.fc.w, wv) || upload(net.allocs, &net.fc.bias, bv)) return 1; }
+      if (upload(net.allocs, &net.fc.w, wv) || upload(net.allocs, &net.fc.bias, bv) || upload_bf16(net.allocs, &net.fc, wv)) return 1; }
     // ---- decoder_input: forward N = T*topp (n = t*topp + c), K = Dp; backward-data is the transpose
     { const int Np = T * h->topp;
       const float* W = blobs[bi]; const float* b = blobs[bi + 1];
@@ -260,8 +282,10 @@ int gem_load_vae(gem_handle* h, int stage, int n_blobs, const float* const* blob
           }
       net.dec_in.taps = 1; net.dec_in.K = Dp; net.dec_in.N = Np;
       net.dec_in_bwd.taps = 1; net.dec_in_bwd.K = Np; net.dec_in_bwd.N = Dp;
-      if (upload(net.allocs, &net.dec_in.w, wf) || upload(net.allocs, &net.dec_in.bias, bf)) return 1;
-      if (upload(net.allocs, &net.dec_in_bwd.w, wb) || upload(net.allocs, &net.dec_in_bwd.bias, zb)) return 1; }
+      if (upload(net.allocs, &net.dec_in.w, wf) || upload(net.allocs, &net.dec_in.bias, bf) || upload_bf16(net.allocs, &net.dec_in, wf))
+          return 1;
+      if (upload(net.allocs, &net.dec_in_bwd.w, wb) || upload(net.allocs, &net.dec_in_bwd.bias, zb) ||
+          upload_bf16(net.allocs, &net.dec_in_bwd, wb)) return 1; }
     // ---- decoder convs
     auto add_dec = [&](int ci, int co, bool transposed, bool bn) -> int {
         FoldedConv f = fold_conv(blobs[bi], blobs[bi + 1], nullptr, bn ? blobs + bi + 2 : nullptr, ci, co, transposed);
@@ -508,6 +532,12 @@ int gem_optimize_windows(gem_handle* h, int B, const float* d_local_pose, const 
     if (optimize_stage_impl(h, GEM_STAGE_GLOBAL, B, w.pose_a, d_heat, d_frame0, d_mean_bone, d_eps_global, *w_global, *opt, out_b,
                             d_stats ? d_stats + B : nullptr, s)) return 1;
     return launch_to_global(out_b, d_cams, d_frame0, d_global, B, T, J, s);
+}
+
+int gem_set_precision(gem_handle* h, int mode) {
+    if (!h || mode < 0 || mode > 2) { set_error("gem_set_precision: mode must be 0 (f32), 1 (bf16x3) or 2 (bf16)"); return 1; }
+    h->precision = mode;
+    return 0;
 }
 
 int gem_profile_enable(gem_handle* h, int on) {

@@ -31,6 +31,8 @@ struct Layer {
     float* w = nullptr;    // device, [taps][N][K], k contiguous
     float* bias = nullptr; // device, [N] (forward layers only)
     float* w4 = nullptr;   // device, [taps][K/4][N][4]: layout of the fused decoder-tail kernel (conv layers only)
+    uint16_t* wb_hi = nullptr;   // device, bf16 [taps][N][K]: bf16(w)                       (precision modes 1, 2)
+    uint16_t* wb_lo = nullptr;   // device, bf16 [taps][N][K]: bf16(w - float(bf16(w)))      (precision mode 1)
 };
 
 struct StageNet {
@@ -107,6 +109,7 @@ struct gem_handle {
     gem::StageNet net[2];
     gem::Workspace ws;
     gem::Profile prof;
+    int precision = 0;             // GEM_PRECISION_*
     int* d_parents = nullptr;
     int* d_children = nullptr;     // [J][J] child lists, -1 terminated
 };
@@ -116,6 +119,13 @@ namespace gem {
 // ---- kernel launchers (each enqueues on `s`, returns 0/1) -------------------------------------------
 int launch_gemm(gem_handle* h, const Layer& L, int epi, const float* A, int lda, const float* aux, float* Cout, int ldc,
                 int M, int T, hipStream_t s, int family, const int* row_map = nullptr);
+
+int pick_splitk(const gem_handle* h, long blocks, int n_tiles, size_t slab_elems);
+int launch_splitk_reduce(gem_handle* h, int epi, int nslab, size_t slab, const float* bias, const float* aux, float* C, int M, int N,
+                         int ldc, const int* m_dev, hipStream_t s);
+// bf16-input MFMA variant of launch_gemm (gemm_bf16.hip): nprod = 1 (plain bf16) or 3 (hi/lo split, fp32-grade)
+int launch_gemm_bf16(gem_handle* h, const Layer& L, int epi, int nprod, const float* A, int lda, const float* aux, float* Cout,
+                     int ldc, int M, int T, hipStream_t s, const int* row_map);
 
 int launch_pack_pose(const float* src, float* dst, int rows, int C, hipStream_t s);      // [rows,C] -> [rows,64]
 int launch_unpack_pose(const float* src, float* dst, int rows, int C, hipStream_t s);    // [rows,64] -> [rows,C]

@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // slots best (workgroups / (256 * per_cu)), preferring >= 2 per CU and fewer slices.
 constexpr int N_CU = 256;
 constexpr int LDS_PER_CU = 160 * 1024;
-static int pick_splitk(const gem_handle* h, long blocks, int n_tiles, size_t slab_elems) {
+int pick_splitk(const gem_handle* h, long blocks, int n_tiles, size_t slab_elems) {
     if (!h->ws.splitk || blocks >= 3 * N_CU) return 1;
     int best = 1;
     double best_score = -1.0;
@@ -222,6 +222,20 @@ static int pick_splitk(const gem_handle* h, long blocks, int n_tiles, size_t sla
         if (score > best_score) { best_score = score; best = sk; }
     }
     return best;
+}
+
+int launch_splitk_reduce(gem_handle* h, int epi, int nslab, size_t slab, const float* bias, const float* aux, float* C, int M, int N,
+                         int ldc, const int* m_dev, hipStream_t s) {
+    const size_t n4 = (size_t)M * (N / 4);
+    const dim3 grid((unsigned)((n4 + 255) / 256));
+    switch (epi) {
+        case EPI_BIAS: hipLaunchKernelGGL(splitk_reduce_kernel<EPI_BIAS>, grid, dim3(256), 0, s, h->ws.splitk, nslab, slab, bias, aux, C, M, N, ldc, m_dev); break;
+        case EPI_BIAS_LRELU: hipLaunchKernelGGL(splitk_reduce_kernel<EPI_BIAS_LRELU>, grid, dim3(256), 0, s, h->ws.splitk, nslab, slab, bias, aux, C, M, N, ldc, m_dev); break;
+        case EPI_MASK: hipLaunchKernelGGL(splitk_reduce_kernel<EPI_MASK>, grid, dim3(256), 0, s, h->ws.splitk, nslab, slab, bias, aux, C, M, N, ldc, m_dev); break;
+        default: hipLaunchKernelGGL(splitk_reduce_kernel<EPI_NONE>, grid, dim3(256), 0, s, h->ws.splitk, nslab, slab, bias, aux, C, M, N, ldc, m_dev); break;
+    }
+    GEM_HIP(hipGetLastError());
+    return 0;
 }
 
 template <int TAPS, int EPI, int RM, int RN, int TAG, int BK>
@@ -259,11 +273,7 @@ static int launch_one(gem_handle* h, const Layer& L, const float* A, int lda, co
     hipLaunchKernelGGL(k, grid, dim3(256), shmem, s, A, lda, L.w, L.bias, aux, h->ws.splitk, ldc, M, L.N, L.K, T, per, slab, m_dev,
                        row_map);
     GEM_HIP(hipGetLastError());
-    const size_t n4 = (size_t)M * (L.N / 4);
-    hipLaunchKernelGGL(splitk_reduce_kernel<EPI>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, h->ws.splitk, (int)grid.z, slab,
-                       L.bias, aux, C, M, L.N, ldc, m_dev);
-    GEM_HIP(hipGetLastError());
-    return 0;
+    return launch_splitk_reduce(h, EPI, (int)grid.z, slab, L.bias, aux, C, M, L.N, ldc, m_dev, s);
 }
 
 template <int TAPS, int EPI, int TAG>
@@ -300,7 +310,9 @@ int launch_gemm(gem_handle* h, const Layer& L, int epi, const float* A, int lda,
         GEM_HIP(hipEventRecord(rec.a, s));
     }
     int rc = 1;
-    if (L.taps == 1) {
+    if (h->precision != GEM_PRECISION_F32 && L.wb_hi && (h->precision == GEM_PRECISION_BF16 || L.wb_lo)) {
+        rc = launch_gemm_bf16(h, L, epi, h->precision == GEM_PRECISION_BF16 ? 1 : 3, A, lda, aux, C, ldc, M, T, s, row_map);
+    } else if (L.taps == 1) {
         // TAG 1 = the decoder_input products (forward and backward-data): the dominant kernel gets its own symbol
         if (family == 0 && epi == EPI_BIAS) rc = launch_tile<1, EPI_BIAS, 1>(h, L, A, lda, aux, C, ldc, M, T, s, row_map);
         else if (epi == EPI_BIAS) rc = launch_tile<1, EPI_BIAS, 0>(h, L, A, lda, aux, C, ldc, M, T, s, row_map);

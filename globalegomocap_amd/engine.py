@@ -68,6 +68,10 @@ class WindowEngine:
         except Exception:
             pass
 
+    def set_precision(self, mode):
+        """'f32' (default) | 'bf16x3' (split-bf16 MFMA, fp32-grade) | 'bf16' for the wide decoder/encoder products."""
+        _capi.check(self.lib.gem_set_precision(self._h, _capi.PRECISION[mode]), self.lib)
+
     # ------------------------------------------------------------------ weights
     def load_vae(self, stage, state_dict):
         blobs = flatten_state_dict(state_dict, self.shape)

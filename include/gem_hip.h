@@ -85,6 +85,15 @@ int gem_version(void);
 int  gem_create(const gem_config* cfg, gem_handle** out);
 void gem_destroy(gem_handle* h);
 
+/* Arithmetic of the wide decoder / encoder products (the narrow tail layers and every energy term are
+ * always fp32):  0 = fp32 MFMA (default, BASELINE configs[1]);
+ *                1 = "bf16x3": operands split into bf16 hi+lo, three bf16 MFMAs per product, fp32 accumulate
+ *                    (error ~2^-16 relative, i.e. fp32-grade, at ~1.5x the fp32 rate);
+ *                2 = bf16 operands, fp32 accumulate (BASELINE configs[2..3] "bf16 VAE decoder / fp32 energy").
+ * May be switched at any time between calls. */
+enum { GEM_PRECISION_F32 = 0, GEM_PRECISION_BF16X3 = 1, GEM_PRECISION_BF16 = 2 };
+int gem_set_precision(gem_handle* h, int mode);
+
 /* network.load_state_dict(torch.load(path)['state_dict']) (optimizer.py:59-63).  `h_blobs[i]` is the
  * i-th float32 tensor of the state_dict in the order of globalegomocap_amd.vae.VAEShape.schema(),
  * `n_elem[i]` its element count (checked).  BatchNorm (eval) is folded into the convolutions and the

@@ -314,3 +314,56 @@ def test_full_size_batch_properties_at_baseline_size(torch_cuda):
     out3, stats3 = eng.optimize_stage(0, pose[perm], mb, eps[perm], w, seq["heat"], starts[perm])
     assert torch.equal(out3, out[torch.as_tensor(perm, device=out.device)])
     assert np.isfinite(out.cpu().numpy()).all()
+
+
+@pytest.mark.parametrize("mode,tol_x,tol_e,tol_g", [("bf16x3", 2e-5, 2e-4, 2e-3), ("bf16", 3e-3, 5e-2, 1e-1)])
+def test_precision_modes_energy_and_gradient(torch_cuda, mode, tol_x, tol_e, tol_g):
+    """Wide products in split-bf16 (fp32-grade) and plain bf16 against the fp32 oracle, full-size network."""
+    sd = vae_schema.synthetic_state_dict(FULL, 5)
+    eng = _engine(FULL, max_windows=8)
+    eng.load_vae(0, sd)
+    eng.set_precision(mode)
+    vae = O.fold_vae(sd)
+    cam = oracle_camera()
+    B = 4
+    seq = synth.make_sequence(n_frames=8 * (B - 1) + 10, seed=33)
+    est = np.asarray(seq["estimated_local_skeleton"], dtype=np.float32)
+    heat = np.asarray(seq["heatmap_list"], dtype=np.float32)
+    starts = (8 * np.arange(B)).astype(np.int32)
+    pose = np.stack([est[s:s + 10] for s in starts])
+    rng = np.random.default_rng(4)
+    mu, _ = O.encode(vae, pose.reshape(B, 10, 45))
+    z = (mu + 0.1 * rng.normal(size=mu.shape)).astype(np.float32)
+    mb = O.mean_bone_length(est)
+    mu_d, lv_d, _ = eng.encode(0, pose.reshape(B, 10, 45))
+    assert np.abs(mu_d.cpu().numpy() - mu).max() <= 50 * tol_x * max(1.0, np.abs(mu).max())
+    E, parts, dz, X = eng.energy_grad(0, z, pose, mb, _ew(W_ALL), heat, starts)
+    for b in range(B):
+        Xo, acts = O.decode(vae, z[b:b + 1], keep=True)
+        f, p, dX = O.energy_and_grad(Xo[0], pose[b], mb, O.Weights(*W_ALL), cam, heat[starts[b]:starts[b] + 10])
+        dzo = O.decode_backward(vae, dX[None], acts)[0]
+        assert np.abs(X[b].cpu().numpy() - Xo[0]).max() <= tol_x * max(1.0, np.abs(Xo[0]).max())
+        assert abs(float(E[b]) - f) <= tol_e * abs(f) + 1e-7
+        assert np.abs(dz[b].cpu().numpy() - dzo).max() <= tol_g * np.abs(dzo).max() + 1e-8
+
+
+@pytest.mark.parametrize("mode,tol_mm", [("bf16x3", 0.5), ("bf16", 1.5)])
+def test_precision_modes_window_pipeline_mpjpe(torch_cuda, golden, tmp_path, mode, tol_mm):
+    """main() mirror in the faster arithmetic modes against the reference's golden run."""
+    import torch
+    from globalegomocap_amd import optimizer as gopt
+    g = golden("pipeline_tiny")
+    lt = golden("lbfgs_tiny")
+    data = synth.make_sequence(n_frames=100, seed=int(g["seq_seed"]))
+    d = tmp_path / "chunk0"
+    d.mkdir()
+    with open(d / "test_data.pkl", "wb") as f:
+        pickle.dump({k: data[k] for k in ("estimated_local_skeleton", "gt_global_skeleton", "camera_pose_list", "heatmap_list")}, f)
+    torch.manual_seed(int(g["eps_seed"]))
+    eps = torch.randn(24, 32)
+    opt = gopt.SequenceOptimizer(DEFAULT_CALIBRATION, sd_from_npz(lt, "global/"), sd_from_npz(lt, "local/"), max_windows=12)
+    opt.engine.set_precision(mode)
+    errors = gopt.main(str(d), DEFAULT_CALIBRATION, 0.0, 0.0, float(g["smooth"]), 0.01, float(g["weight_3d"]), 0.01,
+                       final_smooth=True, eps=eps, optimizer=opt)[0]
+    ref = float(g["err_smooth/optimized_global_mpjpe"])
+    assert abs(errors["optimized_global_mpjpe"] - ref) * 1e3 < tol_mm, (mode, errors["optimized_global_mpjpe"], ref)

@@ -2,9 +2,11 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o /tmp/gemm_bench tools/gemm_bench.hip && /tmp/gemm_bench
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <cmath>
 #include <vector>
 #include "../globalegomocap_amd/csrc/gemm_f32.hip"
+#include "../globalegomocap_amd/csrc/gemm_bf16.hip"
 
 namespace gem {
 void set_error(const std::string& m) { fprintf(stderr, "error: %s\n", m.c_str()); }
@@ -30,6 +32,18 @@ __global__ void ref_kernel(const float* A, int lda, const float* W, const float*
     C[(size_t)row * ldc + col] = v;
 }
 
+static unsigned short h_f2bf(float x) { unsigned u; memcpy(&u, &x, 4); return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16); }
+static float h_bf2f(unsigned short b) { unsigned u = (unsigned)b << 16; float f; memcpy(&f, &u, 4); return f; }
+static void make_bf16(Layer& L) {
+    const size_t n = (size_t)L.taps * L.N * L.K;
+    std::vector<float> w(n);
+    hipMemcpy(w.data(), L.w, n * 4, hipMemcpyDeviceToHost);
+    std::vector<unsigned short> hi(n), lo(n);
+    for (size_t i = 0; i < n; ++i) { hi[i] = h_f2bf(w[i]); lo[i] = h_f2bf(w[i] - h_bf2f(hi[i])); }
+    hipMalloc(&L.wb_hi, n * 2); hipMalloc(&L.wb_lo, n * 2);
+    hipMemcpy(L.wb_hi, hi.data(), n * 2, hipMemcpyHostToDevice);
+    hipMemcpy(L.wb_lo, lo.data(), n * 2, hipMemcpyHostToDevice);
+}
 static float* dev_rand(size_t n, unsigned seed, float scale) {
     std::vector<float> h(n);
     srand(seed);
@@ -67,12 +81,19 @@ int main(int argc, char** argv) {
         Layer L; L.taps = c.taps; L.K = c.K; L.N = c.N;
         L.w = dev_rand((size_t)c.taps * c.N * c.K, 1, 0.05f);
         L.bias = dev_rand(c.N, 2, 0.1f);
+        const char* mode = getenv("GEM_BENCH_MODE");
+        const int nprod = mode && !strcmp(mode, "bf16") ? 1 : (mode && !strcmp(mode, "bf16x3") ? 3 : 0);
+        if (nprod) make_bf16(L);
+        auto run = [&](const float* A_, const float* aux_, float* C_) {
+            return nprod ? launch_gemm_bf16(&h, L, c.epi, nprod, A_, c.K, aux_, C_, c.N, c.M, T, s, nullptr)
+                         : launch_gemm(&h, L, c.epi, A_, c.K, aux_, C_, c.N, c.M, T, s, c.family);
+        };
         float* A = dev_rand((size_t)c.M * c.K, 3, 1.f);
         float* aux = dev_rand((size_t)c.M * c.N, 4, 1.f);
         float *C, *R;
         hipMalloc(&C, (size_t)c.M * c.N * 4); hipMalloc(&R, (size_t)c.M * c.N * 4);
         hipMemset(C, 0, (size_t)c.M * c.N * 4);
-        if (launch_gemm(&h, L, c.epi, A, c.K, aux, C, c.N, c.M, T, s, c.family)) return 1;
+        if (run(A, aux, C)) return 1;
         hipLaunchKernelGGL(ref_kernel, dim3((c.N + 63) / 64, c.M), dim3(64), 0, s, A, c.K, L.w, L.bias, aux, R, c.N, c.M, c.N, c.K, T, c.taps, c.epi);
         hipStreamSynchronize(s);
         std::vector<float> hc((size_t)c.M * c.N), hr((size_t)c.M * c.N);
@@ -80,9 +101,9 @@ int main(int argc, char** argv) {
         hipMemcpy(hr.data(), R, hr.size() * 4, hipMemcpyDeviceToHost);
         double maxerr = 0, maxref = 0;
         for (size_t i = 0; i < hc.size(); ++i) { maxerr = fmax(maxerr, fabs(hc[i] - hr[i])); maxref = fmax(maxref, fabs(hr[i])); }
-        for (int i = 0; i < 5; ++i) launch_gemm(&h, L, c.epi, A, c.K, aux, C, c.N, c.M, T, s, c.family);
+        for (int i = 0; i < 5; ++i) run(A, aux, C);
         hipEventRecord(e0, s);
-        for (int i = 0; i < iters; ++i) launch_gemm(&h, L, c.epi, A, c.K, aux, C, c.N, c.M, T, s, c.family);
+        for (int i = 0; i < iters; ++i) run(A, aux, C);
         hipEventRecord(e1, s);
         hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
