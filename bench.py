@@ -41,6 +41,7 @@ def parse():
     p.add_argument("--workload", default="seq2k", help="seq2k (20 chunks, 240 windows) | w8192 | <number of chunks>")
     p.add_argument("--fit-steps", type=int, default=2000, help="Adam steps to fit the synthetic VAEs (untimed)")
     p.add_argument("--cpu-windows", type=int, default=12, help="windows of the CPU baseline sample (0 = skip)")
+    p.add_argument("--no-extra", action="store_true", help="skip the bf16x3 / bf16 side measurements")
     p.add_argument("--no-profile", action="store_true", help="no HIP-event timing of the dominant kernel")
     p.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "bf16"],
                    help="arithmetic of the wide decoder/encoder products (f32 = BASELINE configs[1])")
@@ -180,6 +181,29 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- side measurement (not `value`): the same workload in the faster arithmetic modes of the wide products
+    other = {}
+    if a.precision == "f32" and not a.no_extra:
+        for mode in ("bf16x3", "bf16"):
+            eng.set_precision(mode)
+            step()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            t1 = time.perf_counter()
+            for _ in range(a.steps):
+                m2, g2, s2 = step()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            dt = time.perf_counter() - t1
+            if world > 1:
+                t = torch.tensor([dt], device=device, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            other[mode] = (dt, g2.cpu().numpy() if rank == 0 else None)
+        eng.set_precision("f32")
+
     if rank == 0:
         st = stats_to_numpy(stats)
         assert (st["status"] == 1).all(), "a window did not finish"
@@ -195,6 +219,12 @@ def main():
             homo = np.concatenate([seqd["est_local_np"][c * CHUNK:c * CHUNK + n_out], np.ones((n_out, 15, 1))], -1)
             est_seq.append(np.einsum("nij,nkj->nki", seqd["cams_np"][c * CHUNK:c * CHUNK + n_out], homo)[..., :3])
         mp_opt, mp_in = mpjpe(np.concatenate(opt_seq), np.concatenate(gt_seq)), mpjpe(np.concatenate(est_seq), np.concatenate(gt_seq))
+
+        def seq_mpjpe(gl):
+            o = [final_smooth(merge_batches(gl[c * per:(c + 1) * per])) for c in range(n_chunks)]
+            return mpjpe(np.concatenate(o), np.concatenate(gt_seq))
+        other_modes = {m: {"windows_per_s": round(B * world * a.steps / dt, 2), "ms_per_step": round(dt / a.steps * 1e3, 3),
+                           "mpjpe_optimised_mm": round(seq_mpjpe(gl) * 1e3, 3)} for m, (dt, gl) in other.items()}
         roof = None
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_dominant_kernel.json")
@@ -244,6 +274,7 @@ def main():
             "mpjpe_mm": {"input": round(mp_in * 1e3, 3), "optimised": round(mp_opt * 1e3, 3)},
             "roofline": roof,
             "cpu_baseline": cpu,
+            "other_precisions": other_modes or None,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -121,8 +121,28 @@ int launch_gemm(gem_handle* h, const Layer& L, int epi, const float* A, int lda,
                 int M, int T, hipStream_t s, int family, const int* row_map = nullptr);
 
 int pick_splitk(const gem_handle* h, long blocks, int n_tiles, size_t slab_elems);
+
+// Device-adaptive split-K of the evaluation rounds: the launch has W workgroups; with M rows still active
+// there are RT = ceil(M/BM) row tiles, and the K walk of every (row tile, column tile) is cut into as many
+// slices as the W workgroups allow (at least 4 k-tiles per slice).  Used identically by the GEMM kernels and
+// by splitk_reduce_kernel.  All M == M_host rounds reproduce the static configuration.
+struct DynSplit { int RT, SK, per; size_t slab; };
+__host__ __device__ inline DynSplit dyn_split(int M, int BM, int CT, int W, int n_tiles, int ldc) {
+    DynSplit d;
+    d.RT = (M + BM - 1) / BM;
+    if (d.RT < 1) d.RT = 1;
+    int cap = W / (d.RT * CT);
+    if (cap < 1) cap = 1;
+    int mx = n_tiles / 4;
+    if (mx < 1) mx = 1;
+    const int sk = cap < mx ? cap : mx;
+    d.per = (n_tiles + sk - 1) / sk;
+    d.SK = (n_tiles + d.per - 1) / d.per;
+    d.slab = (size_t)d.RT * BM * ldc;
+    return d;
+}
 int launch_splitk_reduce(gem_handle* h, int epi, int nslab, size_t slab, const float* bias, const float* aux, float* C, int M, int N,
-                         int ldc, const int* m_dev, hipStream_t s);
+                         int ldc, const int* m_dev, hipStream_t s, int dyn_W = 0, int n_tiles = 0);
 // bf16-input MFMA variant of launch_gemm (gemm_bf16.hip): nprod = 1 (plain bf16) or 3 (hi/lo split, fp32-grade)
 int launch_gemm_bf16(gem_handle* h, const Layer& L, int epi, int nprod, const float* A, int lda, const float* aux, float* Cout,
                      int ldc, int M, int T, hipStream_t s, const int* row_map);

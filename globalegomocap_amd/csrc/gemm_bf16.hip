@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const float* __restrict_
                                                         const uint16_t* __restrict__ Wlo, const float* __restrict__ bias,
                                                         const float* __restrict__ aux, float* __restrict__ C, int ldc, int M, int N,
                                                         int K, int T, int tiles_per_slice, size_t slab_stride,
-                                                        const int* __restrict__ m_dev, const int* __restrict__ row_map) {
+                                                        const int* __restrict__ m_dev, const int* __restrict__ row_map, int dyn_W) {
     constexpr int BM = 64, BN = 64, BK = 64;
     constexpr int LD = BK + 8;                       // bf16 elements per LDS row (16-byte pad)
     constexpr int IMG = BM * LD;                     // one [64][LD] bf16 image
@@ -43,14 +43,29 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const float* __restrict_
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     if (m_dev) M = *m_dev;
-    if (m0 >= M) return;
     const int kTiles = K / BK;
-    const bool split_k = gridDim.z > 1;
-    const int kt_begin = blockIdx.z * tiles_per_slice;
-    const int kt_end = min(TAPS * kTiles, kt_begin + tiles_per_slice);
-    if (split_k) C += (size_t)blockIdx.z * slab_stride;
+    bool split_k = gridDim.z > 1;
+    int kt_begin = blockIdx.z * tiles_per_slice;
+    int kt_end = min(TAPS * kTiles, kt_begin + tiles_per_slice);
+    if (dyn_W > 0) {                      // evaluation rounds: slices re-cut for the active rows (dyn_split)
+        if (M <= 0) return;
+        const int CT = N / BN;
+        const DynSplit d = dyn_split(M, BM, CT, dyn_W, TAPS * kTiles, ldc);
+        const int id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if (id >= CT * d.RT * d.SK) return;
+        const int ks = id / (CT * d.RT);
+        n0 = (id % CT) * BN;
+        m0 = ((id / CT) % d.RT) * BM;
+        kt_begin = ks * d.per;
+        kt_end = min(TAPS * kTiles, kt_begin + d.per);
+        split_k = true;
+        C += (size_t)ks * d.slab;
+    } else {
+        if (m0 >= M) return;
+        if (split_k) C += (size_t)blockIdx.z * slab_stride;
+    }
 
     // A tile: 64 rows x 64 fp32 = 1024 float4 -> 4 per thread (16 threads per row, 16 rows per pass)
     // B tile: 64 rows x 64 bf16 = 512 x 16 B   -> 2 per thread (8 threads per row, 32 rows per pass)
@@ -174,11 +189,12 @@ static int launch_b(gem_handle* h, const Layer& L, const float* A, int lda, cons
         if (want > shmem) shmem = want;
     }
     float* out = grid.z == 1 ? C : h->ws.splitk;
+    const int dyn_W = (m_dev && grid.z > 1 && (size_t)wgs * 64 * 64 <= h->ws.splitk_elems) ? (int)wgs : 0;
     hipLaunchKernelGGL(k, grid, dim3(256), shmem, s, A, lda, L.wb_hi, L.wb_lo, L.bias, aux, out, ldc, M, L.N, L.K, T,
-                       grid.z == 1 ? n_tiles : per, grid.z == 1 ? (size_t)0 : slab, m_dev, row_map);
+                       grid.z == 1 ? n_tiles : per, grid.z == 1 ? (size_t)0 : slab, m_dev, row_map, dyn_W);
     GEM_HIP(hipGetLastError());
     if (grid.z == 1) return 0;
-    return launch_splitk_reduce(h, EPI, (int)grid.z, slab, L.bias, aux, C, M, L.N, ldc, m_dev, s);
+    return launch_splitk_reduce(h, EPI, (int)grid.z, slab, L.bias, aux, C, M, L.N, ldc, m_dev, s, dyn_W, n_tiles);
 }
 
 template <int TAPS, int EPI>

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                                                        const float* __restrict__ aux, float* __restrict__ C,
                                                        int ldc, int M, int N, int K, int T, int tiles_per_slice,
                                                        size_t slab_stride, const int* __restrict__ m_dev,
-                                                       const int* __restrict__ row_map) {
+                                                       const int* __restrict__ row_map, int dyn_W) {
     constexpr int BM = 64 * RM, BN = 64 * RN;
     constexpr int LDS_LD = BK + 4;
     constexpr int TPR = BK / 4;             // threads per tile row (one float4 each)
@@ -45,15 +45,31 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     if (m_dev) M = *m_dev;                 // rows in use this round (active windows are compacted to the front)
-    if (m0 >= M) return;
     const int kTiles = K / BK;
-    // split-K: blockIdx.z owns k-tiles [kt_begin, kt_end) of the TAPS*K/BK tiles and writes a raw partial slab
-    const bool split = gridDim.z > 1;
-    const int kt_begin = blockIdx.z * tiles_per_slice;
-    const int kt_end = min(TAPS * kTiles, kt_begin + tiles_per_slice);
-    if (split) C += (size_t)blockIdx.z * slab_stride;
+    // split-K: a slice owns k-tiles [kt_begin, kt_end) of the TAPS*K/BK tiles and writes a raw partial slab
+    bool split = gridDim.z > 1;
+    int kt_begin = blockIdx.z * tiles_per_slice;
+    int kt_end = min(TAPS * kTiles, kt_begin + tiles_per_slice);
+    if (dyn_W > 0) {
+        // evaluation rounds: re-cut the grid for the rows that are still active (see dyn_split)
+        if (M <= 0) return;
+        const int CT = N / BN;
+        const DynSplit d = dyn_split(M, BM, CT, dyn_W, TAPS * kTiles, ldc);
+        const int id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if (id >= CT * d.RT * d.SK) return;
+        const int ks = id / (CT * d.RT);
+        n0 = (id % CT) * BN;
+        m0 = ((id / CT) % d.RT) * BM;
+        kt_begin = ks * d.per;
+        kt_end = min(TAPS * kTiles, kt_begin + d.per);
+        split = true;
+        C += (size_t)ks * d.slab;
+    } else {
+        if (m0 >= M) return;
+        if (split) C += (size_t)blockIdx.z * slab_stride;
+    }
 
     // ---- per-thread global load coordinates (branch-free: out-of-range rows read row 0 and are zeroed)
     const int c4 = (tid % TPR) * 4;
@@ -180,8 +196,13 @@ template <int EPI>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int nslab, size_t slab_stride,
                                                             const float* __restrict__ bias, const float* __restrict__ aux,
                                                             float* __restrict__ C, int M, int N, int ldc,
-                                                            const int* __restrict__ m_dev) {
+                                                            const int* __restrict__ m_dev, int dyn_W, int n_tiles) {
     if (m_dev) M = *m_dev;
+    if (dyn_W > 0) {                     // slices and slab stride of this round, as the GEMM kernel computed them
+        const DynSplit d = dyn_split(M, 64, N / 64, dyn_W, n_tiles, ldc);
+        nslab = d.SK;
+        slab_stride = d.slab;
+    }
     const int n4 = N / 4;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)M * n4) return;
@@ -225,14 +246,14 @@ int pick_splitk(const gem_handle* h, long blocks, int n_tiles, size_t slab_elems
 }
 
 int launch_splitk_reduce(gem_handle* h, int epi, int nslab, size_t slab, const float* bias, const float* aux, float* C, int M, int N,
-                         int ldc, const int* m_dev, hipStream_t s) {
+                         int ldc, const int* m_dev, hipStream_t s, int dyn_W, int n_tiles) {
     const size_t n4 = (size_t)M * (N / 4);
     const dim3 grid((unsigned)((n4 + 255) / 256));
     switch (epi) {
-        case EPI_BIAS: hipLaunchKernelGGL(splitk_reduce_kernel<EPI_BIAS>, grid, dim3(256), 0, s, h->ws.splitk, nslab, slab, bias, aux, C, M, N, ldc, m_dev); break;
-        case EPI_BIAS_LRELU: hipLaunchKernelGGL(splitk_reduce_kernel<EPI_BIAS_LRELU>, grid, dim3(256), 0, s, h->ws.splitk, nslab, slab, bias, aux, C, M, N, ldc, m_dev); break;
-        case EPI_MASK: hipLaunchKernelGGL(splitk_reduce_kernel<EPI_MASK>, grid, dim3(256), 0, s, h->ws.splitk, nslab, slab, bias, aux, C, M, N, ldc, m_dev); break;
-        default: hipLaunchKernelGGL(splitk_reduce_kernel<EPI_NONE>, grid, dim3(256), 0, s, h->ws.splitk, nslab, slab, bias, aux, C, M, N, ldc, m_dev); break;
+        case EPI_BIAS: hipLaunchKernelGGL(splitk_reduce_kernel<EPI_BIAS>, grid, dim3(256), 0, s, h->ws.splitk, nslab, slab, bias, aux, C, M, N, ldc, m_dev, dyn_W, n_tiles); break;
+        case EPI_BIAS_LRELU: hipLaunchKernelGGL(splitk_reduce_kernel<EPI_BIAS_LRELU>, grid, dim3(256), 0, s, h->ws.splitk, nslab, slab, bias, aux, C, M, N, ldc, m_dev, dyn_W, n_tiles); break;
+        case EPI_MASK: hipLaunchKernelGGL(splitk_reduce_kernel<EPI_MASK>, grid, dim3(256), 0, s, h->ws.splitk, nslab, slab, bias, aux, C, M, N, ldc, m_dev, dyn_W, n_tiles); break;
+        default: hipLaunchKernelGGL(splitk_reduce_kernel<EPI_NONE>, grid, dim3(256), 0, s, h->ws.splitk, nslab, slab, bias, aux, C, M, N, ldc, m_dev, dyn_W, n_tiles); break;
     }
     GEM_HIP(hipGetLastError());
     return 0;
@@ -264,16 +285,18 @@ static int launch_one(gem_handle* h, const Layer& L, const float* A, int lda, co
         const size_t want = ((size_t)LDS_PER_CU / per_cu) & ~(size_t)1023;
         if (want > shmem) shmem = want;
     }
+    // evaluation rounds on small batches: slices re-cut on the device for the rows that are still active
+    const bool dyn = m_dev && RM * RN == 1 && grid.z > 1 && (size_t)wgs * 64 * BN <= h->ws.splitk_elems;
     if (grid.z == 1) {
         hipLaunchKernelGGL(k, grid, dim3(256), shmem, s, A, lda, L.w, L.bias, aux, C, ldc, M, L.N, L.K, T, n_tiles, (size_t)0, m_dev,
-                           row_map);
+                           row_map, 0);
         GEM_HIP(hipGetLastError());
         return 0;
     }
     hipLaunchKernelGGL(k, grid, dim3(256), shmem, s, A, lda, L.w, L.bias, aux, h->ws.splitk, ldc, M, L.N, L.K, T, per, slab, m_dev,
-                       row_map);
+                       row_map, dyn ? (int)wgs : 0);
     GEM_HIP(hipGetLastError());
-    return launch_splitk_reduce(h, EPI, (int)grid.z, slab, L.bias, aux, C, M, L.N, ldc, m_dev, s);
+    return launch_splitk_reduce(h, EPI, (int)grid.z, slab, L.bias, aux, C, M, L.N, ldc, m_dev, s, dyn ? (int)wgs : 0, n_tiles);
 }
 
 template <int TAPS, int EPI, int TAG>
