@@ -4,9 +4,9 @@
 // After the first (wide) decoder layers the network is narrow (128 -> 64 -> 64 -> 64 -> 45 channels):
 // as separate launches these layers, the energy kernel and their adjoints are ~15 dependent kernels of
 // a few microseconds each per evaluation, dominated by launch boundaries and split-K reduce passes.
-// Here one workgroup (4 waves) owns G = floor(32/T) windows = G*T <= 32 rows (one 32-row MFMA tile):
+// Here one workgroup (8 waves) owns G = floor(32/T) windows = G*T <= 32 rows (two 16-row MFMA tiles):
 //
-//   a_in rows -> LDS;  for each fused layer:  act[i+1] = lrelu(conv3(act[i]) + b)   (v_mfma_f32_32x32x2_f32)
+//   a_in rows -> LDS;  for each fused layer:  act[i+1] = lrelu(conv3(act[i]) + b)   (v_mfma_f32_16x16x4_f32)
 //   X = act[n] -> energy terms + dE/dX per window (one wave per window, energy_device.h)
 //   backward-data through the same layers with the LeakyReLU' masks taken from the LDS activations
 //   -> gradient w.r.t. a_in written to HBM for the remaining (wide) backward layers.
@@ -15,11 +15,12 @@
 // window, zero outside).  B operands (weights) are read straight from L2 into registers: fp32 MFMA is
 // slow enough (64 cycles per instruction) that one coalesced 16-byte load per 4 MFMAs is free; the tail
 // weights are stored [tap][K/4][N][4] so that the 32 lanes of a half-wave read 512 contiguous bytes.
-// With N = 64 there are only two 32-wide column tiles, so the 4 waves split K two ways and combine
-// partial tiles through LDS.
+// Output tiles are 16x16 (v_mfma_f32_16x16x4_f32): a 64-wide layer is 8 tiles = one per wave, full K each.
 //
 // Reference semantics: ConvTranspose1d/Conv1d k=3 s=1 p=1 + BatchNorm(eval) + LeakyReLU of
 // networks/models/SeqConvVAE.py:67-92 (folded at load time), total_loss of optimizer.py:226-240.
+#include <algorithm>
+
 #include "energy_device.h"
 
 namespace gem {
@@ -27,129 +28,114 @@ namespace gem {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// B fragments of the first (tile, k-block) a wave will need in layer L: issued before the barrier that ends the
-// previous layer, so that their L2 latency overlaps the epilogue / barrier / energy phase.
+// 8 waves per workgroup = 2 per SIMD: the per-block latency chain (L2 weight fragment -> LDS fragment -> 16 MFMAs)
+// of one wave overlaps the other's, and K is cut twice as fine (each wave walks half as many blocks).
+constexpr int TAIL_WAVES = 8;
+constexpr int TAIL_THREADS = TAIL_WAVES * 64;
+
+// Tiling: 16x16 output tiles (v_mfma_f32_16x16x4_f32), tile t -> (row half t&1, 16-column group t>>1), tile
+// t = wave, wave+8, ...: a 64-wide layer is exactly 8 tiles = one per wave with the FULL K walk, so no partial
+// sums have to be combined through LDS.  K blocks of 64: lane (r = lane&15, q = lane>>4) holds, for each of the
+// four 16-deep groups g, the float4 A[row r][k0+16g+4q .. +3] (LDS) and B[k0+16g+4q .. +3][col r] (L2, layout
+// [tap][K/4][N][4]: 16 lanes read 256 contiguous bytes); MFMA step j of group g uses component j of both, i.e.
+// the k-pairing is a permutation inside the group, which a sum over k does not care about.
+struct TailGeom {
+    int kb, nblk, K4N;
+};
+
+// B fragments of the first block of the first tile a wave owns in layer L: issued before the barrier that ends
+// the previous layer, so that their L2 latency overlaps the epilogue / barrier / energy phase.
 __device__ __forceinline__ void tail_prefetch_first(const TailLayerDev L, f32x4 (&dst)[4]) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 31, fh = lane >> 5;
-    const int ntiles = L.N / 32;
-    const int ksplit = ntiles >= 4 ? 1 : 4 / ntiles;
-    const int kpart = ksplit > 1 ? wave / ntiles : 0;
-    const int kb = L.K / 32, nblk = 3 * kb;
-    const int blk0 = kpart * nblk / ksplit;
-    const int tile = ksplit > 1 ? wave % ntiles : wave;
-    const int tap = blk0 / kb, k0 = (blk0 - tap * kb) * 32;
-    const f32x4* p = reinterpret_cast<const f32x4*>(L.w4) + (size_t)tap * (L.K / 4) * L.N + (size_t)(k0 / 4 + fh) * L.N + tile * 32 + fr;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 15, q = lane >> 4;
+    const int n0 = (wave >> 1) * 16;
+    const f32x4* p = reinterpret_cast<const f32x4*>(L.w4) + (size_t)q * L.N + n0 + c;       // tap 0, k0 = 0
 #pragma unroll
-    for (int c = 0; c < 4; ++c) dst[c] = p[(size_t)(2 * c) * L.N];
+    for (int g = 0; g < 4; ++g) dst[g] = p[(size_t)(4 * g) * L.N];
 }
 
-// bpre: in = fragments from tail_prefetch_first(L); out = the same for `next` (if any), issued before the epilogue
+// bpre: in = fragments from tail_prefetch_first(L); out = the same for `next` (if any), issued before the epilogue.
+// epi(acc, tile_row0, col, bias_value) receives the 4 rows tile_row0 + 4*(lane>>4) + {0..3} of column `col`.
 template <typename Epi>
 __device__ __forceinline__ void tail_gemm(const float* in, int ld_in, const TailLayerDev L, const TailLayerDev next, bool has_next,
-                                          int T, int R, float* red, f32x4 (&bpre)[4], Epi epi) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 31, fh = lane >> 5;
-    const int ntiles = L.N / 32;
-    const int ksplit = ntiles >= 4 ? 1 : 4 / ntiles;          // ntiles is even (N is a multiple of 64)
-    const int kpart = ksplit > 1 ? wave / ntiles : 0;
-    const int kb = L.K / 32;
-    const int nblk = 3 * kb;                                  // (tap, 32-wide k block) pairs
-    const int blk0 = kpart * nblk / ksplit, blk1 = (kpart + 1) * nblk / ksplit;
-    const int t_row = fr % T;
-    const bool row_ok = fr < R;
+                                          int T, int R, f32x4 (&bpre)[4], Epi epi) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int ntiles = 2 * (L.N / 16);
+    const int kb = L.K / 64, nblk = 3 * kb;                   // (tap, 64-wide k block) pairs
     const int K4N = (L.K / 4) * L.N;                          // float4 per tap
     const f32x4* W4 = reinterpret_cast<const f32x4*>(L.w4);
-    const int tile_step = ksplit > 1 ? ntiles : 4;
-    for (int tile = ksplit > 1 ? wave % ntiles : wave; tile < ntiles; tile += tile_step) {
-        const int n0 = tile * 32;
-        f32x16 acc;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-        // B fragments of block `blk_` straight from L2: [tap][K/4][N][4], 512 contiguous bytes per half-wave
+    for (int tile = wave; tile < ntiles; tile += TAIL_WAVES) {
+        const int rt = tile & 1, n0 = (tile >> 1) * 16;
+        const int row = rt * 16 + fr;
+        const int t_row = row % T;
+        const bool row_ok = row < R;
+        const float bv = L.bias ? L.bias[n0 + fr] : 0.f;      // issued now, consumed in the epilogue
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #define TAIL_LOAD_B(blk_, dst_)                                                                        \
         {                                                                                              \
-            const int tap_ = (blk_) / kb, k0_ = ((blk_) - tap_ * kb) * 32;                             \
-            const f32x4* p_ = W4 + (size_t)tap_ * K4N + (size_t)(k0_ / 4 + fh) * L.N + n0 + fr;        \
-            _Pragma("unroll") for (int c = 0; c < 4; ++c) dst_[c] = p_[(size_t)(2 * c) * L.N];         \
+            const int tap_ = ((blk_) >= kb) + ((blk_) >= 2 * kb), k0_ = ((blk_) - tap_ * kb) * 64;     \
+            const f32x4* p_ = W4 + (size_t)tap_ * K4N + (size_t)(k0_ / 4 + fq) * L.N + n0 + fr;        \
+            _Pragma("unroll") for (int g = 0; g < 4; ++g) dst_[g] = p_[(size_t)(4 * g) * L.N];         \
         }
-        // A fragments of block `blk_` from LDS (rows t-1 / t / t+1 of the same window, zero outside)
 #define TAIL_LOAD_A(blk_, dst_)                                                                        \
         {                                                                                              \
-            const int tap_ = (blk_) / kb, k0_ = ((blk_) - tap_ * kb) * 32;                             \
+            const int tap_ = ((blk_) >= kb) + ((blk_) >= 2 * kb), k0_ = ((blk_) - tap_ * kb) * 64;     \
             const int tt_ = t_row + tap_ - 1;                                                          \
             const bool ok_ = row_ok && tt_ >= 0 && tt_ < T;                                            \
-            const float* arow_ = in + (ok_ ? fr + tap_ - 1 : 0) * ld_in + k0_ + 4 * fh;                \
-            _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                            \
-                dst_[c] = *reinterpret_cast<const f32x4*>(arow_ + 8 * c);                              \
-                if (!ok_) dst_[c] = f32x4{0.f, 0.f, 0.f, 0.f};                                         \
+            const float* arow_ = in + (ok_ ? row + tap_ - 1 : 0) * ld_in + k0_ + 4 * fq;               \
+            _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                            \
+                dst_[g] = *reinterpret_cast<const f32x4*>(arow_ + 16 * g);                             \
+                if (!ok_) dst_[g] = f32x4{0.f, 0.f, 0.f, 0.f};                                         \
             }                                                                                          \
         }
 #define TAIL_COMPUTE(a_, b_)                                                                           \
         {                                                                                              \
-            _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                            \
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[c].x, b_[c].x, acc, 0, 0, 0);            \
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[c].y, b_[c].y, acc, 0, 0, 0);            \
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[c].z, b_[c].z, acc, 0, 0, 0);            \
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[c].w, b_[c].w, acc, 0, 0, 0);            \
+            _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                            \
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_[g].x, b_[g].x, acc, 0, 0, 0);            \
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_[g].y, b_[g].y, acc, 0, 0, 0);            \
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_[g].z, b_[g].z, acc, 0, 0, 0);            \
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_[g].w, b_[g].w, acc, 0, 0, 0);            \
             }                                                                                          \
         }
-        // two register sets for both operands, loads issued one block (16 MFMAs = 1024 cycles) ahead of use
+        // two register sets for both operands, loads issued one block (16 MFMAs) ahead of their use
         f32x4 b0[4], b1[4], a0[4], a1[4];
-        const bool first_tile = tile == (ksplit > 1 ? wave % ntiles : wave);
-        if (first_tile) {
+        if (tile == wave) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) b0[c] = bpre[c];
+            for (int g = 0; g < 4; ++g) b0[g] = bpre[g];
         } else {
-            TAIL_LOAD_B(blk0, b0);
+            TAIL_LOAD_B(0, b0);
         }
-        TAIL_LOAD_A(blk0, a0);
+        TAIL_LOAD_A(0, a0);
         // Branch-free pair loop (a conditional prefetch makes hipcc fall back to vmcnt(0) at the join) with
         // sched_barriers (otherwise both prefetches are hoisted to the loop top and waited for together).
-        const int npairs = (blk1 - blk0) / 2;
+        const int npairs = nblk / 2;
         for (int p = 0; p < npairs; ++p) {
-            const int blk = blk0 + 2 * p;
+            const int blk = 2 * p;
             TAIL_LOAD_B(blk + 1, b1);
             TAIL_LOAD_A(blk + 1, a1);
             __builtin_amdgcn_sched_barrier(0);
             TAIL_COMPUTE(a0, b0);
             __builtin_amdgcn_sched_barrier(0);
-            const int nxt = min(blk + 2, blk1 - 1);            // last pair: harmless re-load of the final block
+            const int nxt = min(blk + 2, nblk - 1);            // last pair: harmless re-load of the final block
             TAIL_LOAD_B(nxt, b0);
             TAIL_LOAD_A(nxt, a0);
             __builtin_amdgcn_sched_barrier(0);
             TAIL_COMPUTE(a1, b1);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if ((blk1 - blk0) & 1) TAIL_COMPUTE(a0, b0);
-        if (has_next && tile + tile_step >= ntiles) tail_prefetch_first(next, bpre);     // last tile of this wave
+        if (nblk & 1) TAIL_COMPUTE(a0, b0);
+        if (has_next && tile + TAIL_WAVES >= ntiles) tail_prefetch_first(next, bpre);     // last tile of this wave
 #undef TAIL_LOAD_A
 #undef TAIL_LOAD_B
 #undef TAIL_COMPUTE
-        if (ksplit > 1) {
-            // every wave runs exactly one tile here, so the barriers are uniform
-            if (kpart > 0) {
-                float* r = red + ((kpart - 1) * ntiles + tile) * 1024 + lane;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) r[e * 64] = acc[e];
-            }
-            __syncthreads();
-            if (kpart == 0) {
-                for (int p = 1; p < ksplit; ++p) {
-                    const float* r = red + ((p - 1) * ntiles + tile) * 1024 + lane;
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[e] += r[e * 64];
-                }
-                epi(acc, n0);
-            }
-            __syncthreads();
-        } else {
-            epi(acc, n0);
-        }
+        epi(acc, rt * 16 + 4 * fq, n0 + fr, bv);
     }
 }
 
-__global__ __launch_bounds__(256, 1) void decoder_tail_kernel(TailArgs a) {
+__global__ __launch_bounds__(TAIL_THREADS, 2) void decoder_tail_kernel(TailArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 31, fh = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 31, fh = lane >> 5;
     const int T = a.e.T;
     const int w0 = blockIdx.x * a.G;                         // first slot of this workgroup
     const int B = a.e.n_dev ? *a.e.n_dev : a.B;              // active slots this round
@@ -157,13 +143,12 @@ __global__ __launch_bounds__(256, 1) void decoder_tail_kernel(TailArgs a) {
     const int nwin = min(a.G, B - w0);
     const int R = nwin * T;                                  // valid rows
     const size_t row0 = (size_t)w0 * T;
-    float* red = lds + a.off_red;
 
     // ---- stage the input activation rows
     {
         const int K0 = a.fwd[0].K, q4 = K0 / 4;
         float* dst = lds + a.off_act[0];
-        for (int i = tid; i < 32 * q4; i += 256) {
+        for (int i = tid; i < 32 * q4; i += TAIL_THREADS) {
             const int r = i / q4, c = (i - r * q4) * 4;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (r < R) v = *reinterpret_cast<const f32x4*>(a.a_in + (row0 + r) * K0 + c);
@@ -179,23 +164,19 @@ __global__ __launch_bounds__(256, 1) void decoder_tail_kernel(TailArgs a) {
         const bool last = (i + 1 == a.n);
         float* out = lds + a.off_act[i + 1];
         const int ldo = a.ld_act[i + 1];
-        const float* bias = a.fwd[i].bias;
         float* Xp = last ? a.Xp : nullptr;
         // (by value: taking the address of a kernel-argument member would put the whole struct in scratch)
         const TailLayerDev nxt = !last ? a.fwd[i + 1] : a.bwd[a.n - 1];
-        tail_gemm(lds + a.off_act[i], a.ld_act[i], a.fwd[i], nxt, !last || !a.forward_only, T, R, red, bpre,
-                  [&](const f32x16& acc, int n0) {
-            const int col = n0 + fr;
-            const float bv = bias[col];
+        tail_gemm(lds + a.off_act[i], a.ld_act[i], a.fwd[i], nxt, !last || !a.forward_only, T, R, bpre,
+                  [&](const f32x4& acc, int r0, int col, float bv) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = (e & 3) + 8 * (e >> 2) + 4 * fh;
-                float v = acc[e] + bv;
-                if (!last) v = v > 0.f ? v : v * LEAKY_SLOPE;
-                out[row * ldo + col] = v;
-                if (Xp && row < R) Xp[(row0 + row) * PAD + col] = v;
-            }
-        });
+                      for (int e = 0; e < 4; ++e) {
+                          float v = acc[e] + bv;
+                          if (!last) v = v > 0.f ? v : v * LEAKY_SLOPE;
+                          out[(r0 + e) * ldo + col] = v;
+                          if (Xp && r0 + e < R) Xp[(row0 + r0 + e) * PAD + col] = v;
+                      }
+                  });
         __syncthreads();
     }
     if (a.forward_only) return;
@@ -205,7 +186,8 @@ __global__ __launch_bounds__(256, 1) void decoder_tail_kernel(TailArgs a) {
     float* g_nxt = lds + a.off_g[1];
     if (wave < nwin) {
         float* scr = lds + a.off_escr + wave * 4 * a.escr;
-        energy_window<false>(a.e, a.e.perm ? a.e.perm[w0 + wave] : w0 + wave, lane, lds + a.off_act[a.n] + wave * T * a.ld_act[a.n], a.ld_act[a.n], scr, scr + a.escr,
+        energy_window<false>(a.e, a.e.perm ? a.e.perm[w0 + wave] : w0 + wave, lane,
+                             lds + a.off_act[a.n] + wave * T * a.ld_act[a.n], a.ld_act[a.n], scr, scr + a.escr,
                              scr + 2 * a.escr, scr + 3 * a.escr, g_cur + wave * T * a.ld_g, a.ld_g, a.fwd[a.n - 1].N);
     }
     __syncthreads();
@@ -217,16 +199,16 @@ __global__ __launch_bounds__(256, 1) void decoder_tail_kernel(TailArgs a) {
         const int ldg = a.ld_g;
         float* gout = a.g_out;
         const int K0 = a.fwd[0].K;
-        tail_gemm(g_cur, a.ld_g, a.bwd[i], a.bwd[i > 0 ? i - 1 : 0], i > 0, T, R, red, bpre, [&](const f32x16& acc, int n0) {
-            const int col = n0 + fr;
+        tail_gemm(g_cur, a.ld_g, a.bwd[i], a.bwd[i > 0 ? i - 1 : 0], i > 0, T, R, bpre,
+                  [&](const f32x4& acc, int r0, int col, float) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = (e & 3) + 8 * (e >> 2) + 4 * fh;
-                const float v = acc[e] * (act[row * lda + col] > 0.f ? 1.f : LEAKY_SLOPE);
-                if (i > 0) g_nxt[row * ldg + col] = v;
-                else if (row < R) gout[(row0 + row) * K0 + col] = v;
-            }
-        });
+                      for (int e = 0; e < 4; ++e) {
+                          const int row = r0 + e;
+                          const float v = acc[e] * (act[row * lda + col] > 0.f ? 1.f : LEAKY_SLOPE);
+                          if (i > 0) g_nxt[row * ldg + col] = v;
+                          else if (row < R) gout[(row0 + row) * K0 + col] = v;
+                      }
+                  });
         __syncthreads();
         float* t = g_cur; g_cur = g_nxt; g_nxt = t;
     }
@@ -251,9 +233,10 @@ size_t plan_tail(const std::vector<Layer>& dec, int start, int T, int J, TailArg
     a.ld_g = maxg + 4;
     a.off_g[0] = off; off += 32 * a.ld_g;
     a.off_g[1] = off; off += 32 * a.ld_g;
-    a.off_red = off; off += 3 * 1024;
     a.escr = (T * J * 3 + 3) / 4 * 4;
-    a.off_escr = off; off += a.G * 4 * a.escr;
+    a.off_red = off;                       // (unused since the 16x16 tiling needs no k-split scratch)
+    a.off_escr = off;
+    off += a.G * 4 * a.escr;
     if (out) *out = a;
     return (size_t)off * sizeof(float);
 }
@@ -273,7 +256,7 @@ int launch_tail(gem_handle* h, const TailArgs& a, size_t lds_bytes, hipStream_t 
         GEM_HIP(hipEventRecord(rec.a, s));
     }
     const int wgs = (a.B + a.G - 1) / a.G;
-    hipLaunchKernelGGL(decoder_tail_kernel, dim3(wgs), dim3(256), lds_bytes, s, a);
+    hipLaunchKernelGGL(decoder_tail_kernel, dim3(wgs), dim3(TAIL_THREADS), lds_bytes, s, a);
     GEM_HIP(hipGetLastError());
     if (prof) { GEM_HIP(hipEventRecord(rec.b, s)); h->prof.recs.push_back(rec); }
     return 0;

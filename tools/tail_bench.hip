@@ -1,0 +1,79 @@
+// Stand-alone timing harness for csrc/tail.hip (developer tool).
+//   hipcc -w --offload-arch=gfx950 -O3 -std=c++17 -o tools/tail_bench tools/tail_bench.hip && ./tools/tail_bench 240
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../globalegomocap_amd/csrc/tail.hip"
+namespace gem {
+void set_error(const std::string& m) { fprintf(stderr, "error: %s\n", m.c_str()); }
+bool hip_ok(hipError_t e, const char* what) { if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", what, hipGetErrorString(e)); return false; } return true; }
+}
+using namespace gem;
+static float* dev_rand(size_t n, unsigned seed, float scale) {
+    std::vector<float> h(n); srand(seed);
+    for (size_t i = 0; i < n; ++i) h[i] = scale * ((rand() / (float)RAND_MAX) * 2.f - 1.f);
+    float* d; hipMalloc(&d, n * 4); hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice); return d;
+}
+int main(int argc, char** argv) {
+    const int B = argc > 1 ? atoi(argv[1]) : 240, iters = 50, T = 10, J = 15;
+    const int dims[6] = {256, 128, 64, 64, 64, 64};
+    std::vector<Layer> dec(6);                       // dec[0] is a dummy (not fused), dec[1..5] the fused chain
+    dec[0].K = 512; dec[0].N = 256;
+    for (int i = 1; i < 6; ++i) { dec[i].K = dims[i - 1]; dec[i].N = dims[i]; }
+    TailArgs a;
+    const size_t lds = plan_tail(dec, 1, T, J, &a);
+    printf("LDS %zu bytes, n=%d, G=%d\n", lds, a.n, a.G);
+    for (int i = 0; i < a.n; ++i) {
+        const int K = dims[i], N = dims[i + 1];
+        a.fwd[i] = TailLayerDev{dev_rand((size_t)3 * K * N, 10 + i, 0.05f), dev_rand(N, 20 + i, 0.05f), K, N};
+        a.bwd[i] = TailLayerDev{dev_rand((size_t)3 * K * N, 30 + i, 0.05f), nullptr, N, K};
+    }
+    a.B = B;
+    a.a_in = dev_rand((size_t)B * T * 256, 1, 1.f);
+    hipMalloc(&a.g_out, (size_t)B * T * 256 * 4);
+    hipMalloc(&a.Xp, (size_t)B * T * 256 * 4 + 4096);   // generous: the per-layer probe below writes up to 128 columns at stride 64
+    EnergyArgs& e = a.e;
+    e = EnergyArgs{};
+    e.X0 = dev_rand((size_t)B * T * 45, 2, 1.f);
+    const int F = 8 * B + 10;
+    hipMalloc((void**)&e.heat, (size_t)F * 64 * 64 * 15 * 4); hipMemset((void*)e.heat, 0, (size_t)F * 64 * 64 * 15 * 4);
+    std::vector<int> f0(B); for (int b = 0; b < B; ++b) f0[b] = 8 * b;
+    hipMalloc((void**)&e.frame0, B * 4); hipMemcpy((void*)e.frame0, f0.data(), B * 4, hipMemcpyHostToDevice);
+    e.mean_bone = dev_rand((size_t)B * 15, 3, 0.3f);
+    hipMalloc(&e.f, B * 8); hipMalloc(&e.parts, B * 40);
+    e.w3d = e.ws = e.wb = 0.01f; e.wv = 0; e.wr = 0.01f; e.dw3d = e.dws = e.dwb = 0.01; e.dwr = 0.01;
+    e.T = T; e.J = J; e.H = 64; e.W = 64; e.n_poly = 11;
+    const float poly[11] = {478.6f, 350.4f, 79.f, 62.3f, 32.6f, 15.7f, 7.77f, 2.19f, -0.108f, -0.19f, -0.0278f};
+    for (int i = 0; i < 11; ++i) e.poly[i] = poly[i];
+    e.cx = 659.7f; e.cy = 530.f;
+    const int par[15] = {0, 0, 1, 2, 0, 4, 5, 1, 7, 8, 9, 4, 11, 12, 13};
+    std::vector<int> ch(256, -1);
+    for (int j = 0; j < 15; ++j) { int n = 0; for (int c = 0; c < 15; ++c) if (c != j && par[c] == j) ch[j * 16 + n++] = c; }
+    int *dp, *dc; hipMalloc(&dp, 60); hipMemcpy(dp, par, 60, hipMemcpyHostToDevice);
+    hipMalloc(&dc, 1024); hipMemcpy(dc, ch.data(), 1024, hipMemcpyHostToDevice);
+    e.parents = dp; e.children = dc; e.n_dev = nullptr; e.perm = nullptr;
+    gem_handle h; h.prof.on = false;
+    hipStream_t s; hipStreamCreate(&s);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const int nfull = a.n;
+    for (int nn = 1; nn <= nfull; ++nn) {
+        a.n = nn; a.forward_only = 1;
+        for (int i = 0; i < 3; ++i) launch_tail(&h, a, lds, s);
+        hipEventRecord(e0, s);
+        for (int i = 0; i < iters; ++i) launch_tail(&h, a, lds, s);
+        hipEventRecord(e1, s); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("B=%d first %d forward layers only: %.1f us\n", B, nn, ms * 1e3 / iters);
+    }
+    a.n = nfull;
+    for (int fo = 1; fo >= 0; --fo) {
+        a.forward_only = fo;
+        for (int i = 0; i < 3; ++i) launch_tail(&h, a, lds, s);
+        hipEventRecord(e0, s);
+        for (int i = 0; i < iters; ++i) launch_tail(&h, a, lds, s);
+        hipEventRecord(e1, s); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("B=%d forward_only=%d: %.1f us\n", B, fo, ms * 1e3 / iters);
+    }
+    return 0;
+}
