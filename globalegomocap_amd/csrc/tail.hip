@@ -56,80 +56,95 @@ __device__ __forceinline__ void tail_prefetch_first(const TailLayerDev L, f32x4 
 
 // bpre: in = fragments from tail_prefetch_first(L); out = the same for `next` (if any), issued before the epilogue.
 // epi(acc, tile_row0, col, bias_value) receives the 4 rows tile_row0 + 4*(lane>>4) + {0..3} of column `col`.
-template <typename Epi>
-__device__ __forceinline__ void tail_gemm(const float* in, int ld_in, const TailLayerDev L, const TailLayerDev next, bool has_next,
-                                          int T, int R, f32x4 (&bpre)[4], Epi epi) {
+// NT = tiles per wave (N / 64): the NT tiles of a wave share their 16 rows (tiles wave, wave+8, ... have the same
+// row half), so they walk K together: one A fragment feeds NT independent accumulators.
+template <int NT, typename Epi>
+__device__ __forceinline__ void tail_gemm_nt(const float* in, int ld_in, const TailLayerDev L, const TailLayerDev next, bool has_next,
+                                             int T, int R, f32x4 (&bpre)[4], Epi epi) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
-    const int ntiles = 2 * (L.N / 16);
     const int kb = L.K / 64, nblk = 3 * kb;                   // (tap, 64-wide k block) pairs
     const int K4N = (L.K / 4) * L.N;                          // float4 per tap
     const f32x4* W4 = reinterpret_cast<const f32x4*>(L.w4);
-    for (int tile = wave; tile < ntiles; tile += TAIL_WAVES) {
-        const int rt = tile & 1, n0 = (tile >> 1) * 16;
-        const int row = rt * 16 + fr;
-        const int t_row = row % T;
-        const bool row_ok = row < R;
-        const float bv = L.bias ? L.bias[n0 + fr] : 0.f;      // issued now, consumed in the epilogue
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#define TAIL_LOAD_B(blk_, dst_)                                                                        \
-        {                                                                                              \
-            const int tap_ = ((blk_) >= kb) + ((blk_) >= 2 * kb), k0_ = ((blk_) - tap_ * kb) * 64;     \
-            const f32x4* p_ = W4 + (size_t)tap_ * K4N + (size_t)(k0_ / 4 + fq) * L.N + n0 + fr;        \
-            _Pragma("unroll") for (int g = 0; g < 4; ++g) dst_[g] = p_[(size_t)(4 * g) * L.N];         \
-        }
-#define TAIL_LOAD_A(blk_, dst_)                                                                        \
-        {                                                                                              \
-            const int tap_ = ((blk_) >= kb) + ((blk_) >= 2 * kb), k0_ = ((blk_) - tap_ * kb) * 64;     \
-            const int tt_ = t_row + tap_ - 1;                                                          \
-            const bool ok_ = row_ok && tt_ >= 0 && tt_ < T;                                            \
-            const float* arow_ = in + (ok_ ? row + tap_ - 1 : 0) * ld_in + k0_ + 4 * fq;               \
-            _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                            \
-                dst_[g] = *reinterpret_cast<const f32x4*>(arow_ + 16 * g);                             \
-                if (!ok_) dst_[g] = f32x4{0.f, 0.f, 0.f, 0.f};                                         \
-            }                                                                                          \
-        }
-#define TAIL_COMPUTE(a_, b_)                                                                           \
-        {                                                                                              \
-            _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                            \
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_[g].x, b_[g].x, acc, 0, 0, 0);            \
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_[g].y, b_[g].y, acc, 0, 0, 0);            \
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_[g].z, b_[g].z, acc, 0, 0, 0);            \
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_[g].w, b_[g].w, acc, 0, 0, 0);            \
-            }                                                                                          \
-        }
-        // two register sets for both operands, loads issued one block (16 MFMAs) ahead of their use
-        f32x4 b0[4], b1[4], a0[4], a1[4];
-        if (tile == wave) {
+    const int rt = wave & 1, n0 = (wave >> 1) * 16;           // tile i of this wave: columns n0 + 64*i
+    const int row = rt * 16 + fr;
+    const int t_row = row % T;
+    const bool row_ok = row < R;
+    float bv[NT];
+    f32x4 acc[NT];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) b0[g] = bpre[g];
-        } else {
-            TAIL_LOAD_B(0, b0);
-        }
-        TAIL_LOAD_A(0, a0);
-        // Branch-free pair loop (a conditional prefetch makes hipcc fall back to vmcnt(0) at the join) with
-        // sched_barriers (otherwise both prefetches are hoisted to the loop top and waited for together).
-        const int npairs = nblk / 2;
-        for (int p = 0; p < npairs; ++p) {
-            const int blk = 2 * p;
-            TAIL_LOAD_B(blk + 1, b1);
-            TAIL_LOAD_A(blk + 1, a1);
-            __builtin_amdgcn_sched_barrier(0);
-            TAIL_COMPUTE(a0, b0);
-            __builtin_amdgcn_sched_barrier(0);
-            const int nxt = min(blk + 2, nblk - 1);            // last pair: harmless re-load of the final block
-            TAIL_LOAD_B(nxt, b0);
-            TAIL_LOAD_A(nxt, a0);
-            __builtin_amdgcn_sched_barrier(0);
-            TAIL_COMPUTE(a1, b1);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (nblk & 1) TAIL_COMPUTE(a0, b0);
-        if (has_next && tile + TAIL_WAVES >= ntiles) tail_prefetch_first(next, bpre);     // last tile of this wave
+    for (int i = 0; i < NT; ++i) {
+        bv[i] = L.bias ? L.bias[n0 + 64 * i + fr] : 0.f;      // issued now, consumed in the epilogue
+        acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#define TAIL_LOAD_B(blk_, dst_)                                                                        \
+    {                                                                                                  \
+        const int tap_ = ((blk_) >= kb) + ((blk_) >= 2 * kb), k0_ = ((blk_) - tap_ * kb) * 64;         \
+        const f32x4* p_ = W4 + (size_t)tap_ * K4N + (size_t)(k0_ / 4 + fq) * L.N + n0 + fr;            \
+        _Pragma("unroll") for (int i = 0; i < NT; ++i)                                                 \
+            _Pragma("unroll") for (int g = 0; g < 4; ++g) dst_[i][g] = p_[(size_t)(4 * g) * L.N + 64 * i]; \
+    }
+#define TAIL_LOAD_A(blk_, dst_)                                                                        \
+    {                                                                                                  \
+        const int tap_ = ((blk_) >= kb) + ((blk_) >= 2 * kb), k0_ = ((blk_) - tap_ * kb) * 64;         \
+        const int tt_ = t_row + tap_ - 1;                                                              \
+        const bool ok_ = row_ok && tt_ >= 0 && tt_ < T;                                                \
+        const float* arow_ = in + (ok_ ? row + tap_ - 1 : 0) * ld_in + k0_ + 4 * fq;                   \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                \
+            dst_[g] = *reinterpret_cast<const f32x4*>(arow_ + 16 * g);                                 \
+            if (!ok_) dst_[g] = f32x4{0.f, 0.f, 0.f, 0.f};                                             \
+        }                                                                                              \
+    }
+#define TAIL_COMPUTE(a_, b_)                                                                           \
+    {                                                                                                  \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                \
+            _Pragma("unroll") for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_[g].x, b_[i][g].x, acc[i], 0, 0, 0); \
+            _Pragma("unroll") for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_[g].y, b_[i][g].y, acc[i], 0, 0, 0); \
+            _Pragma("unroll") for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_[g].z, b_[i][g].z, acc[i], 0, 0, 0); \
+            _Pragma("unroll") for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_[g].w, b_[i][g].w, acc[i], 0, 0, 0); \
+        }                                                                                              \
+    }
+    // two register sets for both operands, loads issued one block (16*NT MFMAs) ahead of their use
+    f32x4 b0[NT][4], b1[NT][4], a0[4], a1[4];
+    TAIL_LOAD_B(0, b0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) b0[0][g] = bpre[g];           // tile 0 / block 0 was prefetched by the previous layer
+    TAIL_LOAD_A(0, a0);
+    // Branch-free pair loop (a conditional prefetch makes hipcc fall back to vmcnt(0) at the join) with
+    // sched_barriers (otherwise both prefetches are hoisted to the loop top and waited for together).
+    const int npairs = nblk / 2;
+    for (int p = 0; p < npairs; ++p) {
+        const int blk = 2 * p;
+        TAIL_LOAD_B(blk + 1, b1);
+        TAIL_LOAD_A(blk + 1, a1);
+        __builtin_amdgcn_sched_barrier(0);
+        TAIL_COMPUTE(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        const int nxt = min(blk + 2, nblk - 1);            // last pair: harmless re-load of the final block
+        TAIL_LOAD_B(nxt, b0);
+        TAIL_LOAD_A(nxt, a0);
+        __builtin_amdgcn_sched_barrier(0);
+        TAIL_COMPUTE(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (nblk & 1) TAIL_COMPUTE(a0, b0);
+    if (has_next) tail_prefetch_first(next, bpre);
 #undef TAIL_LOAD_A
 #undef TAIL_LOAD_B
 #undef TAIL_COMPUTE
-        epi(acc, rt * 16 + 4 * fq, n0 + fr, bv);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) epi(acc[i], rt * 16 + 4 * fq, n0 + 64 * i + fr, bv[i]);
+}
+
+template <typename Epi>
+__device__ __forceinline__ void tail_gemm(const float* in, int ld_in, const TailLayerDev L, const TailLayerDev next, bool has_next,
+                                          int T, int R, f32x4 (&bpre)[4], Epi epi) {
+    // N is a multiple of 64: N/64 tiles per wave (the fused chain has N <= 256)
+    switch (L.N / 64) {
+        case 1: tail_gemm_nt<1>(in, ld_in, L, next, has_next, T, R, bpre, epi); break;
+        case 2: tail_gemm_nt<2>(in, ld_in, L, next, has_next, T, R, bpre, epi); break;
+        case 3: tail_gemm_nt<3>(in, ld_in, L, next, has_next, T, R, bpre, epi); break;
+        default: tail_gemm_nt<4>(in, ld_in, L, next, has_next, T, R, bpre, epi); break;
     }
 }
 
@@ -219,6 +234,8 @@ __global__ __launch_bounds__(TAIL_THREADS, 2) void decoder_tail_kernel(TailArgs 
 size_t plan_tail(const std::vector<Layer>& dec, int start, int T, int J, TailArgs* out) {
     const int n = (int)dec.size() - start;
     if (start < 1 || n < 1 || n > TAIL_MAX_LAYERS || T > 32) return 0;
+    for (int i = start; i < (int)dec.size(); ++i)
+        if (dec[i].K > 256 || dec[i].N > 256) return 0;       // tail_gemm handles up to 4 x 64 columns per wave
     TailArgs a{};
     a.n = n;
     a.G = 32 / T;
