@@ -387,7 +387,12 @@ static EnergyArgs energy_args(gem_handle* h, const float* X0, const float* heat,
 static int evaluate(gem_handle* h, int stage, int B, const float* zp, const EnergyArgs& ea, hipStream_t s) {
     StageNet& net = h->net[stage];
     Workspace& w = h->ws;
-    if (net.tail_start < 1) {
+    // The fused tail trades throughput for latency (one workgroup per CU, ~85 us per workgroup): it wins while
+    // all its workgroups (one per 3 windows) are resident at once; beyond that the batched GEMMs are faster
+    // (8196 windows, bf16: 73 k vs 59 k windows/s).  GEM_FORCE_TAIL=1 keeps it on for any batch.
+    static const bool force_tail = getenv("GEM_FORCE_TAIL") != nullptr;
+    const int tail_wgs = (B + (32 / h->T) - 1) / (32 / h->T);
+    if (net.tail_start < 1 || (tail_wgs > 256 && !force_tail)) {
         if (decoder_forward(h, stage, B, zp, s)) return 1;
         if (launch_energy(h, ea, B, s)) return 1;
         return decoder_backward(h, stage, B, s, (int)net.dec.size() - 1, w.dXp);
