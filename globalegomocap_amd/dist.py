@@ -35,11 +35,14 @@ def all_gather_windows(local, n_windows, group=None):
     lo, hi = sizes[rank]
     if local.shape[0] != hi - lo:
         raise ValueError("rank %d holds %d windows, its shard is %d" % (rank, local.shape[0], hi - lo))
-    buf = torch.zeros((cap,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    # gloo (CPU tests, single-GPU rehearsals) gathers host copies; nccl = RCCL gathers device buffers over xGMI
+    dev = local.device
+    stage = torch.device("cpu") if dist.get_backend(group) == "gloo" else dev
+    buf = torch.zeros((cap,) + tuple(local.shape[1:]), dtype=local.dtype, device=stage)
     buf[: hi - lo] = local
     out = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(out, buf, group=group)
-    return torch.cat([o[: h - l] for o, (l, h) in zip(out, sizes)], dim=0)
+    return torch.cat([o[: h - l] for o, (l, h) in zip(out, sizes)], dim=0).to(dev)
 
 
 def optimize_sharded(run_shard, starts, seq_len=10, group=None):

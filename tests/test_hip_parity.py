@@ -367,3 +367,46 @@ def test_precision_modes_window_pipeline_mpjpe(torch_cuda, golden, tmp_path, mod
                        final_smooth=True, eps=eps, optimizer=opt)[0]
     ref = float(g["err_smooth/optimized_global_mpjpe"])
     assert abs(errors["optimized_global_mpjpe"] - ref) * 1e3 < tol_mm, (mode, errors["optimized_global_mpjpe"], ref)
+
+
+@pytest.mark.parametrize("shape,seed,B", [(TINY, 11, 4), (FULL, 5, 3)])
+def test_unfused_layer_path(torch_cuda, monkeypatch, shape, seed, B):
+    """Large batches run the narrow layers as batched GEMMs + the stand-alone energy kernel instead of the fused
+    tail kernel; force that path (GEM_NO_TAIL) and compare it with the oracle and with the fused path."""
+    sd = vae_schema.synthetic_state_dict(shape, seed)
+    vae = O.fold_vae(sd)
+    cam = oracle_camera()
+    seq = synth.make_sequence(n_frames=8 * (B - 1) + 10, seed=41)
+    est = np.asarray(seq["estimated_local_skeleton"], dtype=np.float32)
+    heat = np.asarray(seq["heatmap_list"], dtype=np.float32)
+    starts = (8 * np.arange(B)).astype(np.int32)
+    pose = np.stack([est[s:s + 10] for s in starts])
+    rng = np.random.default_rng(6)
+    mu, _ = O.encode(vae, pose.reshape(B, 10, 45))
+    z = (mu + 0.1 * rng.normal(size=mu.shape)).astype(np.float32)
+    mb = O.mean_bone_length(est)
+    eps = rng.normal(size=(B, shape.latent_dim)).astype(np.float32)
+    w = (1e-1, 1e-1, 1.0, 1e-3, 1e-2)
+    results = {}
+    for tag, no_tail in (("fused", False), ("batched", True)):
+        if no_tail:
+            monkeypatch.setenv("GEM_NO_TAIL", "1")
+        else:
+            monkeypatch.delenv("GEM_NO_TAIL", raising=False)
+        eng = _engine(shape, max_windows=8)
+        eng.load_vae(0, sd)                      # the path is chosen when the weights are loaded
+        E, parts, dz, X = eng.energy_grad(0, z, pose, mb, _ew(W_ALL), heat, starts)
+        out, stats = eng.optimize_stage(0, pose, mb, eps, _ew(w), heat, starts)
+        results[tag] = (E.cpu().numpy(), dz.cpu().numpy(), X.cpu().numpy(), out.cpu().numpy(), stats.cpu().numpy())
+    E, dz, X, out, st = results["batched"]
+    for b in range(B):
+        Xo, acts = O.decode(vae, z[b:b + 1], keep=True)
+        f, p, dX = O.energy_and_grad(Xo[0], pose[b], mb, O.Weights(*W_ALL), cam, heat[starts[b]:starts[b] + 10])
+        dzo = O.decode_backward(vae, dX[None], acts)[0]
+        np.testing.assert_allclose(X[b], Xo[0], rtol=2e-4, atol=2e-5)
+        assert abs(E[b] - f) <= 2e-4 * abs(f) + 1e-7
+        assert np.abs(dz[b] - dzo).max() <= 2e-3 * np.abs(dzo).max() + 1e-8
+    assert (st[:, 3] == 1).all()
+    # both paths do the same arithmetic up to summation order
+    np.testing.assert_allclose(results["fused"][0], E, rtol=1e-5)
+    assert np.abs(results["fused"][1] - dz).max() <= 1e-4 * np.abs(dz).max()
