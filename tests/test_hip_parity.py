@@ -410,3 +410,69 @@ def test_unfused_layer_path(torch_cuda, monkeypatch, shape, seed, B):
     # both paths do the same arithmetic up to summation order
     np.testing.assert_allclose(results["fused"][0], E, rtol=1e-5)
     assert np.abs(results["fused"][1] - dz).max() <= 1e-4 * np.abs(dz).max()
+
+
+def test_projections_outside_the_heatmap_and_error_paths(torch_cuda):
+    """Joints that project outside the 64x64 heat-map sample zeros (grid_sample padding); bad calls raise."""
+    from globalegomocap_amd import _capi
+    sd = vae_schema.synthetic_state_dict(TINY, 11)
+    eng = _engine(TINY, max_windows=4)
+    eng.load_vae(0, sd)
+    vae = O.fold_vae(sd)
+    cam = oracle_camera()
+    rng = np.random.default_rng(8)
+    # final conv bias shifted sideways: the decoded skeleton leaves the image on the right / bottom for part of the joints
+    sd2 = dict(sd)
+    b = np.array(sd["final_layer.3.bias"], dtype=np.float32).reshape(15, 3).copy()
+    # the fisheye maps the whole front half-space inside the image circle; joints BEHIND the camera plane
+    # (z < 0, theta > 0) land beyond it, i.e. outside the 64x64 map on every side
+    b[:, 0] = np.linspace(-1.5, 1.5, 15)
+    b[:, 1] = np.where(np.arange(15) % 2 == 0, 1.2, -1.2)
+    b[:, 2] = np.linspace(-0.8, 0.6, 15)
+    sd2["final_layer.3.bias"] = b.reshape(-1)
+    eng.load_vae(0, sd2)
+    vae2 = O.fold_vae(sd2)
+    z = rng.normal(size=(2, 32)).astype(np.float32)
+    seq = synth.make_sequence(n_frames=18, seed=2)
+    est = np.asarray(seq["estimated_local_skeleton"], dtype=np.float32)
+    heat = rng.uniform(0, 1, size=(18, 64, 64, 15)).astype(np.float32)      # dense heat-maps: borders matter
+    starts = np.array([0, 8], np.int32)
+    pose = np.stack([est[s:s + 10] for s in starts])
+    mb = O.mean_bone_length(est)
+    E, parts, dz, X = eng.energy_grad(0, z, pose, mb, _ew(W_ALL), heat, starts)
+    n_out = 0
+    for k in range(2):
+        Xo, acts = O.decode(vae2, z[k:k + 1], keep=True)
+        uv = O.fisheye_project(cam, Xo[0].reshape(-1, 3))
+        ix, iy = O.heat_coords(uv, 64, 64)
+        n_out += int(((ix < 0) | (ix > 63) | (iy < 0) | (iy > 63)).sum())
+        f, p, dX = O.energy_and_grad(Xo[0], pose[k], mb, O.Weights(*W_ALL), cam, heat[starts[k]:starts[k] + 10])
+        np.testing.assert_allclose(parts[k].cpu().numpy(), p, rtol=5e-4, atol=1e-5)
+        dzo = O.decode_backward(vae2, dX[None], acts)[0]
+        assert np.abs(dz[k].cpu().numpy() - dzo).max() <= 5e-3 * np.abs(dzo).max() + 1e-8
+    assert n_out > 10                      # the case really exercises out-of-map samples
+    # error behaviour: clear messages, no aborts
+    with pytest.raises(ValueError):
+        eng.decode(0, np.zeros((5, 32), np.float32))                        # more windows than max_windows
+    with pytest.raises(_capi.GemError, match="not loaded"):
+        eng.decode(1, np.zeros((1, 32), np.float32))                        # stage without weights
+    with pytest.raises(_capi.GemError, match="heat-maps"):
+        eng.optimize_stage(0, pose, mb, np.zeros((2, 32), np.float32), _ew(W_ALL))   # reproj weight without heat-maps
+    with pytest.raises(RuntimeError):
+        eng.load_vae(0, {k: v for k, v in sd.items() if k != "fc_mu.bias"})
+
+
+def test_joint_on_the_optical_axis_raises_like_the_reference(torch_cuda):
+    """FishEyeCalibrated.py:124-127 raises Exception('norm is zero!'); the mirror turns the NaN energy into it."""
+    import torch
+    from globalegomocap_amd.optimizer import BodyPoseOptimizer
+    sd = dict(vae_schema.synthetic_state_dict(TINY, 11))
+    for k in list(sd):                       # a decoder that outputs exactly its final bias: every joint at (0, 0, 1)
+        if k.startswith(("decoder", "final_layer")) and k.endswith(".weight") and np.asarray(sd[k]).ndim == 3:
+            sd[k] = np.zeros_like(sd[k])
+    sd["final_layer.3.bias"] = np.tile(np.array([0.0, 0.0, 1.0], np.float32), 15)
+    pose = synth.rest_skeleton()[None].repeat(10, 0).astype(np.float32)
+    bpo = BodyPoseOptimizer(DEFAULT_CALIBRATION, torch.from_numpy(pose), sd, seq_len=10, network_seq_len=10, latent_dim=32)
+    bpo.set_weights(vae_weight=0.0, gmm_weight=0.0, smooth_weight=1e-5, bone_length_weight=1e-2, weight_3d=1e-6, reproj_weight=1e-2)
+    with pytest.raises(Exception, match="norm is zero"):
+        bpo.optimize_pose_seq_pytorch_LBFGS(pose, np.zeros((10, 64, 64, 15), np.float32), pose.copy())
