@@ -476,3 +476,71 @@ def test_joint_on_the_optical_axis_raises_like_the_reference(torch_cuda):
     bpo.set_weights(vae_weight=0.0, gmm_weight=0.0, smooth_weight=1e-5, bone_length_weight=1e-2, weight_3d=1e-6, reproj_weight=1e-2)
     with pytest.raises(Exception, match="norm is zero"):
         bpo.optimize_pose_seq_pytorch_LBFGS(pose, np.zeros((10, 64, 64, 15), np.float32), pose.copy())
+
+
+def test_history_ring_wraps_like_torch(torch_cuda, golden):
+    """history_size smaller than the iteration count: the (s, y) ring drops its oldest pair (lbfgs.py:  old_dirs.pop(0))."""
+    from globalegomocap_amd import _capi
+    g = golden("lbfgs_tiny")
+    sd = sd_from_npz(g, "local/")
+    pose, heat = g["pose"], heat_from_centres(g["heat_centres"])
+    eng = _engine(TINY)
+    eng.load_vae(0, sd)
+    mb = eng.mean_bone_length(pose.astype(np.float32))
+    opts = _capi.default_lbfgs_opts()
+    opts.history = 4
+    out, stats = eng.optimize_stage(0, pose[None], mb, g["local_eps"][None], _ew(W_LOCAL), heat, np.zeros(1, np.int32), opts=opts)
+    vae = O.fold_vae(sd)
+    ref, st = O.optimize_stage(vae, oracle_camera(), O.Weights(*W_LOCAL), pose, heat, O.mean_bone_length(pose.astype(np.float32)),
+                               g["local_eps"], O.LBFGSOptions(history=4))
+    s = stats.cpu().numpy()[0]
+    assert s[3] == 1 and abs(int(s[1]) - st["func_evals"]) <= 3
+    assert np.linalg.norm(out[0].cpu().numpy() - ref, axis=-1).mean() < 0.5e-3
+    # and it is a different optimisation from the full-history one
+    out_full, _ = eng.optimize_stage(0, pose[None], mb, g["local_eps"][None], _ew(W_LOCAL), heat, np.zeros(1, np.int32))
+    assert not np.array_equal(out_full.cpu().numpy(), out.cpu().numpy())
+
+
+def test_other_window_length_and_camera(torch_cuda):
+    """seq_len = 8 (4 windows per tail workgroup) with the 14-coefficient calibration file."""
+    from globalegomocap_amd.camera import ALT_CALIBRATION
+    from globalegomocap_amd.engine import WindowEngine
+    shape = vae_schema.VAEShape(latent_dim=48, seq_len=8, hidden=(16, 32, 32, 64, 64))
+    sd = vae_schema.synthetic_state_dict(shape, 17)
+    cam_h = FisheyeCamera.from_json(ALT_CALIBRATION)
+    eng = WindowEngine(shape, cam_h, max_windows=8)
+    eng.load_vae(0, sd)
+    vae = O.fold_vae(sd, seq_len=8)
+    cam = oracle_camera(ALT_CALIBRATION)
+    B = 5
+    seq = synth.make_sequence(n_frames=6 * (B - 1) + 8, seed=19, camera=cam_h)
+    est = np.asarray(seq["estimated_local_skeleton"], dtype=np.float32)
+    heat = np.asarray(seq["heatmap_list"], dtype=np.float32)
+    starts = (6 * np.arange(B)).astype(np.int32)
+    pose = np.stack([est[s:s + 8] for s in starts])
+    rng = np.random.default_rng(2)
+    mu, lv = O.encode(vae, pose.reshape(B, 8, 45))
+    mu_d, lv_d, _ = eng.encode(0, pose.reshape(B, 8, 45))
+    np.testing.assert_allclose(mu_d.cpu().numpy(), mu, rtol=2e-4, atol=2e-5)
+    z = (mu + 0.1 * rng.normal(size=mu.shape)).astype(np.float32)
+    mb = O.mean_bone_length(est)
+    E, parts, dz, X = eng.energy_grad(0, z, pose, mb, _ew(W_ALL), heat, starts)
+    for b in range(B):
+        Xo, acts = O.decode(vae, z[b:b + 1], keep=True)
+        f, p, dX = O.energy_and_grad(Xo[0], pose[b], mb, O.Weights(*W_ALL), cam, heat[starts[b]:starts[b] + 8])
+        dzo = O.decode_backward(vae, dX[None], acts)[0]
+        np.testing.assert_allclose(X[b].cpu().numpy(), Xo[0], rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(parts[b].cpu().numpy(), p, rtol=2e-4, atol=1e-6)
+        assert np.abs(dz[b].cpu().numpy() - dzo).max() <= 2e-3 * np.abs(dzo).max() + 1e-8
+    eps = rng.normal(size=(B, 48)).astype(np.float32)
+    w = (1e-1, 1e-1, 1.0, 1e-3, 1e-2)
+    out, stats = eng.optimize_stage(0, pose, mb, eps, _ew(w), heat, starts)
+    st = stats.cpu().numpy()
+    assert (st[:, 3] == 1).all()
+    # random-init weights + strong energy weights: a long chaotic run, so compare what it achieves, not where it ends
+    from globalegomocap_amd.engine import stats_to_numpy
+    sn = stats_to_numpy(stats)
+    for b in (0, B - 1):
+        ref, so = O.optimize_stage(vae, cam, O.Weights(*w), pose[b], heat[starts[b]:starts[b] + 8], mb, eps[b])
+        assert abs(sn["final_loss"][b] - so["loss"]) <= 0.05 * abs(so["loss"]), (b, sn["final_loss"][b], so["loss"])
+        assert abs(int(sn["func_evals"][b]) - so["func_evals"]) <= 6
