@@ -6,11 +6,7 @@
 
 namespace gem {
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+__device__ __forceinline__ double wave_sum(double v) { return wave_sum_dpp(v); }
 
 constexpr int MAXT = 16;               // frames per window supported by the LDS carve
 constexpr int MAXJ = GEM_MAX_JOINTS;

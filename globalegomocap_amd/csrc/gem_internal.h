@@ -101,6 +101,37 @@ struct Profile {
     double flops[3] = {0, 0, 0};
 };
 
+// Wavefront reductions on the DPP cross-lane path (no LDS traffic): quad swaps, half-row and row mirrors
+// leave every lane of a 16-lane row with the row total; the four row totals are read back with
+// v_readlane and combined in a fixed order.  Doubles travel as two 32-bit halves.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double read_lane(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
+                            __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ __forceinline__ double nan_max(double a, double b) { return (b > a || b != b) ? b : a; }   // NaN wins, like torch's max
+
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+    v += dpp_move<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_move<0x141>(v);     // row_half_mirror
+    v += dpp_move<0x140>(v);     // row_mirror
+    return ((read_lane(v, 0) + read_lane(v, 16)) + read_lane(v, 32)) + read_lane(v, 48);
+}
+__device__ __forceinline__ double wave_max_dpp(double v) {
+    v = nan_max(v, dpp_move<0xB1>(v));
+    v = nan_max(v, dpp_move<0x4E>(v));
+    v = nan_max(v, dpp_move<0x141>(v));
+    v = nan_max(v, dpp_move<0x140>(v));
+    return nan_max(nan_max(nan_max(read_lane(v, 0), read_lane(v, 16)), read_lane(v, 32)), read_lane(v, 48));
+}
+
 }  // namespace gem
 
 struct gem_handle {
@@ -200,5 +231,6 @@ int launch_lbfgs_init(gem_handle* h, int B, const gem_lbfgs_opts& o, hipStream_t
 int launch_lbfgs_advance(gem_handle* h, int B, const gem_lbfgs_opts& o, hipStream_t s);
 int launch_lbfgs_stats(gem_handle* h, int B, gem_window_stats* out, hipStream_t s);
 int launch_compact(gem_handle* h, int B, int force_all, hipStream_t s);
+
 
 }  // namespace gem

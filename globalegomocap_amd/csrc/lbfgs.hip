@@ -21,6 +21,8 @@
 
 namespace gem {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 enum { PH_INIT = 0, PH_BRACKET = 1, PH_ZOOM = 2, PH_DONE = 3 };
 
 struct AdvArgs {
@@ -58,12 +60,13 @@ __device__ __forceinline__ double cubic_interpolate(double x1, double f1, double
 
 // Block-wide reductions with ONE barrier each: partials go to alternating 4-entry LDS slots, so the next
 // reduction cannot overwrite values a slow wave has not read yet (a slot is reused two barriers later).
+template <int NT>
 struct BlockRed {
     double* red;      // [2][4]
     int parity;
     __device__ __forceinline__ double sum(double v) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        v = wave_sum_dpp(v);
+        if (NT == 64) return v;
         double* r = red + 4 * parity;
         parity ^= 1;
         if ((threadIdx.x & 63) == 0) r[threadIdx.x >> 6] = v;
@@ -71,23 +74,18 @@ struct BlockRed {
         return r[0] + r[1] + r[2] + r[3];
     }
     __device__ __forceinline__ double max(double v) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const double w = __shfl_xor(v, o, 64);
-            v = (w > v || w != w) ? w : v;       // NaN wins, like torch's max
-        }
+        v = wave_max_dpp(v);
+        if (NT == 64) return v;
         double* r = red + 4 * parity;
         parity ^= 1;
         if ((threadIdx.x & 63) == 0) r[threadIdx.x >> 6] = v;
         __syncthreads();
-        double m = r[0];
-        for (int i = 1; i < 4; ++i) m = (r[i] > m || r[i] != r[i]) ? r[i] : m;
-        return m;
+        return nan_max(nan_max(nan_max(r[0], r[1]), r[2]), r[3]);
     }
 };
 
-template <int EPT>
-__global__ __launch_bounds__(256) void lbfgs_advance_kernel(AdvArgs a) {
+template <int EPT, int NT>
+__device__ __forceinline__ void lbfgs_advance_body(const AdvArgs& a) {
     __shared__ double red[8];
     __shared__ double ro_s[MAX_HIST];
     __shared__ double al_s[MAX_HIST];
@@ -95,7 +93,7 @@ __global__ __launch_bounds__(256) void lbfgs_advance_kernel(AdvArgs a) {
     LbfgsState* sp = a.state + b;
     int phase = sp->phase;
     if (phase == PH_DONE) return;
-    BlockRed R{red, 0};
+    BlockRed<NT> R{red, 0};
     const gem_lbfgs_opts& o = a.o;
     const int Dp = a.Dp;
     const size_t off = (size_t)b * Dp;
@@ -107,7 +105,7 @@ __global__ __launch_bounds__(256) void lbfgs_advance_kernel(AdvArgs a) {
     double t_prev = sp->t_prev, f_prev = sp->f_prev, gtd_prev = sp->gtd_prev;
     double br_t[2] = {sp->br_t[0], sp->br_t[1]}, br_f[2] = {sp->br_f[0], sp->br_f[1]};
     double br_gtd[2] = {sp->br_gtd[0], sp->br_gtd[1]};
-    for (int i = tid; i < a.hist_cap; i += 256) ro_s[i] = sp->ro[i];
+    for (int i = tid; i < a.hist_cap; i += NT) ro_s[i] = sp->ro[i];
     __syncthreads();
 
     const double f_new = a.f[b];
@@ -115,22 +113,39 @@ __global__ __launch_bounds__(256) void lbfgs_advance_kernel(AdvArgs a) {
     float gn[EPT], xv[EPT], dv[EPT], gcur[EPT], yv[EPT], sv[EPT];
     bool have_x = false, have_d = false;
 #pragma unroll
-    for (int i = 0; i < EPT; ++i) {
-        const int e = tid + 256 * i;
-        gn[i] = e < Dp ? gsrc[e] : 0.f;
-        xv[i] = dv[i] = gcur[i] = yv[i] = sv[i] = 0.f;
-    }
+    for (int i = 0; i < EPT; ++i) xv[i] = dv[i] = gcur[i] = yv[i] = sv[i] = 0.f;
+    // element i of a thread's strip: 16-byte groups when the strip allows it (Dp is a multiple of 64)
     auto load = [&](const float* p, float (&v)[EPT]) {
+        if constexpr (EPT % 4 == 0) {
 #pragma unroll
-        for (int i = 0; i < EPT; ++i) { const int e = tid + 256 * i; v[i] = e < Dp ? p[off + e] : 0.f; }
+            for (int i = 0; i < EPT / 4; ++i) {
+                const int e = (tid + NT * i) * 4;
+                f32x4 w = {0.f, 0.f, 0.f, 0.f};
+                if (e < Dp) w = *reinterpret_cast<const f32x4*>(p + off + e);
+                v[4 * i] = w[0]; v[4 * i + 1] = w[1]; v[4 * i + 2] = w[2]; v[4 * i + 3] = w[3];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) { const int e = tid + NT * i; v[i] = e < Dp ? p[off + e] : 0.f; }
+        }
     };
     auto store = [&](float* p, const float (&v)[EPT]) {
+        if constexpr (EPT % 4 == 0) {
 #pragma unroll
-        for (int i = 0; i < EPT; ++i) { const int e = tid + 256 * i; if (e < Dp) p[off + e] = v[i]; }
+            for (int i = 0; i < EPT / 4; ++i) {
+                const int e = (tid + NT * i) * 4;
+                const f32x4 w = {v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
+                if (e < Dp) *reinterpret_cast<f32x4*>(p + off + e) = w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) { const int e = tid + NT * i; if (e < Dp) p[off + e] = v[i]; }
+        }
     };
     auto copy = [&](float* dst, const float* src) {
-#pragma unroll
-        for (int i = 0; i < EPT; ++i) { const int e = tid + 256 * i; if (e < Dp) dst[off + e] = src[off + e]; }
+        float tmp[EPT];
+        load(src, tmp);
+        store(dst, tmp);
     };
     auto dot = [&](const float (&u)[EPT], const float (&v)[EPT]) {
         float p = 0.f;
@@ -144,6 +159,7 @@ __global__ __launch_bounds__(256) void lbfgs_advance_kernel(AdvArgs a) {
         for (int i = 0; i < EPT; ++i) { const float w = fabsf(u[i] * scale); p = (w > p || w != w) ? w : p; }
         return R.max((double)p);
     };
+    load(gsrc - off, gn);
     float* BG[2] = {a.bg0, a.bg1};
 
     bool do_zoom_head = false, do_ls_end = false, do_start_iter = false, finished = false, emit = false;
@@ -315,38 +331,57 @@ __global__ __launch_bounds__(256) void lbfgs_advance_kernel(AdvArgs a) {
             float q[EPT];
 #pragma unroll
             for (int i = 0; i < EPT; ++i) q[i] = -gcur[i];
-            // two-loop recursion; the (s, y) pair of the next step is in flight during each reduction
+            // two-loop recursion
             auto pair_ptr = [&](const float* base, int k) {
                 const int slot = (hist_start + k) % a.hist_cap;
                 return base + ((size_t)b * a.hist_cap + slot) * Dp - off;
             };
-            float sk[EPT], yk[EPT], sn[EPT], yn[EPT];
-            if (hist_count > 0) { load(pair_ptr(a.S, hist_count - 1), sk); load(pair_ptr(a.Y, hist_count - 1), yk); }
-            for (int k = hist_count - 1; k >= 0; --k) {
+            // Three (s, y) pairs are kept in flight: pair k lives in ring buffer k % 3, and a buffer is refilled
+            // with pair k-3 (first loop) / k+3 (second loop) right after its step, so every reduction overlaps
+            // two outstanding fetches.  The last three steps of the first loop reload their own pair, which
+            // leaves pairs 0,1,2 where the second loop wants them.
+            float s0[EPT], y0[EPT], s1[EPT], y1[EPT], s2[EPT], y2[EPT];
+            const int hc = hist_count;
+            auto ld_pair = [&](int k, float (&sb)[EPT], float (&yb)[EPT]) {
+                load(pair_ptr(a.S, k), sb);
+                load(pair_ptr(a.Y, k), yb);
+            };
+            auto first_k = [&](int j) { const int k = hc - 1 - ((hc - 1 - j + 3) % 3); return k < 0 ? 0 : k; };
+            auto step1 = [&](int k, float (&sb)[EPT], float (&yb)[EPT]) {
                 const int slot = (hist_start + k) % a.hist_cap;
-                const int kn = k > 0 ? k - 1 : 0;
-                load(pair_ptr(a.S, kn), sn);
-                load(pair_ptr(a.Y, kn), yn);
-                const double al = dot(sk, q) * ro_s[slot];
+                const double al = dot(sb, q) * ro_s[slot];
                 if (tid == 0) al_s[k] = al;
                 const float alf = (float)al;
 #pragma unroll
-                for (int i = 0; i < EPT; ++i) { q[i] -= alf * yk[i]; sk[i] = sn[i]; yk[i] = yn[i]; }
+                for (int i = 0; i < EPT; ++i) q[i] -= alf * yb[i];
+                ld_pair(k >= 3 ? k - 3 : k, sb, yb);
+            };
+            auto step2 = [&](int k, float (&sb)[EPT], float (&yb)[EPT]) {
+                const int slot = (hist_start + k) % a.hist_cap;
+                const double be = dot(yb, q) * ro_s[slot];
+                const float cf = (float)(al_s[k] - be);
+#pragma unroll
+                for (int i = 0; i < EPT; ++i) q[i] += cf * sb[i];
+                ld_pair(k + 3 < hc ? k + 3 : hc - 1, sb, yb);
+            };
+            if (hc > 0) {
+                ld_pair(first_k(2), s2, y2);
+                ld_pair(first_k(1), s1, y1);
+                ld_pair(first_k(0), s0, y0);
+            }
+            for (int kk = (hc + 2) / 3 * 3 - 1; kk >= 0; kk -= 3) {
+                if (kk < hc) step1(kk, s2, y2);
+                if (kk - 1 < hc) step1(kk - 1, s1, y1);
+                if (kk - 2 < hc) step1(kk - 2, s0, y0);
             }
             __syncthreads();
             const float hd = (float)H_diag;
 #pragma unroll
             for (int i = 0; i < EPT; ++i) q[i] *= hd;
-            // after the first loop sk/yk hold pair 0 again (kn = 0 on its last step)
-            for (int k = 0; k < hist_count; ++k) {
-                const int slot = (hist_start + k) % a.hist_cap;
-                const int kn = k + 1 < hist_count ? k + 1 : k;
-                load(pair_ptr(a.S, kn), sn);
-                load(pair_ptr(a.Y, kn), yn);
-                const double be = dot(yk, q) * ro_s[slot];
-                const float cf = (float)(al_s[k] - be);
-#pragma unroll
-                for (int i = 0; i < EPT; ++i) { q[i] += cf * sk[i]; sk[i] = sn[i]; yk[i] = yn[i]; }
+            for (int kk = 0; kk < hc; kk += 3) {
+                step2(kk, s0, y0);
+                if (kk + 1 < hc) step2(kk + 1, s1, y1);
+                if (kk + 2 < hc) step2(kk + 2, s2, y2);
             }
 #pragma unroll
             for (int i = 0; i < EPT; ++i) dv[i] = q[i];
@@ -404,6 +439,9 @@ __global__ __launch_bounds__(256) void lbfgs_advance_kernel(AdvArgs a) {
         sp->br_gtd[0] = br_gtd[0]; sp->br_gtd[1] = br_gtd[1];
     }
 }
+
+template <int EPT>
+__global__ __launch_bounds__(256) void lbfgs_advance_kernel(AdvArgs a) { lbfgs_advance_body<EPT, 256>(a); }
 
 __global__ void lbfgs_init_kernel(LbfgsState* st, const float* __restrict__ trial, float* __restrict__ x, int B, int Dp) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -150,7 +150,7 @@ __device__ __forceinline__ void tail_gemm(const float* in, int ld_in, const Tail
 
 __global__ __launch_bounds__(TAIL_THREADS, 2) void decoder_tail_kernel(TailArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 31, fh = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int T = a.e.T;
     const int w0 = blockIdx.x * a.G;                         // first slot of this workgroup
     const int B = a.e.n_dev ? *a.e.n_dev : a.B;              // active slots this round
