@@ -150,6 +150,7 @@ int gem_create(const gem_config* cfg, gem_handle** out) {
     h->T = cfg->seq_len; h->J = cfg->n_joints; h->C = cfg->n_joints * 3; h->Cp = pad64(h->C);
     h->D = cfg->latent_dim; h->Dp = pad64(cfg->latent_dim);
     h->top = cfg->hidden[cfg->n_hidden - 1]; h->topp = pad64(h->top);
+    GEM_HIP(hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, cfg->device));
     Workspace& w = h->ws;
     const int B = cfg->max_windows, T = h->T;
     const size_t rows = (size_t)B * T;
@@ -387,12 +388,14 @@ static EnergyArgs energy_args(gem_handle* h, const float* X0, const float* heat,
 static int evaluate(gem_handle* h, int stage, int B, const float* zp, const EnergyArgs& ea, hipStream_t s) {
     StageNet& net = h->net[stage];
     Workspace& w = h->ws;
-    // The fused tail trades throughput for latency (one workgroup per CU, ~85 us per workgroup): it wins while
-    // all its workgroups (one per 3 windows) are resident at once; beyond that the batched GEMMs are faster
+    // The fused tail trades throughput for latency (~60-80 us per workgroup whatever the batch): it wins while
+    // all its workgroups (one per 16/T windows) are resident at once; beyond that the batched GEMMs are faster
     // (8196 windows, bf16: 73 k vs 59 k windows/s).  GEM_FORCE_TAIL=1 keeps it on for any batch.
     static const bool force_tail = getenv("GEM_FORCE_TAIL") != nullptr;
-    const int tail_wgs = (B + (32 / h->T) - 1) / (32 / h->T);
-    if (net.tail_start < 1 || (tail_wgs > 256 && !force_tail)) {
+    const int tail_g = h->T <= 16 ? 16 / h->T : 1;
+    const int tail_wgs = (B + tail_g - 1) / tail_g;
+    const int tail_cap = h->n_cu;          // one workgroup per CU (the kernel's VGPR budget admits no second one)
+    if (net.tail_start < 1 || (tail_wgs > tail_cap && !force_tail)) {
         if (decoder_forward(h, stage, B, zp, s)) return 1;
         if (launch_energy(h, ea, B, s)) return 1;
         return decoder_backward(h, stage, B, s, (int)net.dec.size() - 1, w.dXp);

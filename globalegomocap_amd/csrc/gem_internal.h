@@ -141,6 +141,7 @@ struct gem_handle {
     gem::Workspace ws;
     gem::Profile prof;
     int precision = 0;             // GEM_PRECISION_*
+    int n_cu = 256;                // compute units of the device (hipDeviceAttributeMultiprocessorCount)
     int* d_parents = nullptr;
     int* d_children = nullptr;     // [J][J] child lists, -1 terminated
 };

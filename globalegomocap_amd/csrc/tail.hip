@@ -4,7 +4,8 @@
 // After the first (wide) decoder layers the network is narrow (128 -> 64 -> 64 -> 64 -> 45 channels):
 // as separate launches these layers, the energy kernel and their adjoints are ~15 dependent kernels of
 // a few microseconds each per evaluation, dominated by launch boundaries and split-K reduce passes.
-// Here one workgroup (8 waves) owns G = floor(32/T) windows = G*T <= 32 rows (two 16-row MFMA tiles):
+// Here one workgroup (8 waves) owns G = floor(16/T) windows = G*T <= 16 rows (ONE 16-row MFMA tile; T = 10: one
+// window per workgroup, so a 240-window round spreads over 240 CUs instead of piling 3 windows on each of 80):
 //
 //   a_in rows -> LDS;  for each fused layer:  act[i+1] = lrelu(conv3(act[i]) + b)   (v_mfma_f32_16x16x4_f32)
 //   X = act[n] -> energy terms + dE/dX per window (one wave per window, energy_device.h)
@@ -15,7 +16,8 @@
 // window, zero outside).  B operands (weights) are read straight from L2 into registers: fp32 MFMA is
 // slow enough (64 cycles per instruction) that one coalesced 16-byte load per 4 MFMAs is free; the tail
 // weights are stored [tap][K/4][N][4] so that the 32 lanes of a half-wave read 512 contiguous bytes.
-// Output tiles are 16x16 (v_mfma_f32_16x16x4_f32): a 64-wide layer is 8 tiles = one per wave, full K each.
+// Output tiles are 16x16 (v_mfma_f32_16x16x4_f32), wave w owns columns 16w..16w+15 (+128 per extra tile) with the
+// full K walk: a 128-wide layer is one tile per wave, a 64-wide layer keeps waves 0-3 busy.
 //
 // Reference semantics: ConvTranspose1d/Conv1d k=3 s=1 p=1 + BatchNorm(eval) + LeakyReLU of
 // networks/models/SeqConvVAE.py:67-92 (folded at load time), total_loss of optimizer.py:226-240.
@@ -33,22 +35,20 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int TAIL_WAVES = 8;
 constexpr int TAIL_THREADS = TAIL_WAVES * 64;
 
-// Tiling: 16x16 output tiles (v_mfma_f32_16x16x4_f32), tile t -> (row half t&1, 16-column group t>>1), tile
-// t = wave, wave+8, ...: a 64-wide layer is exactly 8 tiles = one per wave with the FULL K walk, so no partial
-// sums have to be combined through LDS.  K blocks of 64: lane (r = lane&15, q = lane>>4) holds, for each of the
+// Tiling: 16x16 output tiles (v_mfma_f32_16x16x4_f32), tile i of wave w = columns 16w + 128i, FULL K walk per
+// tile, so no partial sums have to be combined through LDS.  K blocks of 64: lane (r = lane&15, q = lane>>4) holds, for each of the
 // four 16-deep groups g, the float4 A[row r][k0+16g+4q .. +3] (LDS) and B[k0+16g+4q .. +3][col r] (L2, layout
 // [tap][K/4][N][4]: 16 lanes read 256 contiguous bytes); MFMA step j of group g uses component j of both, i.e.
 // the k-pairing is a permutation inside the group, which a sum over k does not care about.
-struct TailGeom {
-    int kb, nblk, K4N;
-};
+constexpr int TAIL_ROWS = 16;          // rows of (window, frame) per workgroup = one MFMA tile
 
 // B fragments of the first block of the first tile a wave owns in layer L: issued before the barrier that ends
 // the previous layer, so that their L2 latency overlaps the epilogue / barrier / energy phase.
 __device__ __forceinline__ void tail_prefetch_first(const TailLayerDev L, f32x4 (&dst)[4]) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 15, q = lane >> 4;
-    const int n0 = (wave >> 1) * 16;
+    const int n0 = wave * 16;
+    if (n0 >= L.N) return;                                                                   // this wave idles in layer L
     const f32x4* p = reinterpret_cast<const f32x4*>(L.w4) + (size_t)q * L.N + n0 + c;       // tap 0, k0 = 0
 #pragma unroll
     for (int g = 0; g < 4; ++g) dst[g] = p[(size_t)(4 * g) * L.N];
@@ -56,8 +56,8 @@ __device__ __forceinline__ void tail_prefetch_first(const TailLayerDev L, f32x4 
 
 // bpre: in = fragments from tail_prefetch_first(L); out = the same for `next` (if any), issued before the epilogue.
 // epi(acc, tile_row0, col, bias_value) receives the 4 rows tile_row0 + 4*(lane>>4) + {0..3} of column `col`.
-// NT = tiles per wave (N / 64): the NT tiles of a wave share their 16 rows (tiles wave, wave+8, ... have the same
-// row half), so they walk K together: one A fragment feeds NT independent accumulators.
+// NT = tiles per wave (N / 128, at least 1): the NT tiles of a wave share the 16 rows, so they walk K together:
+// one A fragment feeds NT independent accumulators.
 template <int NT, typename Epi>
 __device__ __forceinline__ void tail_gemm_nt(const float* in, int ld_in, const TailLayerDev L, const TailLayerDev next, bool has_next,
                                              int T, int R, f32x4 (&bpre)[4], Epi epi) {
@@ -66,15 +66,19 @@ __device__ __forceinline__ void tail_gemm_nt(const float* in, int ld_in, const T
     const int kb = L.K / 64, nblk = 3 * kb;                   // (tap, 64-wide k block) pairs
     const int K4N = (L.K / 4) * L.N;                          // float4 per tap
     const f32x4* W4 = reinterpret_cast<const f32x4*>(L.w4);
-    const int rt = wave & 1, n0 = (wave >> 1) * 16;           // tile i of this wave: columns n0 + 64*i
-    const int row = rt * 16 + fr;
+    const int n0 = wave * 16;                                 // tile i of this wave: columns n0 + 128*i
+    if (n0 >= L.N) {                                          // 64-wide layer: waves 4-7 only fetch ahead
+        if (has_next) tail_prefetch_first(next, bpre);
+        return;
+    }
+    const int row = fr;
     const int t_row = row % T;
     const bool row_ok = row < R;
     float bv[NT];
     f32x4 acc[NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-        bv[i] = L.bias ? L.bias[n0 + 64 * i + fr] : 0.f;      // issued now, consumed in the epilogue
+        bv[i] = L.bias ? L.bias[n0 + 128 * i + fr] : 0.f;      // issued now, consumed in the epilogue
         acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #define TAIL_LOAD_B(blk_, dst_)                                                                        \
@@ -82,7 +86,7 @@ __device__ __forceinline__ void tail_gemm_nt(const float* in, int ld_in, const T
         const int tap_ = ((blk_) >= kb) + ((blk_) >= 2 * kb), k0_ = ((blk_) - tap_ * kb) * 64;         \
         const f32x4* p_ = W4 + (size_t)tap_ * K4N + (size_t)(k0_ / 4 + fq) * L.N + n0 + fr;            \
         _Pragma("unroll") for (int i = 0; i < NT; ++i)                                                 \
-            _Pragma("unroll") for (int g = 0; g < 4; ++g) dst_[i][g] = p_[(size_t)(4 * g) * L.N + 64 * i]; \
+            _Pragma("unroll") for (int g = 0; g < 4; ++g) dst_[i][g] = p_[(size_t)(4 * g) * L.N + 128 * i]; \
     }
 #define TAIL_LOAD_A(blk_, dst_)                                                                        \
     {                                                                                                  \
@@ -133,19 +137,15 @@ __device__ __forceinline__ void tail_gemm_nt(const float* in, int ld_in, const T
 #undef TAIL_LOAD_B
 #undef TAIL_COMPUTE
 #pragma unroll
-    for (int i = 0; i < NT; ++i) epi(acc[i], rt * 16 + 4 * fq, n0 + 64 * i + fr, bv[i]);
+    for (int i = 0; i < NT; ++i) epi(acc[i], 4 * fq, n0 + 128 * i + fr, bv[i]);
 }
 
 template <typename Epi>
 __device__ __forceinline__ void tail_gemm(const float* in, int ld_in, const TailLayerDev L, const TailLayerDev next, bool has_next,
                                           int T, int R, f32x4 (&bpre)[4], Epi epi) {
-    // N is a multiple of 64: N/64 tiles per wave (the fused chain has N <= 256)
-    switch (L.N / 64) {
-        case 1: tail_gemm_nt<1>(in, ld_in, L, next, has_next, T, R, bpre, epi); break;
-        case 2: tail_gemm_nt<2>(in, ld_in, L, next, has_next, T, R, bpre, epi); break;
-        case 3: tail_gemm_nt<3>(in, ld_in, L, next, has_next, T, R, bpre, epi); break;
-        default: tail_gemm_nt<4>(in, ld_in, L, next, has_next, T, R, bpre, epi); break;
-    }
+    // N is 64, 128 or 256 (plan_tail): one tile per wave, two for the 256-wide layer
+    if (L.N > 128) tail_gemm_nt<2>(in, ld_in, L, next, has_next, T, R, bpre, epi);
+    else tail_gemm_nt<1>(in, ld_in, L, next, has_next, T, R, bpre, epi);
 }
 
 __global__ __launch_bounds__(TAIL_THREADS, 2) void decoder_tail_kernel(TailArgs a) {
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(TAIL_THREADS, 2) void decoder_tail_kernel(TailArgs 
     {
         const int K0 = a.fwd[0].K, q4 = K0 / 4;
         float* dst = lds + a.off_act[0];
-        for (int i = tid; i < 32 * q4; i += TAIL_THREADS) {
+        for (int i = tid; i < TAIL_ROWS * q4; i += TAIL_THREADS) {
             const int r = i / q4, c = (i - r * q4) * 4;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (r < R) v = *reinterpret_cast<const f32x4*>(a.a_in + (row0 + r) * K0 + c);
@@ -233,23 +233,25 @@ __global__ __launch_bounds__(TAIL_THREADS, 2) void decoder_tail_kernel(TailArgs 
 // byte size, or 0 when the chain is not fusable.
 size_t plan_tail(const std::vector<Layer>& dec, int start, int T, int J, TailArgs* out) {
     const int n = (int)dec.size() - start;
-    if (start < 1 || n < 1 || n > TAIL_MAX_LAYERS || T > 32) return 0;
-    for (int i = start; i < (int)dec.size(); ++i)
-        if (dec[i].K > 256 || dec[i].N > 256) return 0;       // tail_gemm handles up to 4 x 64 columns per wave
+    if (start < 1 || n < 1 || n > TAIL_MAX_LAYERS || T > TAIL_ROWS) return 0;
+    for (int i = start; i < (int)dec.size(); ++i) {
+        const int K = dec[i].K, N = dec[i].N;                 // tail_gemm: 8 waves x 16 columns x {1,2} tiles
+        if ((K != 64 && K != 128 && K != 256) || (N != 64 && N != 128 && N != 256)) return 0;
+    }
     TailArgs a{};
     a.n = n;
-    a.G = 32 / T;
+    a.G = TAIL_ROWS / T;
     int off = 0, maxg = 0;
     for (int i = 0; i <= n; ++i) {
         const int width = i == 0 ? dec[start].K : dec[start + i - 1].N;
         a.off_act[i] = off;
         a.ld_act[i] = width + 4;
-        off += 32 * (width + 4);
+        off += TAIL_ROWS * (width + 4);
         if (i >= 1 && width > maxg) maxg = width;
     }
     a.ld_g = maxg + 4;
-    a.off_g[0] = off; off += 32 * a.ld_g;
-    a.off_g[1] = off; off += 32 * a.ld_g;
+    a.off_g[0] = off; off += TAIL_ROWS * a.ld_g;
+    a.off_g[1] = off; off += TAIL_ROWS * a.ld_g;
     a.escr = (T * J * 3 + 3) / 4 * 4;
     a.off_red = off;                       // (unused since the 16x16 tiling needs no k-split scratch)
     a.off_escr = off;
