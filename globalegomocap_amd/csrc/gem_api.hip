@@ -303,8 +303,11 @@ int gem_load_vae(gem_handle* h, int stage, int n_blobs, const float* const* blob
     if (add_dec(c.hidden[0], C, false, false)) return 1;
     // fuse as many trailing decoder convs as fit the LDS of one CU (tail.hip); GEM_NO_TAIL=1 disables it
     net.tail_start = -1;
+    // The chain may start at conv 0 (GEM_TAIL_START=0), but its 512x256 weights (3 MB per workgroup and round from
+    // L2) cost more than the batched GEMM they replace: 13.4 k vs 14.3 k windows/s at 240 windows.
+    const int first = getenv("GEM_TAIL_START") ? atoi(getenv("GEM_TAIL_START")) : 1;
     if (!getenv("GEM_NO_TAIL"))
-        for (int st = 1; st < (int)net.dec.size(); ++st) {
+        for (int st = first; st < (int)net.dec.size(); ++st) {
             const size_t bytes = plan_tail(net.dec, st, T, h->J, nullptr);
             if (bytes && bytes <= 160 * 1024) { net.tail_start = st; net.tail_lds = bytes; break; }
         }
@@ -395,7 +398,7 @@ static int evaluate(gem_handle* h, int stage, int B, const float* zp, const Ener
     const int tail_g = h->T <= 16 ? 16 / h->T : 1;
     const int tail_wgs = (B + tail_g - 1) / tail_g;
     const int tail_cap = h->n_cu;          // one workgroup per CU (the kernel's VGPR budget admits no second one)
-    if (net.tail_start < 1 || (tail_wgs > tail_cap && !force_tail)) {
+    if (net.tail_start < 0 || (tail_wgs > tail_cap && !force_tail)) {
         if (decoder_forward(h, stage, B, zp, s)) return 1;
         if (launch_energy(h, ea, B, s)) return 1;
         return decoder_backward(h, stage, B, s, (int)net.dec.size() - 1, w.dXp);
@@ -417,7 +420,7 @@ static int evaluate(gem_handle* h, int stage, int B, const float* zp, const Ener
         ta.fwd[i] = TailLayerDev{f.w4, f.bias, f.K, f.N};
         ta.bwd[i] = TailLayerDev{g.w4, nullptr, g.K, g.N};
     }
-    ta.a_in = w.dec_act[st - 1]; ta.g_out = w.dec_grad[st]; ta.Xp = w.dyn ? nullptr : w.dec_act.back();     // the pose is only read back outside the rounds
+    ta.a_in = st > 0 ? w.dec_act[st - 1] : w.h0; ta.g_out = w.dec_grad[st]; ta.Xp = w.dyn ? nullptr : w.dec_act.back();     // the pose is only read back outside the rounds
     ta.e = ea;
     if (launch_tail(h, ta, net.tail_lds, s)) return 1;
     return decoder_backward(h, stage, B, s, st - 1, w.dec_grad[st]);

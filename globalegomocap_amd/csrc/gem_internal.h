@@ -211,7 +211,7 @@ int launch_energy(gem_handle* h, const EnergyArgs& a, int B, hipStream_t s);
 constexpr int TAIL_MAX_LAYERS = 6;
 struct TailLayerDev { const float* w4; const float* bias; int K, N; };
 struct TailArgs {
-    int n, B, G, forward_only, escr;
+    int n, B, G, forward_only, escr, mask_first;
     TailLayerDev fwd[TAIL_MAX_LAYERS], bwd[TAIL_MAX_LAYERS];
     const float* a_in;       // [B*T, K0] input activation of the first fused layer
     float* g_out;            // [B*T, K0] gradient w.r.t. its pre-activation

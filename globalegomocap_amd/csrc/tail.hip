@@ -143,8 +143,9 @@ __device__ __forceinline__ void tail_gemm_nt(const float* in, int ld_in, const T
 template <typename Epi>
 __device__ __forceinline__ void tail_gemm(const float* in, int ld_in, const TailLayerDev L, const TailLayerDev next, bool has_next,
                                           int T, int R, f32x4 (&bpre)[4], Epi epi) {
-    // N is 64, 128 or 256 (plan_tail): one tile per wave, two for the 256-wide layer
-    if (L.N > 128) tail_gemm_nt<2>(in, ld_in, L, next, has_next, T, R, bpre, epi);
+    // N is 64, 128, 256 or 512 (plan_tail): N/128 tiles per wave, at least one
+    if (L.N > 256) tail_gemm_nt<4>(in, ld_in, L, next, has_next, T, R, bpre, epi);
+    else if (L.N > 128) tail_gemm_nt<2>(in, ld_in, L, next, has_next, T, R, bpre, epi);
     else tail_gemm_nt<1>(in, ld_in, L, next, has_next, T, R, bpre, epi);
 }
 
@@ -219,7 +220,8 @@ __global__ __launch_bounds__(TAIL_THREADS, 2) void decoder_tail_kernel(TailArgs 
 #pragma unroll
                       for (int e = 0; e < 4; ++e) {
                           const int row = r0 + e;
-                          const float v = acc[e] * (act[row * lda + col] > 0.f ? 1.f : LEAKY_SLOPE);
+                          // (a chain that starts at the first conv reads the linear decoder_input output: no mask)
+                          const float v = (i > 0 || a.mask_first) ? acc[e] * (act[row * lda + col] > 0.f ? 1.f : LEAKY_SLOPE) : acc[e];
                           if (i > 0) g_nxt[row * ldg + col] = v;
                           else if (row < R) gout[(row0 + row) * K0 + col] = v;
                       }
@@ -229,17 +231,19 @@ __global__ __launch_bounds__(TAIL_THREADS, 2) void decoder_tail_kernel(TailArgs 
     }
 }
 
-// LDS plan for a fused chain starting at decoder conv `start` (input = output of conv start-1).  Returns the
-// byte size, or 0 when the chain is not fusable.
+// LDS plan for a fused chain starting at decoder conv `start` (input = output of conv start-1, or of
+// decoder_input when start == 0).  Returns the byte size, or 0 when the chain is not fusable.
 size_t plan_tail(const std::vector<Layer>& dec, int start, int T, int J, TailArgs* out) {
     const int n = (int)dec.size() - start;
-    if (start < 1 || n < 1 || n > TAIL_MAX_LAYERS || T > TAIL_ROWS) return 0;
+    if (start < 0 || n < 1 || n > TAIL_MAX_LAYERS || T > TAIL_ROWS) return 0;
     for (int i = start; i < (int)dec.size(); ++i) {
-        const int K = dec[i].K, N = dec[i].N;                 // tail_gemm: 8 waves x 16 columns x {1,2} tiles
-        if ((K != 64 && K != 128 && K != 256) || (N != 64 && N != 128 && N != 256)) return 0;
+        const int K = dec[i].K, N = dec[i].N;                 // tail_gemm: 8 waves x 16 columns x {1,2,4} tiles
+        auto ok = [](int v) { return v == 64 || v == 128 || v == 256 || v == 512; };
+        if (!ok(K) || !ok(N)) return 0;
     }
     TailArgs a{};
     a.n = n;
+    a.mask_first = start > 0;
     a.G = TAIL_ROWS / T;
     int off = 0, maxg = 0;
     for (int i = 0; i <= n; ++i) {
