@@ -261,6 +261,42 @@ def main():
                              "autograd incl. frozen-VAE weight grads + torch.optim.LBFGS" % (nw, torch.__version__),
                    "mpjpe_port_mm": round(mpjpe(ref, gtw) * 1000, 4), "mpjpe_hip_mm": round(mpjpe(glob_np[:nw], gtw) * 1000, 4),
                    "mean_joint_diff_hip_vs_port_mm": round(diff * 1000, 4)}
+        post = None
+        if not a.no_extra:
+            # overlap merge + smoothing + the reference's 18-entry error report on the device, against the
+            # numpy mirror of the reference's calculate_errors on the same sequences (outside the timed region)
+            from globalegomocap_amd.errors import calculate_errors
+            gt_all, est_all = np.concatenate(gt_seq), np.concatenate(est_seq)
+            idx = (f0.long()[:, None] + torch.arange(10, device=device)[None])
+            cw = seqd["cams"][idx]
+            mid_glob = torch.einsum("btij,btkj->btki", cw[..., :3, :3], mid.double()) + cw[..., None, :3, 3]
+            gt_d, est_d = torch.as_tensor(gt_all, device=device), torch.as_tensor(est_all, device=device)
+
+            def device_report():
+                o = eng.merge_windows(glob, n_chunks, smooth=True)
+                m = eng.merge_windows(mid_glob, n_chunks, smooth=False)
+                return o, m, eng.calculate_errors_device(est_d, m, o, gt_d)
+            device_report()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                o_d, m_d, rep = device_report()
+            e1.record()
+            torch.cuda.synchronize()
+            rep = rep.cpu().numpy()
+            nf = min(gt_all.shape[0], 980)                       # bounded host sample: the mirror is per-frame python
+            t0 = time.perf_counter()
+            host = calculate_errors(est_all[:nf], m_d.cpu().numpy()[:nf], o_d.cpu().numpy()[:nf], gt_all[:nf])
+            host_ms = (time.perf_counter() - t0) * 1e3
+            sub = eng.calculate_errors(est_all[:nf], m_d[:nf], o_d[:nf], gt_all[:nf])
+            worst = max(float(np.max(np.abs(np.asarray(sub[k]) - np.asarray(host[k])))) for k in host)
+            post = {"frames": int(gt_all.shape[0]), "device_ms": round(e0.elapsed_time(e1) / 10, 4),
+                    "host_numpy_ms_per_%d_frames" % nf: round(host_ms, 1), "max_abs_diff_vs_host_m": worst,
+                    "optimized_global_mpjpe_mm": round(float(rep[2]) * 1e3, 3),
+                    "optimized_aligned_global_mpjpe_mm": round(float(rep[10]) * 1e3, 3),
+                    "aligned_optimized_mpjpe_mm": round(float(rep[13]) * 1e3, 3),
+                    "bone_length_aligned_optimized_mpjpe_mm": round(float(rep[16]) * 1e3, 3)}
         total_windows = B * world * a.steps
         line = {
             "metric": "optimised windows/sec (10-frame, 15-joint)",
@@ -278,6 +314,7 @@ def main():
             "evals_per_stage": {"local_mean": float(evals[0].mean()), "global_mean": float(evals[1].mean()),
                                 "min": int(evals.min()), "max": int(evals.max())},
             "mpjpe_mm": {"input": round(mp_in * 1e3, 3), "optimised": round(mp_opt * 1e3, 3)},
+            "post": post,
             "roofline": roof,
             "cpu_baseline": cpu,
             "other_precisions": other_modes or None,

@@ -1,0 +1,383 @@
+// Sequence post-processing on the device (gfx950): overlap averaging + Gaussian smoothing of the optimised
+// windows, and the reference's 18-entry error report, all in float64 like the numpy code they replace.
+//
+// Reference: optimizer.py:425-450 (merge_batches, gaussian_filter1d(sigma=1)), calculate_errors.py:8-83,114-179
+// (global / sequence-aligned / per-frame Procrustes / bone-length-normalised MPJPE, hip-midpoint error),
+// utils/rigid_transform_with_scale.py:18-43 (Umeyama with the reflection fix), utils/skeleton.py:124-136
+// (skeleton re-growth with fixed bone lengths).
+//
+// All of it is latency-bound bookkeeping (a 2000-frame sequence is 4 x 720 KB): the point is that the numbers
+// come out of the same stream as the optimisation, without the host loops of the reference (one LAPACK SVD per
+// frame and alignment: ~1 s of numpy per 2000 frames).  Reductions are fixed-order trees: results are
+// bitwise reproducible.
+#include "gem_internal.h"
+
+namespace gem {
+
+// ---------------------------------------------------------------------------------------------------
+// 3x3 SVD by one-sided Jacobi (Hestenes): A = U diag(S) V^T, columns of U/V orthonormal, S >= 0 unsorted.
+// Accurate to eps * cond(A) (no A^T A squaring).  Row-major 3x3 arrays.
+__device__ inline void svd3(const double* A, double* U, double* S, double* V) {
+    double a[9];
+    for (int i = 0; i < 9; ++i) { a[i] = A[i]; V[i] = (i % 4 == 0) ? 1.0 : 0.0; }
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = 0.0;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                const double alpha = a[p] * a[p] + a[3 + p] * a[3 + p] + a[6 + p] * a[6 + p];
+                const double beta = a[q] * a[q] + a[3 + q] * a[3 + q] + a[6 + q] * a[6 + q];
+                const double gamma = a[p] * a[q] + a[3 + p] * a[3 + q] + a[6 + p] * a[6 + q];
+                if (gamma == 0.0 || fabs(gamma) <= 1e-300) continue;
+                const double rel = fabs(gamma) / sqrt(alpha * beta);
+                off = rel > off ? rel : off;
+                if (!(rel > 1e-17)) continue;
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+                for (int r = 0; r < 3; ++r) {
+                    const double ap = a[3 * r + p], aq = a[3 * r + q];
+                    a[3 * r + p] = c * ap - s * aq;
+                    a[3 * r + q] = s * ap + c * aq;
+                    const double vp = V[3 * r + p], vq = V[3 * r + q];
+                    V[3 * r + p] = c * vp - s * vq;
+                    V[3 * r + q] = s * vp + c * vq;
+                }
+            }
+        if (off < 1e-16) break;
+    }
+    double smax = 0.0;
+    for (int k = 0; k < 3; ++k) {
+        S[k] = sqrt(a[k] * a[k] + a[3 + k] * a[3 + k] + a[6 + k] * a[6 + k]);
+        smax = S[k] > smax ? S[k] : smax;
+    }
+    int bad = -1;
+    for (int k = 0; k < 3; ++k) {
+        if (S[k] > 1e-14 * smax && S[k] > 0.0) {
+            for (int r = 0; r < 3; ++r) U[3 * r + k] = a[3 * r + k] / S[k];
+        } else {
+            bad = k;
+        }
+    }
+    if (bad >= 0) {          // rank-deficient (coplanar points): complete U with the cross product of the other two
+        const int i = (bad + 1) % 3, j = (bad + 2) % 3;
+        U[bad] = U[3 + i] * U[6 + j] - U[6 + i] * U[3 + j];
+        U[3 + bad] = U[6 + i] * U[j] - U[i] * U[6 + j];
+        U[6 + bad] = U[i] * U[3 + j] - U[3 + i] * U[j];
+        S[bad] = 0.0;
+    }
+}
+
+__device__ inline double det3(const double* m) {
+    return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+}
+
+struct Sim3 {
+    double cR[9];      // c * R, row-major: aligned = p @ cR + t  (row vector convention of the reference)
+    double t[3];
+};
+
+// rigid_transform_3D from moments: cov = (P-mp)^T (Q-mq) / n, var = sum_d var(P_d).
+__device__ inline void umeyama_moments(const double* mp, const double* mq, const double* cov, double var, Sim3* out) {
+    double U[9], S[3], V[9];
+    svd3(cov, U, S, V);
+    // numpy: cov = Vn diag(S) Wn, R = Vn @ Wn with (S[-1], Vn[:, -1]) negated when det(Vn) det(Wn) < 0; here
+    // Vn = U, Wn = V^T, and "last" = the smallest singular value.
+    int kmin = 0;
+    for (int k = 1; k < 3; ++k)
+        if (S[k] < S[kmin]) kmin = k;
+    double d[3] = {1.0, 1.0, 1.0};
+    if (det3(U) * det3(V) < 0.0) d[kmin] = -1.0;
+    const double c = (d[0] * S[0] + d[1] * S[1] + d[2] * S[2]) / var;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double r = 0.0;
+            for (int k = 0; k < 3; ++k) r += U[3 * i + k] * d[k] * V[3 * j + k];
+            out->cR[3 * i + j] = c * r;
+        }
+    for (int j = 0; j < 3; ++j) out->t[j] = mq[j] - (mp[0] * out->cR[j] + mp[1] * out->cR[3 + j] + mp[2] * out->cR[6 + j]);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Per-frame metrics: one thread per frame, its three J x 3 working sets live in LDS columns ([item][thread],
+// conflict-free).  Output row layout (11 + J doubles per frame, stored [col][frame]):
+//   0-2   sum_j |src - gt|            src = est, mid, opt
+//   3-4   |hip midpoint src - gt|      src = est, opt
+//   5-7   sum_j |procrustes(src) - gt|
+//   8-10  sum_j |procrustes(resized src) - resized^k gt|, k = 1, 2, 3   (the reference re-normalises gt per call)
+//   11..  per-joint error of the last one
+constexpr int ERR_FT = 64;                 // frames (threads) per workgroup
+
+struct ErrArgs {
+    const double* src[3];
+    const double* gt;
+    double* frame_out;      // [11 + MAXJ_ERR][F]
+    double* out;            // [17 + J]
+    int F, J;
+    int parents[MAXJ_ERR];
+    double bone_mm[MAXJ_ERR];
+};
+
+#define LD3(buf, j, d) buf[((j) * 3 + (d)) * ERR_FT + tx]
+
+__device__ inline void frame_umeyama(const double* P, const double* Q, int J, int tx, Sim3* sim) {
+    double mp[3] = {0, 0, 0}, mq[3] = {0, 0, 0};
+    for (int j = 0; j < J; ++j)
+        for (int d = 0; d < 3; ++d) { mp[d] += LD3(P, j, d); mq[d] += LD3(Q, j, d); }
+    for (int d = 0; d < 3; ++d) { mp[d] /= J; mq[d] /= J; }
+    double cov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, var = 0.0;
+    for (int j = 0; j < J; ++j) {
+        double p[3], q[3];
+        for (int d = 0; d < 3; ++d) { p[d] = LD3(P, j, d) - mp[d]; q[d] = LD3(Q, j, d) - mq[d]; }
+        for (int a = 0; a < 3; ++a) {
+            var += p[a] * p[a];
+            for (int b = 0; b < 3; ++b) cov[3 * a + b] += p[a] * q[b];
+        }
+    }
+    for (int i = 0; i < 9; ++i) cov[i] /= J;
+    umeyama_moments(mp, mq, cov, var / J, sim);
+}
+
+__device__ inline void apply_sim(const Sim3& s, const double* p, double* o) {
+    for (int j = 0; j < 3; ++j) o[j] = p[0] * s.cR[j] + p[1] * s.cR[3 + j] + p[2] * s.cR[6 + j] + s.t[j];
+}
+
+// skeleton.py:124-136: bone vectors from the ORIGINAL joints, rescaled to bone_mm/1000, then re-grown in index order.
+__device__ inline void resize_skeleton(double* X, double* W, const ErrArgs& a, int tx) {
+    const int J = a.J;
+    for (int j = 0; j < J; ++j) {
+        double v[3], n2 = 0.0;
+        for (int d = 0; d < 3; ++d) { v[d] = LD3(X, j, d) - LD3(X, a.parents[j], d); n2 += v[d] * v[d]; }
+        const double sc = j == 0 ? 0.0 : a.bone_mm[j] / sqrt(n2);
+        for (int d = 0; d < 3; ++d) LD3(W, j, d) = v[d] * sc / 1000.0;
+    }
+    for (int j = 0; j < J; ++j)
+        for (int d = 0; d < 3; ++d) LD3(X, j, d) = LD3(X, a.parents[j], d) + LD3(W, j, d);
+}
+
+__global__ __launch_bounds__(ERR_FT) void errors_frame_kernel(ErrArgs a) {
+    extern __shared__ double lds_d[];
+    const int tx = threadIdx.x, f = blockIdx.x * ERR_FT + tx, J = a.J;
+    double* G = lds_d;
+    double* C = G + J * 3 * ERR_FT;
+    double* W = C + J * 3 * ERR_FT;
+    if (f >= a.F) return;                    // (no barriers in this kernel: every thread works on its own columns)
+    const size_t base = (size_t)f * J * 3;
+    auto put = [&](int col, double v) { a.frame_out[(size_t)col * a.F + f] = v; };
+    for (int i = 0; i < J * 3; ++i) G[i * ERR_FT + tx] = a.gt[base + i];
+    for (int s = 0; s < 3; ++s) {
+        for (int i = 0; i < J * 3; ++i) C[i * ERR_FT + tx] = a.src[s][base + i];
+        double e = 0.0;
+        for (int j = 0; j < J; ++j) {
+            double n2 = 0.0;
+            for (int d = 0; d < 3; ++d) { const double x = LD3(C, j, d) - LD3(G, j, d); n2 += x * x; }
+            e += sqrt(n2);
+        }
+        put(s, e);
+        if (s != 1) {                        // hip midpoint = (joint 7 + joint 11) / 2 (calculate_errors.py:33-47)
+            double n2 = 0.0;
+            for (int d = 0; d < 3; ++d) {
+                const double x = (LD3(C, 7, d) + LD3(C, 11, d)) / 2 - (LD3(G, 7, d) + LD3(G, 11, d)) / 2;
+                n2 += x * x;
+            }
+            put(s == 0 ? 3 : 4, sqrt(n2));
+        }
+        Sim3 sim;
+        frame_umeyama(C, G, J, tx, &sim);
+        e = 0.0;
+        for (int j = 0; j < J; ++j) {
+            double p[3] = {LD3(C, j, 0), LD3(C, j, 1), LD3(C, j, 2)}, o[3], n2 = 0.0;
+            apply_sim(sim, p, o);
+            for (int d = 0; d < 3; ++d) { const double x = o[d] - LD3(G, j, d); n2 += x * x; }
+            e += sqrt(n2);
+        }
+        put(5 + s, e);
+    }
+    for (int s = 0; s < 3; ++s) {
+        resize_skeleton(G, W, a, tx);        // gt is re-normalised once more per call, as the reference does
+        for (int i = 0; i < J * 3; ++i) C[i * ERR_FT + tx] = a.src[s][base + i];
+        resize_skeleton(C, W, a, tx);
+        Sim3 sim;
+        frame_umeyama(C, G, J, tx, &sim);
+        double e = 0.0;
+        for (int j = 0; j < J; ++j) {
+            double p[3] = {LD3(C, j, 0), LD3(C, j, 1), LD3(C, j, 2)}, o[3], n2 = 0.0;
+            apply_sim(sim, p, o);
+            for (int d = 0; d < 3; ++d) { const double x = o[d] - LD3(G, j, d); n2 += x * x; }
+            const double en = sqrt(n2);
+            e += en;
+            if (s == 2) put(11 + j, en);
+        }
+        put(8 + s, e);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Sequence-level part: ONE workgroup.  Three similarity alignments over all F*J points (means, centred
+// moments, SVD by thread 0, aligned errors) and the column sums of the per-frame table.
+constexpr int ERR_ST = 1024;
+
+struct SeqRed {
+    double* lds;       // [2][16]
+    int parity;
+    __device__ inline double sum(double v) {          // all threads get the total; one barrier per call
+        v = wave_sum_dpp(v);
+        double* r = lds + 16 * parity;
+        parity ^= 1;
+        if ((threadIdx.x & 63) == 0) r[threadIdx.x >> 6] = v;
+        __syncthreads();
+        double t = 0.0;
+        for (int i = 0; i < ERR_ST / 64; ++i) t += r[i];
+        return t;
+    }
+};
+
+__global__ __launch_bounds__(ERR_ST) void errors_sequence_kernel(ErrArgs a) {
+    __shared__ double red[32];
+    __shared__ Sim3 sim_s;
+    SeqRed R{red, 0};
+    const int tid = threadIdx.x, J = a.J, F = a.F;
+    const size_t N = (size_t)F * J;
+    double* out = a.out;
+    for (int s = 0; s < 3; ++s) {
+        const double* P = a.src[s];
+        const double* Q = a.gt;
+        double acc[6] = {0, 0, 0, 0, 0, 0};
+        for (size_t i = tid; i < N; i += ERR_ST)
+            for (int d = 0; d < 3; ++d) { acc[d] += P[i * 3 + d]; acc[3 + d] += Q[i * 3 + d]; }
+        double m[6];
+        for (int k = 0; k < 6; ++k) m[k] = R.sum(acc[k]) / (double)N;
+        double c[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (size_t i = tid; i < N; i += ERR_ST) {
+            double p[3], q[3];
+            for (int d = 0; d < 3; ++d) { p[d] = P[i * 3 + d] - m[d]; q[d] = Q[i * 3 + d] - m[3 + d]; }
+            for (int x = 0; x < 3; ++x) {
+                c[9] += p[x] * p[x];
+                for (int y = 0; y < 3; ++y) c[3 * x + y] += p[x] * q[y];
+            }
+        }
+        double cov[10];
+        for (int k = 0; k < 10; ++k) cov[k] = R.sum(c[k]) / (double)N;
+        if (tid == 0) umeyama_moments(m, m + 3, cov, cov[9], &sim_s);
+        __syncthreads();
+        const Sim3 sim = sim_s;
+        double e = 0.0, er = 0.0;
+        for (size_t i = tid; i < N; i += ERR_ST) {
+            double p[3] = {P[i * 3], P[i * 3 + 1], P[i * 3 + 2]}, o[3], n2 = 0.0;
+            apply_sim(sim, p, o);
+            for (int d = 0; d < 3; ++d) { const double x = o[d] - Q[i * 3 + d]; n2 += x * x; }
+            e += sqrt(n2);
+        }
+        for (int f = tid; f < F; f += ERR_ST) {
+            const double* p7 = P + ((size_t)f * J + 7) * 3;
+            const double* p11 = P + ((size_t)f * J + 11) * 3;
+            const double* q7 = Q + ((size_t)f * J + 7) * 3;
+            const double* q11 = Q + ((size_t)f * J + 11) * 3;
+            double a7[3], a11[3], n2 = 0.0;
+            apply_sim(sim, p7, a7);
+            apply_sim(sim, p11, a11);
+            for (int d = 0; d < 3; ++d) { const double x = (a7[d] + a11[d]) / 2 - (q7[d] + q11[d]) / 2; n2 += x * x; }
+            er += sqrt(n2);
+        }
+        e = R.sum(e);
+        er = R.sum(er);
+        if (tid == 0) { out[8 + s] = e / (double)N; out[5 + s] = er / (double)F; }
+        __syncthreads();
+    }
+    for (int col = 0; col < 11 + J; ++col) {
+        double v = 0.0;
+        for (int f = tid; f < F; f += ERR_ST) v += a.frame_out[(size_t)col * F + f];
+        v = R.sum(v);
+        if (tid == 0) {
+            if (col < 3) out[col] = v / (double)N;                       // *_global_mpjpe
+            else if (col < 5) out[col] = v / (double)F;                   // *_camera_pos_error
+            else if (col < 8) out[11 + (col - 5)] = v / (double)N;        // per-frame Procrustes
+            else if (col < 11) out[14 + (col - 8)] = v / (double)N;       // bone-length normalised
+            else out[17 + (col - 11)] = v / (double)F;                    // joints_error
+        }
+    }
+}
+
+size_t errors_frame_lds_bytes(int J) { return (size_t)3 * J * 3 * ERR_FT * sizeof(double); }
+
+int launch_errors(gem_handle* h, const double* est, const double* mid, const double* opt, const double* gt, int F,
+                  const double* bone_mm, double* frame_out, double* out, hipStream_t s) {
+    ErrArgs a;
+    a.src[0] = est; a.src[1] = mid; a.src[2] = opt; a.gt = gt;
+    a.frame_out = frame_out; a.out = out; a.F = F; a.J = h->J;
+    for (int j = 0; j < MAXJ_ERR; ++j) {
+        a.parents[j] = j < h->J ? h->cfg.parents[j] : 0;
+        a.bone_mm[j] = j < h->J ? bone_mm[j] : 0.0;
+    }
+    const size_t lds = errors_frame_lds_bytes(h->J);
+    static bool attr_set = false;
+    if (!attr_set) {
+        GEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(errors_frame_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)errors_frame_lds_bytes(MAXJ_ERR)));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(errors_frame_kernel, dim3((F + ERR_FT - 1) / ERR_FT), dim3(ERR_FT), lds, s, a);
+    GEM_HIP(hipGetLastError());
+    hipLaunchKernelGGL(errors_sequence_kernel, dim3(1), dim3(ERR_ST), 0, s, a);
+    GEM_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// merge_batches (optimizer.py:425-437) per chunk + gaussian_filter1d(sigma=1, mode='reflect', truncate=4)
+// along the frames of the chunk (optimizer.py:448-450).  windows [n_chunks*wpc, T, JC] f64 ->
+// merged [n_chunks*fpc, JC] f64 with fpc = wpc*(T-overlap) + overlap.
+__global__ void merge_windows_kernel(const double* __restrict__ win, double* __restrict__ out, int n_chunks, int wpc, int T, int JC,
+                                     int overlap) {
+    const int stride = T - overlap, fpc = wpc * stride + overlap;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)n_chunks * fpc * JC) return;
+    const int c = (int)(i % JC);
+    const size_t fr = i / JC;
+    const int chunk = (int)(fr / fpc), f = (int)(fr % fpc);
+    int w = f / stride, t = f - w * stride;
+    if (w >= wpc) { w = wpc - 1; t = f - w * stride; }                 // the last `overlap` frames of the chunk
+    const double* base = win + (size_t)chunk * wpc * T * JC;
+    double v = base[((size_t)w * T + t) * JC + c];
+    if (t < overlap && w > 0) v = (base[((size_t)(w - 1) * T + t + stride) * JC + c] + v) / 2;
+    out[i] = v;
+}
+
+__global__ void gauss_smooth_kernel(const double* __restrict__ in, double* __restrict__ out, int n_chunks, int fpc, int JC) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)n_chunks * fpc * JC) return;
+    const int c = (int)(i % JC);
+    const size_t fr = i / JC;
+    const int chunk = (int)(fr / fpc), f = (int)(fr % fpc);
+    // scipy: radius = int(truncate * sigma + 0.5) = 4, weights exp(-x^2 / 2) normalised, correlate1d, mode='reflect'
+    double w[5], wsum = 0.0;
+    for (int k = 0; k <= 4; ++k) w[k] = exp(-0.5 * k * k);
+    wsum = w[0] + 2 * (w[1] + w[2] + w[3] + w[4]);
+    const double* base = in + (size_t)chunk * fpc * JC;
+    double acc = 0.0;
+    for (int k = -4; k <= 4; ++k) {
+        int g = f + k;
+        // 'reflect' = (d c b a | a b c d | d c b a), period 2n
+        const int period = 2 * fpc;
+        g = ((g % period) + period) % period;
+        if (g >= fpc) g = period - 1 - g;
+        acc += w[k < 0 ? -k : k] / wsum * base[(size_t)g * JC + c];
+    }
+    out[i] = acc;
+}
+
+int launch_merge(const double* win, double* tmp, double* out, int n_chunks, int wpc, int T, int JC, int overlap, int smooth,
+                 hipStream_t s) {
+    const int fpc = wpc * (T - overlap) + overlap;
+    const size_t n = (size_t)n_chunks * fpc * JC;
+    if (n == 0) return 0;
+    const dim3 grid((unsigned)((n + 255) / 256));
+    hipLaunchKernelGGL(merge_windows_kernel, grid, dim3(256), 0, s, win, smooth ? tmp : out, n_chunks, wpc, T, JC, overlap);
+    GEM_HIP(hipGetLastError());
+    if (smooth) {
+        hipLaunchKernelGGL(gauss_smooth_kernel, grid, dim3(256), 0, s, (const double*)tmp, out, n_chunks, fpc, JC);
+        GEM_HIP(hipGetLastError());
+    }
+    return 0;
+}
+
+}  // namespace gem

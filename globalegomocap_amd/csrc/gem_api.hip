@@ -213,6 +213,7 @@ void gem_destroy(gem_handle* h) {
     free_all(h->net[0].allocs);
     free_all(h->net[1].allocs);
     free_all(h->ws.allocs);
+    if (h->post_work) (void)hipFree(h->post_work);
     delete h;
 }
 
@@ -549,6 +550,42 @@ int gem_set_precision(gem_handle* h, int mode) {
     if (!h || mode < 0 || mode > 2) { set_error("gem_set_precision: mode must be 0 (f32), 1 (bf16x3) or 2 (bf16)"); return 1; }
     h->precision = mode;
     return 0;
+}
+
+static int post_scratch(gem_handle* h, size_t elems) {
+    if (elems <= h->post_work_elems) return 0;
+    GEM_HIP(hipDeviceSynchronize());                 // a previous call may still be reading the old buffer
+    if (h->post_work) GEM_HIP(hipFree(h->post_work));
+    h->post_work = nullptr; h->post_work_elems = 0;
+    GEM_HIP(hipMalloc((void**)&h->post_work, elems * sizeof(double)));
+    h->post_work_elems = elems;
+    return 0;
+}
+
+int gem_merge_windows(gem_handle* h, const double* d_windows, int n_chunks, int windows_per_chunk, int overlap, int smooth,
+                      double* d_out, void* stream) {
+    if (!h) { set_error("gem_merge_windows: null handle"); return 1; }
+    if (n_chunks < 0 || windows_per_chunk < 1 || overlap < 0 || 2 * overlap > h->T) {
+        set_error("gem_merge_windows: need windows_per_chunk >= 1 and 0 <= 2*overlap <= seq_len"); return 1;
+    }
+    if (n_chunks == 0) return 0;
+    if (!d_windows || !d_out) { set_error("gem_merge_windows: null argument"); return 1; }
+    GEM_HIP(hipSetDevice(h->cfg.device));
+    const int fpc = windows_per_chunk * (h->T - overlap) + overlap;
+    const size_t n = (size_t)n_chunks * fpc * h->C;
+    if (smooth && post_scratch(h, n)) return 1;
+    return launch_merge(d_windows, h->post_work, d_out, n_chunks, windows_per_chunk, h->T, h->C, overlap, smooth, (hipStream_t)stream);
+}
+
+int gem_calculate_errors(gem_handle* h, const double* d_est, const double* d_mid, const double* d_opt, const double* d_gt,
+                         int n_frames, const double* h_bone_mm, double* d_out, void* stream) {
+    if (!h) { set_error("gem_calculate_errors: null handle"); return 1; }
+    if (h->J < 12) { set_error("gem_calculate_errors: the hip-midpoint error needs joints 7 and 11 (n_joints >= 12)"); return 1; }
+    if (n_frames < 1) { set_error("gem_calculate_errors: n_frames must be >= 1"); return 1; }
+    if (!d_est || !d_mid || !d_opt || !d_gt || !h_bone_mm || !d_out) { set_error("gem_calculate_errors: null argument"); return 1; }
+    GEM_HIP(hipSetDevice(h->cfg.device));
+    if (post_scratch(h, (size_t)(11 + MAXJ_ERR) * n_frames)) return 1;
+    return launch_errors(h, d_est, d_mid, d_opt, d_gt, n_frames, h_bone_mm, h->post_work, d_out, (hipStream_t)stream);
 }
 
 int gem_profile_enable(gem_handle* h, int on) {

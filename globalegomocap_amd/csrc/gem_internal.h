@@ -13,6 +13,7 @@ constexpr int PAD = 64;                    // every feature dimension is zero-pa
 constexpr float LEAKY_SLOPE = 0.01f;       // torch.nn.LeakyReLU default (SeqConvVAE.py:38,77,90)
 constexpr double BN_EPS = 1e-5;            // torch.nn.BatchNorm1d default
 constexpr int MAX_HIST = 128;              // capacity of the per-window (s,y) ring
+constexpr int MAXJ_ERR = GEM_MAX_JOINTS;   // joints handled by the error-report kernels (errors.hip)
 constexpr int N_LOG = 1 << 16;             // ring of active-window counts kept for the profiling hook
 
 inline int pad64(int x) { return (x + PAD - 1) / PAD * PAD; }
@@ -142,6 +143,8 @@ struct gem_handle {
     gem::Profile prof;
     int precision = 0;             // GEM_PRECISION_*
     int n_cu = 256;                // compute units of the device (hipDeviceAttributeMultiprocessorCount)
+    double* post_work = nullptr;   // scratch of the post-processing calls (errors.hip), grown on demand
+    size_t post_work_elems = 0;
     int* d_parents = nullptr;
     int* d_children = nullptr;     // [J][J] child lists, -1 terminated
 };
@@ -227,6 +230,13 @@ int launch_relative_global(const float* local, const double* cams, const int32_t
                            hipStream_t s);
 int launch_to_global(const float* rel, const double* cams, const int32_t* frame0, double* out, int B, int T, int J,
                      hipStream_t s);
+
+// sequence post-processing (errors.hip)
+int launch_errors(gem_handle* h, const double* est, const double* mid, const double* opt, const double* gt, int F,
+                  const double* bone_mm, double* frame_out, double* out, hipStream_t s);
+int launch_merge(const double* win, double* tmp, double* out, int n_chunks, int wpc, int T, int JC, int overlap, int smooth,
+                 hipStream_t s);
+size_t errors_frame_lds_bytes(int J);
 
 int launch_lbfgs_init(gem_handle* h, int B, const gem_lbfgs_opts& o, hipStream_t s);
 int launch_lbfgs_advance(gem_handle* h, int B, const gem_lbfgs_opts& o, hipStream_t s);

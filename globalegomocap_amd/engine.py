@@ -172,6 +172,50 @@ class WindowEngine:
                                                   _stream()), self.lib)
         return mid, glob, stats
 
+    # ------------------------------------------------------------------ sequence post-processing
+    def _f64(self, a):
+        t = torch.as_tensor(np.asarray(a) if not torch.is_tensor(a) else a)
+        return t.to(device=self.device, dtype=torch.float64).contiguous()
+
+    def merge_windows(self, windows, n_chunks, overlap=2, smooth=True):
+        """merge_batches per chunk (+ gaussian_filter1d sigma=1 per chunk): [n_chunks*wpc,T,J,3] -> [n_chunks*fpc,J,3] f64."""
+        w = self._f64(windows).reshape(-1, self.T, N_JOINTS, 3)
+        if n_chunks < 1 or w.shape[0] % n_chunks:
+            raise ValueError("merge_windows: %d windows do not split into %d chunks" % (w.shape[0], n_chunks))
+        wpc = w.shape[0] // n_chunks
+        fpc = wpc * (self.T - overlap) + overlap
+        out = torch.empty(n_chunks * fpc, N_JOINTS, 3, device=self.device, dtype=torch.float64)
+        _capi.check(self.lib.gem_merge_windows(self._h, _ptr(w), n_chunks, wpc, overlap, 1 if smooth else 0, _ptr(out), _stream()),
+                    self.lib)
+        return out
+
+    ERROR_KEYS = ("original_global_mpjpe", "mid_global_mpjpe", "optimized_global_mpjpe", "original_camera_pos_error",
+                  "optimized_camera_pos_error", "original_aligned_camera_pos_error", "mid_aligned_camera_pose_error",
+                  "optimized_aligned_camera_pos_error", "original_aligned_global_mpjpe", "aligned_mid_seq_mpjpe",
+                  "optimized_aligned_global_mpjpe", "aligned_original_mpjpe", "aligned_mid_optimized_mpjpe",
+                  "aligned_optimized_mpjpe", "bone_length_aligned_original_mpjpe", "bone_length_aligned_mid_optimized_mpjpe",
+                  "bone_length_aligned_optimized_mpjpe")
+
+    def calculate_errors_device(self, est, mid, opt, gt):
+        """calculate_errors on the device: returns the [17+J] f64 tensor (no synchronisation)."""
+        from .skeleton import mean_bone_length_mm
+        e, m, o, g = (self._f64(x).reshape(-1, N_JOINTS, 3) for x in (est, mid, opt, gt))
+        if not (e.shape == m.shape == o.shape == g.shape):
+            raise AssertionError("calculate_errors: sequences differ in shape")
+        bone = np.ascontiguousarray(mean_bone_length_mm(), dtype=np.float64)
+        out = torch.empty(17 + N_JOINTS, device=self.device, dtype=torch.float64)
+        _capi.check(self.lib.gem_calculate_errors(self._h, _ptr(e), _ptr(m), _ptr(o), _ptr(g), e.shape[0],
+                                                  bone.ctypes.data_as(C.POINTER(C.c_double)), _ptr(out), _stream()), self.lib)
+        return out
+
+    def calculate_errors(self, est, mid, opt, gt):
+        """Same keys and definitions as the reference's calculate_errors (calculate_errors.py:114-179)."""
+        from collections import OrderedDict
+        v = self.calculate_errors_device(est, mid, opt, gt).cpu().numpy()
+        r = OrderedDict((k, float(v[i])) for i, k in enumerate(self.ERROR_KEYS))
+        r["joints_error"] = v[17:].copy()
+        return r
+
     # ------------------------------------------------------------------ profiling hook (bench.py)
     def profile_enable(self, on):
         _capi.check(self.lib.gem_profile_enable(self._h, 1 if on else 0), self.lib)

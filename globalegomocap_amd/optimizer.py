@@ -108,10 +108,11 @@ class SequenceOptimizer:
         w_local = energy_weights(weight_3d / 10000, smoothness_weight / 100, bone_length_weight, vae_weight, reproj_weight)
         return w_local, w_global
 
-    def run(self, est_local, cams, heat, starts, chunk_of_window, chunk_bounds, w_local, w_global, eps=None):
+    def run(self, est_local, cams, heat, starts, chunk_of_window, chunk_bounds, w_local, w_global, eps=None, keep_device=False):
         """est_local [F,15,3], cams [F,4,4], heat [F,H,W,15]; starts [B] first frame of each window;
         chunk_bounds [(f0, f1)] per chunk for the per-chunk mean bone length (optimizer.py:42-43).
-        Returns (mid_local f32 [B,T,15,3], global f64 [B,T,15,3], stats)."""
+        Returns (mid_local f32 [B,T,15,3], global f64 [B,T,15,3], stats); the two pose arrays stay torch device
+        tensors with keep_device=True (for the device post-processing)."""
         e = self.engine
         dev = e.device
         B = len(starts)
@@ -128,15 +129,20 @@ class SequenceOptimizer:
         mid, glob, stats = e.optimize_windows(pose_d, cams_d, heat_d, f0, mb_w, eps_l, eps_g, w_local, w_global, self.opts)
         st = stats_to_numpy(stats)
         _raise_if_degenerate(st)
+        if keep_device:
+            return mid, glob, st
         return mid.cpu().numpy(), glob.cpu().numpy(), st
 
 
 def main(data_id, camera_model_path, vae_weight, gmm_weight, smoothness_weight, bone_length_weight, weight_3d,
          reproj_weight, visualization=False, final_smooth=False, merge=True, save=False, save_pose=False,
-         global_vae_path=GLOBAL_VAE_PATH, local_vae_path=LOCAL_VAE_PATH, eps=None, optimizer=None, return_stats=False):
+         global_vae_path=GLOBAL_VAE_PATH, local_vae_path=LOCAL_VAE_PATH, eps=None, optimizer=None, return_stats=False,
+         device_metrics=False):
     """pickle in, poses out -- the reference's `main` (optimizer.py:311-507) for one chunk directory.
 
     Returns (errors OrderedDict[18], final_estimated_seq, mid_local_pose_seq, final_optimized_seq, final_gt_seq).
+    device_metrics=True keeps the optimised windows on the device and runs the overlap merge, the Gaussian
+    smoothing and `calculate_errors` there (gem_merge_windows / gem_calculate_errors) instead of in numpy.
     """
     if visualization or save:
         raise NotImplementedError("visualization/save write open3d meshes (optimizer.py:452-504): outside the hot path")
@@ -151,17 +157,24 @@ def main(data_id, camera_model_path, vae_weight, gmm_weight, smoothness_weight, 
     opt = optimizer or SequenceOptimizer(camera_model_path, global_vae_path, local_vae_path, max_windows=max(len(starts), 1))
     w_local, w_global = opt.stage_weights(vae_weight, smoothness_weight, bone_length_weight, weight_3d, reproj_weight)
     mid_local, opt_global, stats = opt.run(est_local, cams, heat, starts, np.zeros(len(starts), dtype=np.int64),
-                                           [(0, len(est_local))], w_local, w_global, eps=eps)
+                                           [(0, len(est_local))], w_local, w_global, eps=eps, keep_device=device_metrics)
+    opt_global_d = None
+    if device_metrics:
+        opt_global_d, mid_local = opt_global, mid_local.cpu().numpy()
     # the sequences main() returns besides the optimised one (host float64, as in the reference)
     loc_w, cam_w = cut_windows(est_local, starts, seq_len), cut_windows(cams, starts, seq_len)
     est_global = to_global_numpy(relative_global_numpy(loc_w, cam_w), cam_w)
     mid_global = to_global_numpy(relative_global_numpy(mid_local, cam_w), cam_w)
-    final_optimized_seq = merge_batches(opt_global, overlap)
+    if device_metrics:
+        final_optimized_d = opt.engine.merge_windows(opt_global_d, 1, overlap=overlap, smooth=final_smooth is True)
+        final_optimized_seq = final_optimized_d.cpu().numpy()
+    else:
+        final_optimized_seq = merge_batches(opt_global, overlap)
     final_estimated_seq = merge_batches(est_global, overlap)
     mid_local_pose_seq = merge_batches(mid_local, overlap)
     mid_estimated_seq = merge_batches(mid_global, overlap)
     final_gt_seq = merge_batches(cut_windows(gt, starts, seq_len), overlap)
-    if final_smooth is True:
+    if final_smooth is True and not device_metrics:
         from .sequence import final_smooth as _smooth
         final_optimized_seq = _smooth(final_optimized_seq)
     if save_pose:
@@ -171,6 +184,9 @@ def main(data_id, camera_model_path, vae_weight, gmm_weight, smoothness_weight, 
         with open(os.path.join(out_dir, "result_pose.pkl"), "wb") as f:
             pickle.dump({"estimated_pose": final_estimated_seq, "optimized_pose": final_optimized_seq,
                          "mid_optimized_pose": mid_estimated_seq, "gt_pose": final_gt_seq}, f)
-    errors = calculate_errors(final_estimated_seq, mid_estimated_seq, final_optimized_seq, final_gt_seq)
+    if device_metrics:
+        errors = opt.engine.calculate_errors(final_estimated_seq, mid_estimated_seq, final_optimized_d, final_gt_seq)
+    else:
+        errors = calculate_errors(final_estimated_seq, mid_estimated_seq, final_optimized_seq, final_gt_seq)
     res = (errors, list(final_estimated_seq), list(mid_local_pose_seq), final_optimized_seq, list(final_gt_seq))
     return res + (stats,) if return_stats else res

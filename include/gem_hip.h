@@ -147,6 +147,26 @@ int gem_optimize_windows(gem_handle* h, int B, const float* d_local_pose, const 
                          const gem_lbfgs_opts* opt, float* d_mid_local, double* d_global,
                          gem_window_stats* d_stats, void* stream);
 
+/* ---- sequence post-processing: the reporting side of the path, on the same stream ----
+ * Both calls may grow an internal scratch buffer (hipMalloc, synchronous) the first time a larger sequence is seen. */
+
+/* merge_batches (optimizer.py:425-437) per chunk, then optionally gaussian_filter1d(sigma=1, axis=0) per chunk
+ * (optimizer.py:448-450).  d_windows [n_chunks*windows_per_chunk, T, J, 3] f64 (e.g. d_global of
+ * gem_optimize_windows) -> d_out [n_chunks*frames_per_chunk, J, 3] f64 with
+ * frames_per_chunk = windows_per_chunk*(T-overlap)+overlap. */
+int gem_merge_windows(gem_handle* h, const double* d_windows, int n_chunks, int windows_per_chunk, int overlap,
+                      int smooth, double* d_out, void* stream);
+
+/* calculate_errors (calculate_errors.py:114-179): d_est / d_mid / d_opt / d_gt [n_frames,J,3] f64 (metres),
+ * h_bone_mm [J] reference bone lengths in mm (utils/skeleton.py:102-110).  d_out [17+J] f64 in the order of
+ * the reference's result dict: original/mid/optimized_global_mpjpe, original/optimized_camera_pos_error,
+ * original/mid/optimized aligned camera error, original/mid/optimized sequence-aligned mpjpe,
+ * per-frame-Procrustes mpjpe x3, bone-length-normalised mpjpe x3, joints_error[J].
+ * Includes the batched 3x3 SVD Umeyama (utils/rigid_transform_with_scale.py:18-43) and the skeleton
+ * re-growth (utils/skeleton.py:124-136).  Needs n_joints >= 12 (hip joints 7 and 11). */
+int gem_calculate_errors(gem_handle* h, const double* d_est, const double* d_mid, const double* d_opt,
+                         const double* d_gt, int n_frames, const double* h_bone_mm, double* d_out, void* stream);
+
 /* Timing hook for bench.py's roofline: average device time (ms) of the launches of the dominant
  * kernel family since the last reset, measured with HIP events on the launch stream.
  * family: 0 = decoder GEMMs (forward + backward-data), 1 = energy kernel, 2 = L-BFGS advance.

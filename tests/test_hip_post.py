@@ -1,0 +1,128 @@
+"""GPU parity tests of the sequence post-processing calls: overlap merge + Gaussian
+smoothing and the 18-entry error report, against the host mirrors (which tests/test_host_cpu.py pins to
+the reference's golden run) and against the golden run itself."""
+import numpy as np
+import pytest
+
+from globalegomocap_amd import sequence, synth
+from globalegomocap_amd.camera import FisheyeCamera, DEFAULT_CALIBRATION
+from globalegomocap_amd.errors import calculate_errors
+from globalegomocap_amd.skeleton import MEAN3D_MM
+from helpers import TINY
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("gpu tests need a HIP device")
+    from globalegomocap_amd.engine import WindowEngine
+    return WindowEngine(TINY, FisheyeCamera.from_json(DEFAULT_CALIBRATION), max_windows=8)
+
+
+def _sequences(F, seed, noise=(0.03, 0.02, 0.01)):
+    """gt = walking mean skeleton with per-frame articulation; est/mid/opt = rotated, scaled, noisy copies."""
+    rng = np.random.default_rng(seed)
+    base = MEAN3D_MM.T / 1000.0
+    t = np.arange(F)[:, None, None]
+    gt = base[None] + 0.05 * np.sin(0.1 * t + rng.uniform(0, 6, (1, 15, 3))) + np.array([0.01, 0.0, 0.002]) * t
+    out = []
+    for k, s in enumerate(noise):
+        a = 0.2 * (k + 1)
+        Rz = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1.0]])
+        out.append((1.0 + 0.05 * k) * gt @ Rz + rng.normal(0, s, gt.shape) + rng.normal(0, 0.1, (1, 1, 3)))
+    return out[0], out[1], out[2], gt
+
+
+@pytest.mark.parametrize("n_chunks,wpc,overlap,smooth", [(3, 12, 2, True), (1, 1, 2, True), (2, 5, 2, False), (2, 4, 0, True),
+                                                         (1, 3, 5, False)])
+def test_merge_and_smooth_against_host_mirror(engine, n_chunks, wpc, overlap, smooth):
+    rng = np.random.default_rng(7)
+    w = rng.normal(size=(n_chunks * wpc, 10, 15, 3))
+    got = engine.merge_windows(w, n_chunks, overlap=overlap, smooth=smooth).cpu().numpy()
+    ref = []
+    for c in range(n_chunks):
+        m = sequence.merge_batches(w[c * wpc:(c + 1) * wpc], overlap=overlap)
+        ref.append(sequence.final_smooth(m) if smooth else m)
+    ref = np.concatenate(ref)
+    assert got.shape == ref.shape
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-14)      # float64 both sides; only the summation order differs
+
+
+def test_merge_rejects_bad_arguments(engine):
+    from globalegomocap_amd._capi import GemError
+    with pytest.raises(ValueError):
+        engine.merge_windows(np.zeros((5, 10, 15, 3)), 2)
+    with pytest.raises(GemError):
+        engine.merge_windows(np.zeros((4, 10, 15, 3)), 2, overlap=6)
+
+
+@pytest.mark.parametrize("F,seed", [(98, 1), (257, 2), (1, 3), (2000, 4)])
+def test_error_report_against_host_mirror(engine, F, seed):
+    est, mid, opt, gt = _sequences(F, seed)
+    ref = calculate_errors(est, mid, opt, gt)
+    got = engine.calculate_errors(est, mid, opt, gt)
+    assert list(got.keys()) == list(ref.keys())
+    for k in ref:
+        np.testing.assert_allclose(got[k], ref[k], rtol=1e-9, atol=1e-12, err_msg=k)
+
+
+def test_error_report_is_reproducible_and_handles_reflections(engine):
+    est, mid, opt, gt = _sequences(130, 9)
+    est = est * np.array([1.0, 1.0, -1.0])          # mirrored estimate: det(V)det(W) < 0 -> the reflection fix is exercised
+    a = engine.calculate_errors_device(est, mid, opt, gt).cpu().numpy()
+    b = engine.calculate_errors_device(est, mid, opt, gt).cpu().numpy()
+    assert np.array_equal(a, b)
+    ref = calculate_errors(est, mid, opt, gt)
+    got = engine.calculate_errors(est, mid, opt, gt)
+    for k in ref:
+        np.testing.assert_allclose(got[k], ref[k], rtol=1e-9, atol=1e-12, err_msg=k)
+
+
+def test_error_report_against_reference_golden(engine, golden):
+    g = golden("pipeline_tiny")
+    data = synth.make_sequence(n_frames=100, seed=int(g["seq_seed"]), with_heatmaps=False)
+    cams = np.asarray(data["camera_pose_list"])
+    for tag in ("smooth", "raw"):
+        mid = g["mid_local_" + tag] + cams[:98, :3, 3][:, None, :]      # see tests/test_host_cpu.py for why this is exact
+        e = engine.calculate_errors(g["est_" + tag], mid, g["opt_" + tag], g["gt_" + tag])
+        for k, v in e.items():
+            ref = g["err_%s/%s" % (tag, k)]
+            tol = dict(rtol=1e-5, atol=1e-7) if "mid" in k else dict(rtol=1e-9, atol=1e-12)
+            np.testing.assert_allclose(v, ref, err_msg=k, **tol)
+
+
+def test_error_report_rejects_bad_arguments(engine):
+    est, mid, opt, gt = _sequences(10, 5)
+    with pytest.raises(AssertionError):
+        engine.calculate_errors(est[:5], mid, opt, gt)
+
+
+@pytest.mark.parametrize("smooth", [True, False])
+def test_main_with_device_metrics_matches_host_metrics(golden, tmp_path, smooth):
+    """The main() mirror with merge / smoothing / calculate_errors on the device vs the same run with numpy."""
+    import pickle
+    import torch
+    from globalegomocap_amd import optimizer as gopt
+    from helpers import sd_from_npz
+    g = golden("pipeline_tiny")
+    lt = golden("lbfgs_tiny")
+    data = synth.make_sequence(n_frames=100, seed=int(g["seq_seed"]))
+    d = tmp_path / "chunk0"
+    d.mkdir()
+    with open(d / "test_data.pkl", "wb") as f:
+        pickle.dump({k: data[k] for k in ("estimated_local_skeleton", "gt_global_skeleton", "camera_pose_list", "heatmap_list")}, f)
+    torch.manual_seed(int(g["eps_seed"]))
+    eps = torch.randn(24, 32)
+    kw = dict(final_smooth=smooth, global_vae_path=sd_from_npz(lt, "global/"), local_vae_path=sd_from_npz(lt, "local/"), eps=eps)
+    args = (str(d), DEFAULT_CALIBRATION, 0.0, 0.0, float(g["smooth"]), 0.01, float(g["weight_3d"]), 0.01)
+    host = gopt.main(*args, **kw)
+    dev = gopt.main(*args, device_metrics=True, **kw)
+    np.testing.assert_allclose(dev[3], host[3], rtol=0, atol=1e-13)           # final_optimized_seq (the run itself is bitwise repeatable)
+    assert list(dev[0].keys()) == list(host[0].keys())
+    for k in host[0]:
+        np.testing.assert_allclose(dev[0][k], host[0][k], rtol=1e-9, atol=1e-12, err_msg=k)
+    tag = "smooth" if smooth else "raw"
+    assert abs(dev[0]["optimized_global_mpjpe"] - float(g["err_%s/optimized_global_mpjpe" % tag])) < 0.5e-3
