@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, spec
 PEAK_BF16_MATRIX_TFLOPS = 2500.0    # dense bf16 MFMA, spec
+PEAK_HBM_GBPS = 8000.0              # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 CHUNK = 100                         # frames per chunk directory (process_test_data.py:177-184)
 LATENT_GAIN = float(os.environ.get("GEM_BENCH_LATENT_GAIN", "8"))   # latent gauge of the synthetic VAEs (see vae_torch.fit_vae)
 PROFILE_STEPS = 2
@@ -297,6 +298,23 @@ def main():
                     "optimized_aligned_global_mpjpe_mm": round(float(rep[10]) * 1e3, 3),
                     "aligned_optimized_mpjpe_mm": round(float(rep[13]) * 1e3, 3),
                     "bone_length_aligned_optimized_mpjpe_mm": round(float(rep[16]) * 1e3, 3)}
+        lift = None
+        if not a.no_extra:
+            # heat-map argmax + fisheye un-projection, one streaming pass over the resident heat-maps
+            depth_d = seqd["est_local"].double().norm(dim=-1)
+            eng.lift_skeleton(seqd["heat"], depth_d)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                eng.lift_skeleton(seqd["heat"], depth_d)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 10
+            nbytes = seqd["heat"].numel() * 4
+            lift = {"frames": int(n_frames), "ms": round(ms, 4), "heatmap_bytes": int(nbytes),
+                    "achieved_GBps": round(nbytes / ms / 1e6, 1), "frac_of_hbm_peak": round(nbytes / ms / 1e6 / PEAK_HBM_GBPS, 4),
+                    "note": "incl. the f32/f64 output allocation of the Python wrapper; kernel-only time is in profiles/"}
         total_windows = B * world * a.steps
         line = {
             "metric": "optimised windows/sec (10-frame, 15-joint)",
@@ -315,6 +333,7 @@ def main():
                                 "min": int(evals.min()), "max": int(evals.max())},
             "mpjpe_mm": {"input": round(mp_in * 1e3, 3), "optimised": round(mp_opt * 1e3, 3)},
             "post": post,
+            "lift": lift,
             "roofline": roof,
             "cpu_baseline": cpu,
             "other_precisions": other_modes or None,

@@ -60,6 +60,7 @@ SIGNATURES = {
                                        C.POINTER(GemEnergyWeights), C.POINTER(GemLbfgsOpts), _P, _P, _P, _P]),
     "gem_merge_windows": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "gem_calculate_errors": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.POINTER(C.c_double), _P, _P]),
+    "gem_lift_skeleton": (C.c_int, [_P, _P, _P, C.c_int, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "gem_profile_enable": (C.c_int, [_P, C.c_int]),
     "gem_profile_read": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
 }

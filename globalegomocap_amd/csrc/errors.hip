@@ -380,4 +380,170 @@ int launch_merge(const double* win, double* tmp, double* out, int n_chunks, int 
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Input lifting: network outputs -> estimated_local_skeleton.
+//
+// Reference: Skeleton.set_skeleton_from_file / set_skeleton / get_max_preds (utils/skeleton.py:74-90,32-45,176-204)
+// and FishEyeCameraCalibrated.camera2world (utils/fisheye/FishEyeCalibrated.py:18-33).  The reference blows the
+// 64x64 heat-map up to 1024x1024 with cv2.INTER_NEAREST, pads 128 zero columns left and right, and takes the
+// row-major argmax of the 1280-wide image.  Every source texel becomes a constant 16x16 block, so the first
+// maximum of the big image is the top-left pixel of the block of the first row-major maximum of the 64x64 map:
+// (x, y) = (16 sx + 128, 16 sy); a non-positive maximum gives (0, 0) (the `maxvals > 0` mask, and the zero
+// padding wins the argmax at index 0 anyway).  The 1.3 M-pixel intermediate is never built.
+//
+// HBM-bound: one pass over the heat-maps in their pickle layout [F,H,W,J] (245 KB per frame for 0.4 KB out).
+// One 256-thread workgroup per frame; thread (g = tid>>4, j = tid&15) scans pixels g, g+16, ... of joint j: a
+// wavefront's load covers 4 pixels x 15 joints = 240 contiguous bytes.
+struct LiftArgs {
+    const float* heat;
+    const double* depth;
+    double* out64;
+    float* out32;
+    int F, H, W, J, up, pad_x, pad_y, n_poly;
+    double poly[GEM_MAX_POLY];     // polynomialC2W, ascending powers
+    double cx, cy;
+};
+
+__device__ inline bool lift_better(float v, int i, float b, int bi) {
+    // numpy argmax: NaN is maximal, first occurrence wins
+    const bool vn = v != v, bn = b != b;
+    if (vn || bn) return vn && (!bn || i < bi);
+    return v > b || (v == b && i < bi);
+}
+
+__global__ __launch_bounds__(256) void lift_skeleton_kernel(LiftArgs a) {
+    __shared__ float s_val[16][16];
+    __shared__ int s_idx[16][16];
+    const int f = blockIdx.x, tid = threadIdx.x, g = tid >> 4, j = tid & 15;
+    const int P = a.H * a.W, J = a.J;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    if (j < J) {
+        const float* base = a.heat + (size_t)f * P * J + j;
+#pragma unroll 8
+        for (int p = g; p < P; p += 16) {
+            const float v = base[(size_t)p * J];
+            if (lift_better(v, p, best, bi)) { best = v; bi = p; }
+        }
+    }
+    s_val[g][j] = best;
+    s_idx[g][j] = bi;
+    __syncthreads();
+    if (tid < J) {
+        float b = s_val[0][tid];
+        int i = s_idx[0][tid];
+        for (int k = 1; k < 16; ++k)
+            if (lift_better(s_val[k][tid], s_idx[k][tid], b, i)) { b = s_val[k][tid]; i = s_idx[k][tid]; }
+        double X = 0.0, Y = 0.0;
+        if (b > 0.f) {                                   // NaN > 0 is false: masked like the reference
+            X = (double)((i % a.W) * a.up + a.pad_x);
+            Y = (double)((i / a.W) * a.up + a.pad_y);
+        }
+        const double x = X - a.cx, y = Y - a.cy;
+        const double r = sqrt(x * x + y * y);
+        double z = a.poly[a.n_poly - 1];                 // np.polyval(p[::-1], r): Horner from the highest power
+        for (int k = a.n_poly - 2; k >= 0; --k) z = z * r + a.poly[k];
+        const double v[3] = {x, y, -z};
+        const double n = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        const double d = a.depth[(size_t)f * J + tid];
+        for (int c = 0; c < 3; ++c) {
+            const double o = v[c] / n * d;
+            if (a.out64) a.out64[((size_t)f * J + tid) * 3 + c] = o;
+            if (a.out32) a.out32[((size_t)f * J + tid) * 3 + c] = (float)o;
+        }
+    }
+}
+
+// Streaming variant (used when a frame is a whole number of float4): A = the largest thread count <= 256 with
+// 4A a multiple of J, so that a thread's four lanes of every 16-byte load always hold the same four joints
+// ((4t + c) mod J, the stride 4A being a multiple of J) and the running maxima stay in registers.  A wavefront's
+// load is 1 KB contiguous.  The 4A candidates are then combined per joint by 16 lanes each.
+typedef float lift_f4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void lift_skeleton_stream_kernel(LiftArgs a, int A) {
+    __shared__ float c_val[16 * 80];
+    __shared__ int c_idx[16 * 80];
+    const int f = blockIdx.x, tid = threadIdx.x, J = a.J;
+    const int n4 = a.H * a.W * J / 4, n_slots = 4 * A / J;
+    const lift_f4* base = reinterpret_cast<const lift_f4*>(a.heat + (size_t)f * a.H * a.W * J);
+    if (tid < A) {
+        float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int bi[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+#pragma unroll 8
+        for (int q = tid; q < n4; q += A) {
+            const lift_f4 v = __builtin_nontemporal_load(base + q);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                // ascending scan: a strict improvement (or the first NaN) takes over; the pixel index (a division by
+                // the runtime J) is only worked out then
+                if (v[c] > best[c] || (v[c] != v[c] && best[c] == best[c])) { best[c] = v[c]; bi[c] = (4 * q + c) / J; }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int e = 4 * tid + c, j = e % J, slot = e / J;
+            c_val[j * 80 + slot] = best[c];
+            c_idx[j * 80 + slot] = bi[c];
+        }
+    }
+    __syncthreads();
+    const int j = tid >> 4, part = tid & 15;
+    float b = -INFINITY;
+    int i = 0x7fffffff;
+    if (j < J)
+        for (int sl = part; sl < n_slots; sl += 16)
+            if (lift_better(c_val[j * 80 + sl], c_idx[j * 80 + sl], b, i)) { b = c_val[j * 80 + sl]; i = c_idx[j * 80 + sl]; }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(b, o, 16);
+        const int oi = __shfl_xor(i, o, 16);
+        if (lift_better(ob, oi, b, i)) { b = ob; i = oi; }
+    }
+    if (j < J && part == 0) {
+        double X = 0.0, Y = 0.0;
+        if (b > 0.f) {
+            X = (double)((i % a.W) * a.up + a.pad_x);
+            Y = (double)((i / a.W) * a.up + a.pad_y);
+        }
+        const double x = X - a.cx, y = Y - a.cy;
+        const double r = sqrt(x * x + y * y);
+        double z = a.poly[a.n_poly - 1];
+        for (int k = a.n_poly - 2; k >= 0; --k) z = z * r + a.poly[k];
+        const double v[3] = {x, y, -z};
+        const double n = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        const double d = a.depth[(size_t)f * J + j];
+        for (int c = 0; c < 3; ++c) {
+            const double o = v[c] / n * d;
+            if (a.out64) a.out64[((size_t)f * J + j) * 3 + c] = o;
+            if (a.out32) a.out32[((size_t)f * J + j) * 3 + c] = (float)o;
+        }
+    }
+}
+
+int launch_lift(gem_handle* h, const float* heat, const double* depth, int F, const double* poly, int n_poly, int up, int pad_x,
+                int pad_y, double* out64, float* out32, hipStream_t s) {
+    LiftArgs a;
+    a.heat = heat; a.depth = depth; a.out64 = out64; a.out32 = out32;
+    a.F = F; a.H = h->cfg.heat_h; a.W = h->cfg.heat_w; a.J = h->J; a.up = up; a.pad_x = pad_x; a.pad_y = pad_y; a.n_poly = n_poly;
+    for (int i = 0; i < GEM_MAX_POLY; ++i) a.poly[i] = i < n_poly ? poly[i] : 0.0;
+    a.cx = h->cfg.cx; a.cy = h->cfg.cy;
+    Profile::Rec rec;
+    const bool prof = h->prof.on;
+    if (prof) {
+        GEM_HIP(hipEventCreate(&rec.a)); GEM_HIP(hipEventCreate(&rec.b));
+        rec.family = 3; rec.flops = (double)F * a.H * a.W * a.J * sizeof(float);      // algorithmic bytes of this launch
+        GEM_HIP(hipEventRecord(rec.a, s));
+    }
+    const int Jr = a.J / (a.J % 4 == 0 ? 4 : a.J % 2 == 0 ? 2 : 1);      // J / gcd(J, 4)
+    const int A = 256 / Jr * Jr;
+    static const bool simple = getenv("GEM_LIFT_SIMPLE") != nullptr;
+    if (!simple && (a.H * a.W * a.J) % 4 == 0 && 4 * A / a.J <= 80 && (reinterpret_cast<uintptr_t>(heat) & 15) == 0)
+        hipLaunchKernelGGL(lift_skeleton_stream_kernel, dim3(F), dim3(256), 0, s, a, A);
+    else
+        hipLaunchKernelGGL(lift_skeleton_kernel, dim3(F), dim3(256), 0, s, a);
+    GEM_HIP(hipGetLastError());
+    if (prof) { GEM_HIP(hipEventRecord(rec.b, s)); h->prof.recs.push_back(rec); }
+    return 0;
+}
+
 }  // namespace gem

@@ -588,6 +588,19 @@ int gem_calculate_errors(gem_handle* h, const double* d_est, const double* d_mid
     return launch_errors(h, d_est, d_mid, d_opt, d_gt, n_frames, h_bone_mm, h->post_work, d_out, (hipStream_t)stream);
 }
 
+int gem_lift_skeleton(gem_handle* h, const float* d_heat, const double* d_depth, int n_frames, const double* h_poly_c2w,
+                      int n_poly_c2w, int upscale, int pad_x, int pad_y, double* d_out64, float* d_out32, void* stream) {
+    if (!h) { set_error("gem_lift_skeleton: null handle"); return 1; }
+    if (n_frames < 0 || n_poly_c2w < 1 || n_poly_c2w > GEM_MAX_POLY || upscale < 1 || pad_x < 0 || pad_y < 0) {
+        set_error("gem_lift_skeleton: need n_frames >= 0, 1 <= n_poly_c2w <= 16, upscale >= 1, pads >= 0"); return 1;
+    }
+    if (n_frames == 0) return 0;
+    if (!d_heat || !d_depth || !h_poly_c2w || (!d_out64 && !d_out32)) { set_error("gem_lift_skeleton: null argument"); return 1; }
+    GEM_HIP(hipSetDevice(h->cfg.device));
+    return launch_lift(h, d_heat, d_depth, n_frames, h_poly_c2w, n_poly_c2w, upscale, pad_x, pad_y, d_out64, d_out32,
+                       (hipStream_t)stream);
+}
+
 int gem_profile_enable(gem_handle* h, int on) {
     if (!h) { set_error("gem_profile_enable: null handle"); return 1; }
     h->prof.on = on != 0;
@@ -595,7 +608,7 @@ int gem_profile_enable(gem_handle* h, int on) {
 }
 
 int gem_profile_read(gem_handle* h, int family, double* total_ms, int64_t* n_launches, double* flops) {
-    if (!h || family < 0 || family > 2) { set_error("gem_profile_read: bad argument"); return 1; }
+    if (!h || family < 0 || family > 3) { set_error("gem_profile_read: bad argument"); return 1; }
     GEM_HIP(hipSetDevice(h->cfg.device));
     Profile& p = h->prof;
     // fold finished event pairs into the totals (caller has synchronised the stream)

@@ -97,9 +97,9 @@ struct Profile {
     bool on = false;
     struct Rec { hipEvent_t a, b; int family; double flops; long log_idx = -1; double flops_per_window = 0; };
     std::vector<Rec> recs;
-    double total_ms[3] = {0, 0, 0};
-    int64_t n[3] = {0, 0, 0};
-    double flops[3] = {0, 0, 0};
+    double total_ms[4] = {0, 0, 0, 0};
+    int64_t n[4] = {0, 0, 0, 0};
+    double flops[4] = {0, 0, 0, 0};      // family 3 (input lifting) counts algorithmic BYTES here
 };
 
 // Wavefront reductions on the DPP cross-lane path (no LDS traffic): quad swaps, half-row and row mirrors
@@ -237,6 +237,8 @@ int launch_errors(gem_handle* h, const double* est, const double* mid, const dou
 int launch_merge(const double* win, double* tmp, double* out, int n_chunks, int wpc, int T, int JC, int overlap, int smooth,
                  hipStream_t s);
 size_t errors_frame_lds_bytes(int J);
+int launch_lift(gem_handle* h, const float* heat, const double* depth, int F, const double* poly, int n_poly, int up, int pad_x,
+                int pad_y, double* out64, float* out32, hipStream_t s);
 
 int launch_lbfgs_init(gem_handle* h, int B, const gem_lbfgs_opts& o, hipStream_t s);
 int launch_lbfgs_advance(gem_handle* h, int B, const gem_lbfgs_opts& o, hipStream_t s);

@@ -216,6 +216,22 @@ class WindowEngine:
         r["joints_error"] = v[17:].copy()
         return r
 
+    # ------------------------------------------------------------------ input lifting
+    def lift_skeleton(self, heat, depth, upscale=16, pad_x=128, pad_y=0, want_f64=True):
+        """heat [F,H,W,15] f32 + depth [F,15] -> estimated_local_skeleton [F,15,3] (f64 like the reference's pickle,
+        and f32 for optimize_windows): heat-map argmax + fisheye un-projection (utils/skeleton.py:32-45,176-204)."""
+        heat_t = self._f32(heat)
+        if heat_t.dim() != 4 or tuple(heat_t.shape[1:]) != (self.heat_size[0], self.heat_size[1], N_JOINTS):
+            raise ValueError("lift_skeleton wants heat-maps [F,%d,%d,%d]" % (self.heat_size[0], self.heat_size[1], N_JOINTS))
+        F = heat_t.shape[0]
+        dep = self._f64(depth).reshape(F, N_JOINTS)
+        poly = np.ascontiguousarray(self.camera.poly_c2w, dtype=np.float64)
+        o64 = torch.empty(F, N_JOINTS, 3, device=self.device, dtype=torch.float64) if want_f64 else None
+        o32 = torch.empty(F, N_JOINTS, 3, device=self.device, dtype=torch.float32)
+        _capi.check(self.lib.gem_lift_skeleton(self._h, _ptr(heat_t), _ptr(dep), F, poly.ctypes.data_as(C.POINTER(C.c_double)),
+                                               len(poly), upscale, pad_x, pad_y, _ptr(o64), _ptr(o32), _stream()), self.lib)
+        return o64, o32
+
     # ------------------------------------------------------------------ profiling hook (bench.py)
     def profile_enable(self, on):
         _capi.check(self.lib.gem_profile_enable(self._h, 1 if on else 0), self.lib)

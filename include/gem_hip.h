@@ -167,9 +167,23 @@ int gem_merge_windows(gem_handle* h, const double* d_windows, int n_chunks, int 
 int gem_calculate_errors(gem_handle* h, const double* d_est, const double* d_mid, const double* d_opt,
                          const double* d_gt, int n_frames, const double* h_bone_mm, double* d_out, void* stream);
 
+/* ---- input lifting: raw network outputs -> estimated_local_skeleton ----
+ * Skeleton.set_skeleton_from_file + set_skeleton + get_max_preds (utils/skeleton.py:74-90,32-45,176-204) followed by
+ * FishEyeCameraCalibrated.camera2world (utils/fisheye/FishEyeCalibrated.py:18-33), without the bone-length resize
+ * (the reference's data preparation passes bone_length_file=None, MakeDataForOptimization/process_test_data.py:59-62).
+ *   d_heat   [n_frames,H,W,J] f32   heat-maps as stored in the .mat files / the pickle
+ *   d_depth  [n_frames,J] f64       predicted joint distances
+ *   h_poly_c2w                      the calibration's polynomialC2W (ascending powers)
+ *   upscale, pad_x, pad_y           16, 128, 0: cv2.resize(64 -> 1024, INTER_NEAREST) + np.pad 128 columns each side
+ * Outputs (either may be NULL): d_out64 [n_frames,J,3] f64 (what the reference pickles), d_out32 the same as f32
+ * (what gem_optimize_windows consumes).  Family 3 of the profiling hook times this kernel (bytes instead of flops). */
+int gem_lift_skeleton(gem_handle* h, const float* d_heat, const double* d_depth, int n_frames, const double* h_poly_c2w,
+                      int n_poly_c2w, int upscale, int pad_x, int pad_y, double* d_out64, float* d_out32, void* stream);
+
 /* Timing hook for bench.py's roofline: average device time (ms) of the launches of the dominant
  * kernel family since the last reset, measured with HIP events on the launch stream.
- * family: 0 = decoder GEMMs (forward + backward-data), 1 = energy kernel, 2 = L-BFGS advance.
+ * family: 0 = decoder_input GEMMs (forward + backward-data), 1 = fused tail / energy kernel, 2 = L-BFGS advance,
+ *         3 = input lifting (`flops` then returns algorithmic bytes).
  * `gem_profile_enable(h, 1)` turns event recording on (off by default: events cost launches). */
 int gem_profile_enable(gem_handle* h, int on);
 int gem_profile_read(gem_handle* h, int family, double* total_ms, int64_t* n_launches, double* flops);

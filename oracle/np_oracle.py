@@ -21,6 +21,8 @@ Reference map (all paths relative to the reference tree):
   optimize_stage                    optimizer.py:242-276
   relative_global / to_global       utils/utils.py:62-66,99-112; optimizer.py:302-308
   optimize_sequence                 optimizer.py:311-450 (window loop, merge_batches, final smooth)
+  lift_skeleton                     utils/skeleton.py:32-45,74-90,176-204; utils/fisheye/FishEyeCalibrated.py:18-33
+                                    (pinned by oracle/make_golden_lift.py -> tests/golden/lift.npz)
 """
 from dataclasses import dataclass, field
 
@@ -611,3 +613,30 @@ def optimize_sequence(data, vae_local, vae_global, cam, eps, w_local=LOCAL_W, w_
         out["opt"] = gaussian_filter1d(out["opt"], sigma=1, axis=0)
     out["stats"] = stats
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# Input lifting: heat-maps + depths -> estimated_local_skeleton (literal restatement, big image and all)
+def lift_skeleton(heat_hwj, depth, poly_c2w, cx, cy, size=1024, pad=128):
+    """heat_hwj [H,W,J] (H == W), depth [J] -> [J,3] float64.
+
+    set_skeleton_from_file (utils/skeleton.py:74-90): cv2.resize(heatmap, (size, size), INTER_NEAREST) -- for an
+    integer ratio that is a plain repeat of every texel -- then np.pad(128) on the width, transpose to [J,H,W];
+    get_max_preds (:176-204): row-major argmax, (x, y) = (idx % width, idx // width), zeroed where max <= 0;
+    camera2world (FishEyeCalibrated.py:18-33): ray (x - cx, y - cy, -polyval(C2W, r)) normalised, times depth."""
+    heat = np.asarray(heat_hwj)
+    H, W, J = heat.shape
+    assert H == W and size % H == 0
+    big = np.repeat(np.repeat(heat, size // H, axis=0), size // W, axis=1)
+    big = np.pad(big, ((0, 0), (pad, pad), (0, 0)), "constant", constant_values=0).transpose(2, 0, 1)
+    width = big.shape[2]
+    flat = big.reshape(J, -1)
+    idx = np.argmax(flat, axis=1)
+    maxv = np.amax(flat, axis=1)
+    preds = np.stack([idx % width, np.floor(idx / width)], axis=1).astype(np.float32)
+    preds *= np.greater(maxv, 0.0).astype(np.float32)[:, None]
+    pc = preds.astype(np.float64) - np.array([cx, cy])
+    x, y = pc[:, 0], pc[:, 1]
+    z = np.polyval(np.asarray(poly_c2w, dtype=np.float64)[::-1], np.sqrt(x * x + y * y))
+    p3 = np.array([x, y, -z])
+    return (p3 / np.linalg.norm(p3, axis=0) * np.asarray(depth, dtype=np.float64)).T

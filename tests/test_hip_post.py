@@ -126,3 +126,47 @@ def test_main_with_device_metrics_matches_host_metrics(golden, tmp_path, smooth)
         np.testing.assert_allclose(dev[0][k], host[0][k], rtol=1e-9, atol=1e-12, err_msg=k)
     tag = "smooth" if smooth else "raw"
     assert abs(dev[0]["optimized_global_mpjpe"] - float(g["err_%s/optimized_global_mpjpe" % tag])) < 0.5e-3
+
+
+# ------------------------------------------------------------------------------------------------ input lifting (8f.2)
+@pytest.mark.parametrize("tag", ["default", "alt"])
+def test_input_lifting_against_reference_golden(golden, tag):
+    from globalegomocap_amd.camera import ALT_CALIBRATION
+    from globalegomocap_amd.engine import WindowEngine
+    g = golden("lift")
+    cam = FisheyeCamera.from_json(DEFAULT_CALIBRATION if tag == "default" else ALT_CALIBRATION)
+    eng = WindowEngine(TINY, cam, max_windows=4)
+    o64, o32 = eng.lift_skeleton(g["heat"].astype(np.float32), g["depth"])
+    ref = g["skeleton_" + tag]
+    np.testing.assert_allclose(o64.cpu().numpy(), ref, rtol=1e-12, atol=1e-14)
+    assert np.array_equal(o32.cpu().numpy(), ref.astype(np.float32)) or \
+        np.max(np.abs(o32.cpu().numpy() - ref.astype(np.float32))) < 1e-6
+
+
+def test_input_lifting_against_oracle_random_and_nan(engine):
+    from oracle import np_oracle as O
+    rng = np.random.default_rng(5)
+    F = 12
+    heat = rng.normal(0.2, 1.0, (F, 64, 64, 15)).astype(np.float32)
+    heat[0, 5, 6, 2] = np.nan               # numpy's argmax lets NaN win, the `max > 0` mask then zeroes the prediction
+    heat[1] = np.round(heat[1])             # many ties
+    depth = rng.uniform(0.2, 2.0, (F, 15))
+    o64, o32 = engine.lift_skeleton(heat, depth)
+    cam = engine.camera
+    ref = np.stack([O.lift_skeleton(heat[f], depth[f], cam.poly_c2w, cam.cx, cam.cy) for f in range(F)])
+    np.testing.assert_allclose(o64.cpu().numpy(), ref, rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(o32.cpu().numpy(), ref, rtol=1e-6, atol=1e-7)
+
+
+def test_input_lifting_feeds_the_window_optimiser_shapes_and_errors(engine):
+    from globalegomocap_amd._capi import GemError
+    with pytest.raises(ValueError):
+        engine.lift_skeleton(np.zeros((2, 32, 64, 15), np.float32), np.ones((2, 15)))
+    o64, o32 = engine.lift_skeleton(np.zeros((0, 64, 64, 15), np.float32), np.ones((0, 15)))
+    assert o64.shape == (0, 15, 3) and o32.shape == (0, 15, 3)
+    heat = np.random.default_rng(0).uniform(0, 1, (3, 64, 64, 15)).astype(np.float32)
+    _, a = engine.lift_skeleton(heat, np.ones((3, 15)), want_f64=False)
+    assert a.dtype.is_floating_point and tuple(a.shape) == (3, 15, 3)
+    assert np.allclose(np.linalg.norm(a.cpu().numpy(), axis=-1), 1.0, atol=1e-6)      # unit depth -> unit rays
+    with pytest.raises(GemError):
+        engine.lift_skeleton(heat, np.ones((3, 15)), upscale=0)

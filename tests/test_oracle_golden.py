@@ -191,3 +191,16 @@ def test_torch_port_cpu_baseline_matches_reference(golden):
         np.testing.assert_allclose(got[:4], ref[:4], rtol=1e-4, atol=1e-8)
         np.testing.assert_allclose(got[:8], ref[:8], rtol=5e-3, atol=1e-7)
         assert np.linalg.norm(out - g[tag + "_out"], axis=-1).mean() < 0.5e-3
+
+
+def test_input_lifting_matches_reference_set_skeleton(golden):
+    """heat-map argmax on the 1280x1024 blow-up + camera2world (utils/skeleton.py:32-45) for both calibrations,
+    incl. empty / all-negative / constant maps, first and last texel, ties."""
+    from globalegomocap_amd.camera import FisheyeCamera
+    g = golden("lift")
+    heat, depth = g["heat"].astype(np.float32), g["depth"]
+    for tag, path in (("default", DEFAULT_CALIBRATION), ("alt", ALT_CALIBRATION)):
+        c = FisheyeCamera.from_json(path)
+        for f in range(heat.shape[0]):
+            got = O.lift_skeleton(heat[f], depth[f], c.poly_c2w, c.cx, c.cy)
+            np.testing.assert_allclose(got, g["skeleton_" + tag][f], rtol=1e-13, atol=1e-15)
