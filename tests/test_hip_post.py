@@ -170,3 +170,40 @@ def test_input_lifting_feeds_the_window_optimiser_shapes_and_errors(engine):
     assert np.allclose(np.linalg.norm(a.cpu().numpy(), axis=-1), 1.0, atol=1e-6)      # unit depth -> unit rays
     with pytest.raises(GemError):
         engine.lift_skeleton(heat, np.ones((3, 15)), upscale=0)
+
+
+# ------------------------------------------------------------------------------------------------ whole-sequence driver
+def test_whole_sequence_driver_matches_per_chunk_main(golden, tmp_path, capsys):
+    """All chunk directories in one batched call vs the reference's loop of main() per chunk (same noise order)."""
+    import pickle
+    import torch
+    from globalegomocap_amd import optimizer as gopt, whole_sequence as ws
+    from helpers import sd_from_npz
+    lt = golden("lbfgs_tiny")
+    sd_g, sd_l = sd_from_npz(lt, "global/"), sd_from_npz(lt, "local/")
+    for i, n in ((1, 100), (2, 100), (10, 60)):
+        d = tmp_path / ("seq_%d" % i)
+        d.mkdir()
+        data = synth.make_sequence(n_frames=n, seed=40 + i)
+        with open(d / "test_data.pkl", "wb") as f:
+            pickle.dump({k: data[k] for k in ("estimated_local_skeleton", "gt_global_skeleton", "camera_pose_list", "heatmap_list")}, f)
+    kw = dict(global_vae_path=sd_g, local_vae_path=sd_l)
+    torch.manual_seed(77)
+    per_chunk = [gopt.main(p, DEFAULT_CALIBRATION, 0.0, 0.0, 0.001, 0.01, 0.01, 0.01, final_smooth=True, **kw)
+                 for p in ws.list_chunks(str(tmp_path))]
+    torch.manual_seed(77)
+    summary, results, est, opt, gt = ws.optimize_directory(str(tmp_path), DEFAULT_CALIBRATION, **kw)
+    out = capsys.readouterr().out
+    assert out.count("running data:") == 3 and "Average optimized global pose mpjpe" in out and "joints error is" in out
+    assert len(results) == 3 and len(opt) == 98 + 98 + 58 == len(est) == len(gt)
+    ref_opt = np.concatenate([np.asarray(r[3]) for r in per_chunk])
+    assert np.linalg.norm(np.asarray(opt) - ref_opt, axis=-1).mean() < 0.5e-3
+    for k in results[0]:
+        ref = np.mean([r[0][k] for r in per_chunk], axis=0)
+        tol = 1e-9 if k.startswith("original") or k in ("aligned_original_mpjpe", "bone_length_aligned_original_mpjpe") else 0.5e-3
+        np.testing.assert_allclose(summary[k], ref, rtol=0, atol=tol, err_msg=k)
+    # host-side metrics and split batches give the same report
+    torch.manual_seed(77)
+    s2 = ws.optimize_directory(str(tmp_path), DEFAULT_CALIBRATION, chunks_per_batch=2, device_metrics=False, verbose=False, **kw)[0]
+    for k in summary:
+        np.testing.assert_allclose(s2[k], summary[k], rtol=0, atol=0.5e-3, err_msg=k)

@@ -134,3 +134,27 @@ def test_full_size_parameter_count_matches_the_reference():
         if "running" not in name:
             n += int(np.prod(shp))
     assert n == 32557677
+
+
+def test_chunk_listing_and_background_reader(tmp_path):
+    import pickle
+    from globalegomocap_amd import whole_sequence as ws
+    assert sorted(["c10", "c2", "c1", "C3x", "c2b"], key=ws.natural_key) == ["c1", "c2", "c2b", "C3x", "c10"]
+    for i, n in ((2, 30), (10, 20), (1, 25)):
+        d = tmp_path / ("chunk_%d" % i)
+        d.mkdir()
+        data = synth.make_sequence(n_frames=n, seed=i)
+        with open(d / "test_data.pkl", "wb") as f:
+            pickle.dump({k: data[k] for k in ("estimated_local_skeleton", "gt_global_skeleton", "camera_pose_list", "heatmap_list")}, f)
+    (tmp_path / "notes.txt").write_text("not a chunk")
+    paths = ws.list_chunks(str(tmp_path))
+    assert [os.path.basename(p) for p in paths] == ["chunk_1", "chunk_2", "chunk_10"]
+    got = list(ws.ChunkStream(paths, depth=1))
+    assert [len(c["est_local"]) for c in got] == [25, 30, 20]
+    assert got[0]["heat"].dtype == np.float32 and got[0]["heat"].shape == (25, 64, 64, 15) and got[0]["cams"].shape == (25, 4, 4)
+    assert [len(b) for b in ws._batches(iter(got), 2)] == [2, 1] and [len(b) for b in ws._batches(iter(got), None)] == [3]
+    (tmp_path / "chunk_3").mkdir()
+    with open(tmp_path / "chunk_3" / "test_data.pkl", "wb") as f:
+        pickle.dump({"estimated_local_skeleton": []}, f)
+    with pytest.raises(KeyError):                      # a broken chunk surfaces in the consumer, like the reference's KeyError
+        list(ws.ChunkStream(ws.list_chunks(str(tmp_path))))
