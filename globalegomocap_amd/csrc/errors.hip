@@ -98,8 +98,8 @@ __device__ inline void umeyama_moments(const double* mp, const double* mq, const
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Per-frame metrics: one thread per frame, its three J x 3 working sets live in LDS columns ([item][thread],
-// conflict-free).  Output row layout (11 + J doubles per frame, stored [col][frame]):
+// Per-frame metrics: six threads per frame (one per source and variant), each with its three J x 3 working sets
+// in LDS columns ([item][thread], conflict-free).  Output row layout (11 + J doubles per frame, stored [col][frame]):
 //   0-2   sum_j |src - gt|            src = est, mid, opt
 //   3-4   |hip midpoint src - gt|      src = est, opt
 //   5-7   sum_j |procrustes(src) - gt|
@@ -156,16 +156,21 @@ __device__ inline void resize_skeleton(double* X, double* W, const ErrArgs& a, i
 
 __global__ __launch_bounds__(ERR_FT) void errors_frame_kernel(ErrArgs a) {
     extern __shared__ double lds_d[];
-    const int tx = threadIdx.x, f = blockIdx.x * ERR_FT + tx, J = a.J;
+    // six independent tasks per frame: (source s = est / mid / opt) x (plain + Procrustes | bone-length normalised)
+    const int tx = threadIdx.x, J = a.J;
+    const long task = (long)blockIdx.x * ERR_FT + tx;
+    const int f = (int)(task / 6), k = (int)(task % 6), s = k % 3;
     double* G = lds_d;
     double* C = G + J * 3 * ERR_FT;
     double* W = C + J * 3 * ERR_FT;
     if (f >= a.F) return;                    // (no barriers in this kernel: every thread works on its own columns)
     const size_t base = (size_t)f * J * 3;
     auto put = [&](int col, double v) { a.frame_out[(size_t)col * a.F + f] = v; };
-    for (int i = 0; i < J * 3; ++i) G[i * ERR_FT + tx] = a.gt[base + i];
-    for (int s = 0; s < 3; ++s) {
-        for (int i = 0; i < J * 3; ++i) C[i * ERR_FT + tx] = a.src[s][base + i];
+    for (int i = 0; i < J * 3; ++i) {
+        G[i * ERR_FT + tx] = a.gt[base + i];
+        C[i * ERR_FT + tx] = a.src[s][base + i];
+    }
+    if (k < 3) {
         double e = 0.0;
         for (int j = 0; j < J; ++j) {
             double n2 = 0.0;
@@ -181,71 +186,67 @@ __global__ __launch_bounds__(ERR_FT) void errors_frame_kernel(ErrArgs a) {
             }
             put(s == 0 ? 3 : 4, sqrt(n2));
         }
-        Sim3 sim;
-        frame_umeyama(C, G, J, tx, &sim);
-        e = 0.0;
-        for (int j = 0; j < J; ++j) {
-            double p[3] = {LD3(C, j, 0), LD3(C, j, 1), LD3(C, j, 2)}, o[3], n2 = 0.0;
-            apply_sim(sim, p, o);
-            for (int d = 0; d < 3; ++d) { const double x = o[d] - LD3(G, j, d); n2 += x * x; }
-            e += sqrt(n2);
-        }
-        put(5 + s, e);
-    }
-    for (int s = 0; s < 3; ++s) {
-        resize_skeleton(G, W, a, tx);        // gt is re-normalised once more per call, as the reference does
-        for (int i = 0; i < J * 3; ++i) C[i * ERR_FT + tx] = a.src[s][base + i];
+    } else {
+        // the reference re-normalises the (already normalised) gt on every call: s + 1 re-growths for source s
+        for (int r = 0; r <= s; ++r) resize_skeleton(G, W, a, tx);
         resize_skeleton(C, W, a, tx);
-        Sim3 sim;
-        frame_umeyama(C, G, J, tx, &sim);
-        double e = 0.0;
-        for (int j = 0; j < J; ++j) {
-            double p[3] = {LD3(C, j, 0), LD3(C, j, 1), LD3(C, j, 2)}, o[3], n2 = 0.0;
-            apply_sim(sim, p, o);
-            for (int d = 0; d < 3; ++d) { const double x = o[d] - LD3(G, j, d); n2 += x * x; }
-            const double en = sqrt(n2);
-            e += en;
-            if (s == 2) put(11 + j, en);
-        }
-        put(8 + s, e);
     }
+    Sim3 sim;
+    frame_umeyama(C, G, J, tx, &sim);
+    double e = 0.0;
+    for (int j = 0; j < J; ++j) {
+        double p[3] = {LD3(C, j, 0), LD3(C, j, 1), LD3(C, j, 2)}, o[3], n2 = 0.0;
+        apply_sim(sim, p, o);
+        for (int d = 0; d < 3; ++d) { const double x = o[d] - LD3(G, j, d); n2 += x * x; }
+        const double en = sqrt(n2);
+        e += en;
+        if (k == 5) put(11 + j, en);
+    }
+    put(k < 3 ? 5 + s : 8 + s, e);
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Sequence-level part: ONE workgroup.  Three similarity alignments over all F*J points (means, centred
-// moments, SVD by thread 0, aligned errors) and the column sums of the per-frame table.
+// Sequence-level part: three workgroups, one per source sequence (est, mid, opt).  Each does its similarity
+// alignment over all F*J points (means, centred moments, SVD by thread 0, aligned errors) with ONE barrier per
+// group of sums, and a third of the column sums of the per-frame table.
 constexpr int ERR_ST = 1024;
+constexpr int ERR_NW = ERR_ST / 64;
 
-struct SeqRed {
-    double* lds;       // [2][16]
-    int parity;
-    __device__ inline double sum(double v) {          // all threads get the total; one barrier per call
-        v = wave_sum_dpp(v);
-        double* r = lds + 16 * parity;
-        parity ^= 1;
-        if ((threadIdx.x & 63) == 0) r[threadIdx.x >> 6] = v;
-        __syncthreads();
-        double t = 0.0;
-        for (int i = 0; i < ERR_ST / 64; ++i) t += r[i];
-        return t;
+// K sums at once: wavefront DPP reductions, [K][16] partials in LDS, every thread adds the 16 partials of each value
+// in the same order.  Alternating LDS halves: one barrier per call is enough (see lbfgs.hip's BlockRed).
+template <int K>
+__device__ inline void block_sums(double (&v)[K], double* lds, int& parity) {
+    double* r = lds + parity * (16 * ERR_NW);
+    parity ^= 1;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const double w = wave_sum_dpp(v[k]);
+        if ((threadIdx.x & 63) == 0) r[k * ERR_NW + (threadIdx.x >> 6)] = w;
     }
-};
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        double t = 0.0;
+        for (int i = 0; i < ERR_NW; ++i) t += r[k * ERR_NW + i];
+        v[k] = t;
+    }
+}
 
 __global__ __launch_bounds__(ERR_ST) void errors_sequence_kernel(ErrArgs a) {
-    __shared__ double red[32];
+    __shared__ double red[2 * 16 * ERR_NW];
     __shared__ Sim3 sim_s;
-    SeqRed R{red, 0};
-    const int tid = threadIdx.x, J = a.J, F = a.F;
+    int parity = 0;
+    const int tid = threadIdx.x, J = a.J, F = a.F, s = blockIdx.x;
     const size_t N = (size_t)F * J;
     double* out = a.out;
-    for (int s = 0; s < 3; ++s) {
+    {
         const double* P = a.src[s];
         const double* Q = a.gt;
-        double acc[6] = {0, 0, 0, 0, 0, 0};
+        double m[6] = {0, 0, 0, 0, 0, 0};
         for (size_t i = tid; i < N; i += ERR_ST)
-            for (int d = 0; d < 3; ++d) { acc[d] += P[i * 3 + d]; acc[3 + d] += Q[i * 3 + d]; }
-        double m[6];
-        for (int k = 0; k < 6; ++k) m[k] = R.sum(acc[k]) / (double)N;
+            for (int d = 0; d < 3; ++d) { m[d] += P[i * 3 + d]; m[3 + d] += Q[i * 3 + d]; }
+        block_sums<6>(m, red, parity);
+        for (int k = 0; k < 6; ++k) m[k] /= (double)N;
         double c[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         for (size_t i = tid; i < N; i += ERR_ST) {
             double p[3], q[3];
@@ -255,17 +256,17 @@ __global__ __launch_bounds__(ERR_ST) void errors_sequence_kernel(ErrArgs a) {
                 for (int y = 0; y < 3; ++y) c[3 * x + y] += p[x] * q[y];
             }
         }
-        double cov[10];
-        for (int k = 0; k < 10; ++k) cov[k] = R.sum(c[k]) / (double)N;
-        if (tid == 0) umeyama_moments(m, m + 3, cov, cov[9], &sim_s);
+        block_sums<10>(c, red, parity);
+        for (int k = 0; k < 10; ++k) c[k] /= (double)N;
+        if (tid == 0) umeyama_moments(m, m + 3, c, c[9], &sim_s);
         __syncthreads();
         const Sim3 sim = sim_s;
-        double e = 0.0, er = 0.0;
+        double e[2] = {0.0, 0.0};
         for (size_t i = tid; i < N; i += ERR_ST) {
             double p[3] = {P[i * 3], P[i * 3 + 1], P[i * 3 + 2]}, o[3], n2 = 0.0;
             apply_sim(sim, p, o);
             for (int d = 0; d < 3; ++d) { const double x = o[d] - Q[i * 3 + d]; n2 += x * x; }
-            e += sqrt(n2);
+            e[0] += sqrt(n2);
         }
         for (int f = tid; f < F; f += ERR_ST) {
             const double* p7 = P + ((size_t)f * J + 7) * 3;
@@ -276,23 +277,21 @@ __global__ __launch_bounds__(ERR_ST) void errors_sequence_kernel(ErrArgs a) {
             apply_sim(sim, p7, a7);
             apply_sim(sim, p11, a11);
             for (int d = 0; d < 3; ++d) { const double x = (a7[d] + a11[d]) / 2 - (q7[d] + q11[d]) / 2; n2 += x * x; }
-            er += sqrt(n2);
+            e[1] += sqrt(n2);
         }
-        e = R.sum(e);
-        er = R.sum(er);
-        if (tid == 0) { out[8 + s] = e / (double)N; out[5 + s] = er / (double)F; }
-        __syncthreads();
+        block_sums<2>(e, red, parity);
+        if (tid == 0) { out[8 + s] = e[0] / (double)N; out[5 + s] = e[1] / (double)F; }
     }
-    for (int col = 0; col < 11 + J; ++col) {
-        double v = 0.0;
-        for (int f = tid; f < F; f += ERR_ST) v += a.frame_out[(size_t)col * F + f];
-        v = R.sum(v);
+    for (int col = s; col < 11 + J; col += 3) {
+        double v[1] = {0.0};
+        for (int f = tid; f < F; f += ERR_ST) v[0] += a.frame_out[(size_t)col * F + f];
+        block_sums<1>(v, red, parity);
         if (tid == 0) {
-            if (col < 3) out[col] = v / (double)N;                       // *_global_mpjpe
-            else if (col < 5) out[col] = v / (double)F;                   // *_camera_pos_error
-            else if (col < 8) out[11 + (col - 5)] = v / (double)N;        // per-frame Procrustes
-            else if (col < 11) out[14 + (col - 8)] = v / (double)N;       // bone-length normalised
-            else out[17 + (col - 11)] = v / (double)F;                    // joints_error
+            if (col < 3) out[col] = v[0] / (double)N;                       // *_global_mpjpe
+            else if (col < 5) out[col] = v[0] / (double)F;                   // *_camera_pos_error
+            else if (col < 8) out[11 + (col - 5)] = v[0] / (double)N;        // per-frame Procrustes
+            else if (col < 11) out[14 + (col - 8)] = v[0] / (double)N;       // bone-length normalised
+            else out[17 + (col - 11)] = v[0] / (double)F;                    // joints_error
         }
     }
 }
@@ -315,9 +314,9 @@ int launch_errors(gem_handle* h, const double* est, const double* mid, const dou
                                     (int)errors_frame_lds_bytes(MAXJ_ERR)));
         attr_set = true;
     }
-    hipLaunchKernelGGL(errors_frame_kernel, dim3((F + ERR_FT - 1) / ERR_FT), dim3(ERR_FT), lds, s, a);
+    hipLaunchKernelGGL(errors_frame_kernel, dim3((unsigned)(((long)F * 6 + ERR_FT - 1) / ERR_FT)), dim3(ERR_FT), lds, s, a);
     GEM_HIP(hipGetLastError());
-    hipLaunchKernelGGL(errors_sequence_kernel, dim3(1), dim3(ERR_ST), 0, s, a);
+    hipLaunchKernelGGL(errors_sequence_kernel, dim3(3), dim3(ERR_ST), 0, s, a);
     GEM_HIP(hipGetLastError());
     return 0;
 }
