@@ -37,12 +37,24 @@ def all_gather_windows(local, n_windows, group=None):
         raise ValueError("rank %d holds %d windows, its shard is %d" % (rank, local.shape[0], hi - lo))
     # gloo (CPU tests, single-GPU rehearsals) gathers host copies; nccl = RCCL gathers device buffers over xGMI
     dev = local.device
-    stage = torch.device("cpu") if dist.get_backend(group) == "gloo" else dev
-    buf = torch.zeros((cap,) + tuple(local.shape[1:]), dtype=local.dtype, device=stage)
-    buf[: hi - lo] = local
-    out = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(out, buf, group=group)
-    return torch.cat([o[: h - l] for o, (l, h) in zip(out, sizes)], dim=0).to(dev)
+    shape = (cap,) + tuple(local.shape[1:])
+    if dist.get_backend(group) == "gloo":
+        buf = torch.zeros(shape, dtype=local.dtype, device="cpu")
+        buf[: hi - lo] = local
+        out = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(out, buf, group=group)
+        return torch.cat([o[: h - l] for o, (l, h) in zip(out, sizes)], dim=0).to(dev)
+    # one flat receive buffer, one collective; equal shards (the weak-scaling bench) need no copy afterwards
+    if hi - lo == cap:
+        buf = local.contiguous()
+    else:
+        buf = torch.zeros(shape, dtype=local.dtype, device=dev)
+        buf[: hi - lo] = local
+    out = torch.empty((world * cap,) + tuple(local.shape[1:]), dtype=local.dtype, device=dev)
+    dist.all_gather_into_tensor(out, buf, group=group)
+    if all(h - l == cap for l, h in sizes):
+        return out
+    return torch.cat([out[r * cap: r * cap + (h - l)] for r, (l, h) in enumerate(sizes)], dim=0)
 
 
 def optimize_sharded(run_shard, starts, seq_len=10, group=None):
