@@ -160,6 +160,9 @@ __device__ __forceinline__ void lbfgs_advance_body(const AdvArgs& a) {
         return R.max((double)p);
     };
     load(gsrc - off, gn);
+    // d and x are needed on every path but the very first evaluation: fetch them with the gradient instead of one
+    // dependent round trip later
+    if (phase != PH_INIT) { load(a.d, dv); load(a.x, xv); have_d = have_x = true; }
     float* BG[2] = {a.bg0, a.bg1};
 
     bool do_zoom_head = false, do_ls_end = false, do_start_iter = false, finished = false, emit = false;
@@ -175,8 +178,6 @@ __device__ __forceinline__ void lbfgs_advance_body(const AdvArgs& a) {
         if (maxabs(gn, 1.f) <= o.tol_grad) finished = true;
         else do_start_iter = true;
     } else {
-        load(a.d, dv);
-        have_d = true;
         const double gtd_new = dot(gn, dv);
         if (phase == PH_BRACKET) {
             if (!first_bracket) ls_iter++;
@@ -277,9 +278,6 @@ __device__ __forceinline__ void lbfgs_advance_body(const AdvArgs& a) {
         float bl[EPT], gold[EPT];
         load(BG[low], bl);
         load(a.g, gold);
-        if (!have_d) { load(a.d, dv); have_d = true; }
-        load(a.x, xv);
-        have_x = true;
         const float tf = (float)t;
 #pragma unroll
         for (int i = 0; i < EPT; ++i) {
