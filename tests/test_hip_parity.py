@@ -544,3 +544,41 @@ def test_other_window_length_and_camera(torch_cuda):
         ref, so = O.optimize_stage(vae, cam, O.Weights(*w), pose[b], heat[starts[b]:starts[b] + 8], mb, eps[b])
         assert abs(sn["final_loss"][b] - so["loss"]) <= 0.05 * abs(so["loss"]), (b, sn["final_loss"][b], so["loss"])
         assert abs(int(sn["func_evals"][b]) - so["func_evals"]) <= 6
+
+
+def test_two_engines_on_two_streams_do_not_interfere(torch_cuda):
+    """BASELINE configs[2] regime (several sequences in flight on one GPU): two handles, two HIP streams, calls
+    interleaved so that their kernels overlap on the device; each result must be bitwise what the engine produces
+    alone (no shared scratch, no hidden global state in the library)."""
+    import torch
+    from globalegomocap_amd.sequence import window_starts
+    shapes = (FULL, TINY)
+    Bs = (48, 36)
+    engs, args, alone = [], [], []
+    for k, (shape, B) in enumerate(zip(shapes, Bs)):
+        eng = _engine(shape, max_windows=B)
+        eng.load_vae(0, vae_schema.synthetic_state_dict(shape, 20 + k))
+        eng.load_vae(1, vae_schema.synthetic_state_dict(shape, 30 + k))
+        n_chunks = B // 12
+        seq = synth.make_sequence_device(n_chunks * 100, seed=50 + k, device=eng.device)
+        starts = np.concatenate([c * 100 + window_starts(100) for c in range(n_chunks)]).astype(np.int32)
+        f0 = torch.as_tensor(starts, device=eng.device)
+        mb = eng.mean_bone_length(seq["est_local"][:100]).reshape(1, 15).expand(B, 15).contiguous()
+        g = torch.Generator().manual_seed(60 + k)
+        eps = torch.randn(2, B, shape.latent_dim, generator=g).to(eng.device)
+        a = (seq["est_local"], seq["cams"], seq["heat"], f0, mb, eps[0].contiguous(), eps[1].contiguous(),
+             _ew((1e-1, 1e-1, 1.0, 1e-3, 1e-2)), _ew((1e-1, 1e-2, 1.0, 0.0, 0.0)))
+        engs.append(eng); args.append(a)
+        mid, glob, stats = eng.optimize_windows(*a)
+        alone.append((mid.clone(), glob.clone(), stats.clone()))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    got = [[], []]
+    for rep in range(3):
+        for k in (0, 1):
+            with torch.cuda.stream(streams[k]):
+                got[k].append(engs[k].optimize_windows(*args[k]))
+    torch.cuda.synchronize()
+    for k in (0, 1):
+        for mid, glob, stats in got[k]:
+            assert torch.equal(mid, alone[k][0]) and torch.equal(glob, alone[k][1]) and torch.equal(stats, alone[k][2])
