@@ -308,6 +308,8 @@ static int launch_tile(gem_handle* h, const Layer& L, const float* A, int lda, c
     if (force && force[0] == '1') return launch_one<TAPS, EPI, 1, 1, TAG, 32>(h, L, A, lda, aux, C, ldc, M, T, s, row_map);
     if (force && force[0] == '2' && L.N % 128 == 0) return launch_one<TAPS, EPI, 2, 2, TAG, 32>(h, L, A, lda, aux, C, ldc, M, T, s, row_map);
     if (force && force[0] == '3' && L.K % 64 == 0) return launch_one<TAPS, EPI, 1, 1, TAG, 64>(h, L, A, lda, aux, C, ldc, M, T, s, row_map);
+    if (force && force[0] == '4') return launch_one<TAPS, EPI, 2, 1, TAG, 32>(h, L, A, lda, aux, C, ldc, M, T, s, row_map);
+    if (force && force[0] == '5' && L.N % 128 == 0) return launch_one<TAPS, EPI, 1, 2, TAG, 32>(h, L, A, lda, aux, C, ldc, M, T, s, row_map);
     if (L.N % 128 == 0 && big_blocks >= 512) return launch_one<TAPS, EPI, 2, 2, TAG, 32>(h, L, A, lda, aux, C, ldc, M, T, s, row_map);
     return launch_one<TAPS, EPI, 1, 1, TAG, 32>(h, L, A, lda, aux, C, ldc, M, T, s, row_map);
 }
