@@ -118,7 +118,7 @@ class SequenceOptimizer:
         B = len(starts)
         pose_d = torch.as_tensor(np.asarray(est_local), dtype=torch.float32).to(dev).contiguous()
         cams_d = torch.as_tensor(np.asarray(cams), dtype=torch.float64).to(dev).contiguous()
-        heat_d = torch.as_tensor(np.asarray(heat)).to(dev, dtype=torch.float32).contiguous()
+        heat_d = (heat if torch.is_tensor(heat) else torch.as_tensor(np.asarray(heat))).to(dev, dtype=torch.float32).contiguous()
         mb = torch.stack([e.mean_bone_length(pose_d[a:b]) for a, b in chunk_bounds])
         mb_w = mb[torch.as_tensor(np.asarray(chunk_of_window), dtype=torch.long, device=dev)].contiguous()
         if eps is None:

@@ -2,8 +2,8 @@
 
 The reference's `optimize_whole_sequence.py` walks the chunk directories of a sequence (natsorted), calls
 `main()` on each -- 12 windows, one after the other -- and averages the per-chunk error dicts
-(`optimize_whole_sequence.py:48-118`).  Here the chunks are read by a background thread while the previous
-batch is on the device, all their windows go through `SequenceOptimizer.run` together (BASELINE configs[1]: a
+(`optimize_whole_sequence.py:48-118`).  Here the chunks are read by background threads (which also start the
+heat-map uploads), all their windows go through `SequenceOptimizer.run` together (BASELINE configs[1]: a
 2000-frame sequence = 20 chunks = 240 windows per call), and the per-chunk merge / smoothing / error report run
 on the device as well.  Results, keys, printed summary and the order in which the reparameterisation noise is
 drawn (chunk by chunk, window by window, local then global) follow the reference.
@@ -12,9 +12,7 @@ drawn (chunk by chunk, window by window, local then global) follow the reference
 """
 import os
 import pickle
-import queue
 import re
-import threading
 from collections import OrderedDict
 
 import numpy as np
@@ -51,41 +49,64 @@ def list_chunks(data_dir):
     return [os.path.join(data_dir, n) for n in names if os.path.isdir(os.path.join(data_dir, n))]
 
 
-def load_chunk(path):
-    """`<chunk>/test_data.pkl` (optimizer.py:315-324) as dense arrays; KeyError on a missing key like the reference."""
+def load_chunk(path, device=None):
+    """`<chunk>/test_data.pkl` (optimizer.py:315-324) as dense arrays; KeyError on a missing key like the reference.
+    With `device`, the heat-maps (99 % of the bytes) go straight to that device from the calling thread."""
     with open(os.path.join(path, "test_data.pkl"), "rb") as f:
         d = pickle.load(f)
-    return {"path": path,
-            "est_local": np.asarray(d["estimated_local_skeleton"], dtype=np.float64),
-            "gt": np.asarray(d["gt_global_skeleton"], dtype=np.float64),
-            "cams": np.asarray(d["camera_pose_list"], dtype=np.float64),
-            "heat": np.asarray(d["heatmap_list"], dtype=np.float32)}
+    c = {"path": path,
+         "est_local": np.asarray(d["estimated_local_skeleton"], dtype=np.float64),
+         "gt": np.asarray(d["gt_global_skeleton"], dtype=np.float64),
+         "cams": np.asarray(d["camera_pose_list"], dtype=np.float64)}
+    heat = d["heatmap_list"]
+    if device is None:
+        c["heat"] = np.asarray(heat, dtype=np.float32)
+    else:
+        # frame by frame into one pinned staging buffer (no intermediate 25 MB numpy copy), then one async H2D copy on
+        # this thread's own stream; the consumer waits on the event
+        n = len(heat)
+        shape = (n,) + tuple(np.shape(heat[0])) if n else (0, 64, 64, 15)
+        stage = torch.empty(shape, dtype=torch.float32).pin_memory()
+        view = stage.numpy()
+        for i in range(n):
+            view[i] = heat[i]
+        stream = torch.cuda.Stream(device=device)
+        with torch.cuda.stream(stream):
+            c["heat"] = stage.to(device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+        c["heat_ready"], c["_stage"] = ev, stage          # keep the pinned buffer alive until the copy has run
+    return c
 
 
 class ChunkStream:
-    """Reads chunk pickles on a background thread, `depth` chunks ahead of the consumer."""
+    """Reads chunk pickles on `workers` background threads, at most `depth` chunks ahead of the consumer, and yields
+    them in directory order."""
 
-    def __init__(self, paths, depth=4):
-        self._q = queue.Queue(maxsize=max(1, depth))
-        self._t = threading.Thread(target=self._run, args=(list(paths),), daemon=True)
-        self._t.start()
-
-    def _run(self, paths):
-        try:
-            for p in paths:
-                self._q.put(load_chunk(p))
-            self._q.put(None)
-        except BaseException as e:          # surfaced in the consumer
-            self._q.put(e)
+    def __init__(self, paths, depth=8, workers=4, device=None):
+        from concurrent.futures import ThreadPoolExecutor
+        self._paths = list(paths)
+        self._depth = max(1, depth)
+        self._device = device
+        self._pool = ThreadPoolExecutor(max_workers=max(1, workers))
 
     def __iter__(self):
-        while True:
-            item = self._q.get()
-            if item is None:
-                return
-            if isinstance(item, BaseException):
-                raise item
-            yield item
+        pending = []
+        it = iter(self._paths)
+        try:
+            while True:
+                while len(pending) < self._depth:
+                    p = next(it, None)
+                    if p is None:
+                        break
+                    pending.append(self._pool.submit(load_chunk, p, self._device))
+                if not pending:
+                    return
+                yield pending.pop(0).result()          # a reader's exception (e.g. KeyError) surfaces here
+        finally:
+            for f in pending:
+                f.cancel()
+            self._pool.shutdown(wait=True)
 
 
 def _batches(stream, chunks_per_batch):
@@ -111,7 +132,8 @@ def optimize_directory(data_dir, camera_model_path, vae_weight=0.0, gmm_weight=0
         raise FileNotFoundError("no chunk directories under %s" % data_dir)
     opt = optimizer
     results, est_all, opt_all, gt_all = [], [], [], []
-    for batch in _batches(ChunkStream(paths), chunks_per_batch):
+    device = torch.device("cuda", torch.cuda.current_device())
+    for batch in _batches(ChunkStream(paths, device=device), chunks_per_batch):
         starts, chunk_of, bounds, f_off, eps = [], [], [], 0, []
         for ci, c in enumerate(batch):
             if verbose:
@@ -131,8 +153,11 @@ def optimize_directory(data_dir, camera_model_path, vae_weight=0.0, gmm_weight=0
         for c in batch:                          # global torch RNG, in the reference's order (D5)
             eps.append(torch.randn(2 * len(c["starts"]), opt.engine.D))
         w_local, w_global = opt.stage_weights(vae_weight, smoothness_weight, bone_length_weight, weight_3d, reproj_weight)
+        for c in batch:
+            torch.cuda.current_stream().wait_event(c["heat_ready"])
+        heat_d = batch[0]["heat"] if len(batch) == 1 else torch.cat([c["heat"] for c in batch])
         mid_local, opt_global, _ = opt.run(np.concatenate([c["est_local"] for c in batch]), np.concatenate([c["cams"] for c in batch]),
-                                           np.concatenate([c["heat"] for c in batch]), np.concatenate(starts),
+                                           heat_d, np.concatenate(starts),
                                            np.concatenate(chunk_of), bounds, w_local, w_global, eps=torch.cat(eps), keep_device=True)
         mid_np = mid_local.cpu().numpy()
         w0 = 0

@@ -1,0 +1,71 @@
+"""Developer measurement: the host-inclusive rate of the drop-in interface.
+
+Writes a synthetic 2000-frame sequence as 20 chunk directories (the reference's `test_data.pkl` schema), then times
+`whole_sequence.optimize_directory` end to end -- pickle reading, host->device copies of the heat-maps, the batched
+optimisation, device merge / smoothing / error report -- against the device-resident rate `bench.py` reports.
+
+    python tools/whole_sequence_timing.py [weights_cache.pt]
+"""
+import os
+import pickle
+import sys
+import tempfile
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import bench
+from globalegomocap_amd import synth, vae as V, whole_sequence as ws
+from globalegomocap_amd.camera import FisheyeCamera, DEFAULT_CALIBRATION
+from globalegomocap_amd.optimizer import SequenceOptimizer
+
+dev = torch.device("cuda")
+shape = V.VAEShape()
+cam = FisheyeCamera.from_json(DEFAULT_CALIBRATION)
+cache = sys.argv[1] if len(sys.argv) > 1 else None
+if cache and os.path.exists(cache):
+    sd_l, _, sd_g, _ = torch.load(cache, weights_only=False)
+else:
+    sd_l, _ = bench.fit_weights(shape, 101, dev, 2000, False)
+    sd_g, _ = bench.fit_weights(shape, 102, dev, 2000, True)
+
+root = tempfile.mkdtemp(prefix="gem_seq_")
+seq = synth.make_sequence_device(2000, 1000, dev, cam, cam_jitter=bench.CAM_JITTER)
+heat = seq["heat"].cpu().numpy()
+for c in range(20):
+    sl = slice(c * 100, (c + 1) * 100)
+    d = os.path.join(root, "chunk_%d" % c)
+    os.makedirs(d)
+    with open(os.path.join(d, "test_data.pkl"), "wb") as f:
+        pickle.dump({"estimated_local_skeleton": list(seq["est_local_np"][sl]), "gt_global_skeleton": list(seq["gt_global"][sl]),
+                     "camera_pose_list": list(seq["cams_np"][sl]), "heatmap_list": list(heat[sl])}, f, protocol=4)
+size_mb = sum(os.path.getsize(os.path.join(root, d, "test_data.pkl")) for d in os.listdir(root)) / 1e6
+
+opt = SequenceOptimizer(DEFAULT_CALIBRATION, sd_g, sd_l, max_windows=240)
+ws.optimize_directory(root, DEFAULT_CALIBRATION, optimizer=opt, verbose=False)          # warm-up (page cache, clocks)
+torch.cuda.synchronize()
+t_read = time.perf_counter()
+chunks = list(ws.ChunkStream(ws.list_chunks(root)))
+t_read = time.perf_counter() - t_read
+runs = []
+for _ in range(5):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    summary = ws.optimize_directory(root, DEFAULT_CALIBRATION, optimizer=opt, verbose=False)[0]
+    torch.cuda.synchronize()
+    runs.append(time.perf_counter() - t0)
+best = min(runs)
+print("pickles: %.0f MB in 20 chunks; reading them alone: %.1f ms" % (size_mb, t_read * 1e3))
+print("optimize_directory end to end: %.1f ms (best of 5; %s) = %.0f windows/s host-inclusive" %
+      (best * 1e3, ", ".join("%.1f" % (r * 1e3) for r in runs), 240 / best))
+print("optimized_global_mpjpe %.2f mm" % (summary["optimized_global_mpjpe"] * 1e3))
+if os.environ.get("GEM_WS_PROFILE"):
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    ws.optimize_directory(root, DEFAULT_CALIBRATION, optimizer=opt, verbose=False)
+    torch.cuda.synchronize()
+    pr.disable()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
