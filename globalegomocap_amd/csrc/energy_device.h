@@ -12,8 +12,8 @@ constexpr int MAXT = 16;               // frames per window supported by the LDS
 constexpr int MAXJ = GEM_MAX_JOINTS;
 constexpr int ENERGY_SCRATCH = MAXT * MAXJ * 3;     // floats per scratch array
 
-// BLOCK_SYNC: the workgroup is this one wavefront (plain __syncthreads); otherwise several wavefronts of
-// a workgroup each run their own window, and only the wavefront's own LDS traffic has to be ordered.
+// BLOCK_SYNC: the cooperating threads are the whole workgroup (plain __syncthreads); otherwise several wavefronts
+// of a workgroup each run their own window, and only the wavefront's own LDS traffic has to be ordered.
 template <bool BLOCK_SYNC>
 __device__ __forceinline__ void energy_sync() {
     if (BLOCK_SYNC) {
@@ -27,14 +27,18 @@ __device__ __forceinline__ void energy_sync() {
 
 // xsrc: decoded pose rows [T][ldx] (global or LDS); xs/gs/bs/as: LDS scratch of ENERGY_SCRATCH floats each;
 // gdst: gradient rows [T][ldg], columns [J*3, gcols) are zero-filled.
-template <bool BLOCK_SYNC>
+// NT threads work on the window (`lane` = 0..NT-1): 64 = one wavefront; more = the whole workgroup (BLOCK_SYNC), so
+// that the T*J*3 = 450 values are one pass and every global-memory latency (x0, mean bone, heat-map texels) is paid
+// once instead of once per 64-lane pass.
+template <bool BLOCK_SYNC, int NT = 64>
 __device__ __forceinline__ void energy_window(const EnergyArgs& a, int b, int lane, const float* xsrc, int ldx, float* xs,
                                               float* gs, float* bs, float* as, float* gdst, int ldg, int gcols) {
+    static_assert(NT == 64 || BLOCK_SYNC, "more than one wavefront per window needs workgroup barriers");
     const int T = a.T, J = a.J, JC = J * 3, n = T * JC;
     const float* x0 = a.X0 + (size_t)b * n;
 
     double e3d = 0, esm = 0, ebone = 0, evae = 0, erep = 0;
-    for (int e = lane; e < n; e += 64) {
+    for (int e = lane; e < n; e += NT) {
         const int t = e / JC, c = e - t * JC;
         const float x = xsrc[t * ldx + c];
         xs[e] = x;
@@ -45,7 +49,7 @@ __device__ __forceinline__ void energy_window(const EnergyArgs& a, int b, int la
     }
     energy_sync<BLOCK_SYNC>();
     // smoothness: acceleration a_t (t = 1..T-2) then gather
-    for (int e = lane; e < n; e += 64) {
+    for (int e = lane; e < n; e += NT) {
         const int t = e / JC;
         float acc = 0.f;
         if (t >= 1 && t <= T - 2) {
@@ -55,7 +59,7 @@ __device__ __forceinline__ void energy_window(const EnergyArgs& a, int b, int la
         as[e] = acc;
     }
     // bone length: per (t, joint)
-    for (int p = lane; p < T * J; p += 64) {
+    for (int p = lane; p < T * J; p += NT) {
         const int t = p / J, j = p - t * J;
         const int par = a.parents[j];
         const float* xj = xs + (t * J + j) * 3;
@@ -69,7 +73,7 @@ __device__ __forceinline__ void energy_window(const EnergyArgs& a, int b, int la
         o[0] = coef * bx; o[1] = coef * by; o[2] = coef * bz;
     }
     energy_sync<BLOCK_SYNC>();
-    for (int e = lane; e < n; e += 64) {
+    for (int e = lane; e < n; e += NT) {
         const int t = e / JC;
         float g = gs[e];
         const float w2 = 2.f * a.ws;
@@ -79,7 +83,7 @@ __device__ __forceinline__ void energy_window(const EnergyArgs& a, int b, int la
         gs[e] = g;
     }
     energy_sync<BLOCK_SYNC>();
-    for (int p = lane; p < T * J; p += 64) {
+    for (int p = lane; p < T * J; p += NT) {
         const int t = p / J, j = p - t * J;
         float gx = bs[p * 3 + 0], gy = bs[p * 3 + 1], gz = bs[p * 3 + 2];
         const int* ch = a.children + j * MAXJ;
@@ -145,11 +149,23 @@ __device__ __forceinline__ void energy_window(const EnergyArgs& a, int b, int la
     }
     energy_sync<BLOCK_SYNC>();
     // gradient rows, zero-padded
-    for (int i = lane; i < T * gcols; i += 64) {
+    for (int i = lane; i < T * gcols; i += NT) {
         const int t = i / gcols, c = i - t * gcols;
         gdst[t * ldg + c] = c < JC ? gs[t * JC + c] : 0.f;
     }
     e3d = wave_sum(e3d); esm = wave_sum(esm); ebone = wave_sum(ebone); evae = wave_sum(evae); erep = wave_sum(erep);
+    if (NT > 64) {                   // combine the wavefronts' partial sums in wave order (as[] is free by now)
+        double* red = reinterpret_cast<double*>(as);
+        const int wv = lane >> 6;
+        if ((lane & 63) == 0) { red[wv * 5 + 0] = e3d; red[wv * 5 + 1] = esm; red[wv * 5 + 2] = ebone; red[wv * 5 + 3] = evae; red[wv * 5 + 4] = erep; }
+        __syncthreads();
+        if (lane == 0) {
+            e3d = esm = ebone = evae = erep = 0.0;
+            for (int w = 0; w < NT / 64; ++w) {
+                e3d += red[w * 5 + 0]; esm += red[w * 5 + 1]; ebone += red[w * 5 + 2]; evae += red[w * 5 + 3]; erep += red[w * 5 + 4];
+            }
+        }
+    }
     if (lane == 0) {
         if (a.parts) {
             double* p = a.parts + (size_t)b * 5;

@@ -200,7 +200,12 @@ __global__ __launch_bounds__(TAIL_THREADS, 2) void decoder_tail_kernel(TailArgs 
     // ---- energy terms + dE/dX: one wave per window
     float* g_cur = lds + a.off_g[0];
     float* g_nxt = lds + a.off_g[1];
-    if (wave < nwin) {
+    if (a.G == 1) {
+        // one window per workgroup: all eight wavefronts share its energy terms
+        float* scr = lds + a.off_escr;
+        energy_window<true, TAIL_THREADS>(a.e, a.e.perm ? a.e.perm[w0] : w0, tid, lds + a.off_act[a.n], a.ld_act[a.n], scr,
+                                          scr + a.escr, scr + 2 * a.escr, scr + 3 * a.escr, g_cur, a.ld_g, a.fwd[a.n - 1].N);
+    } else if (wave < nwin) {
         float* scr = lds + a.off_escr + wave * 4 * a.escr;
         energy_window<false>(a.e, a.e.perm ? a.e.perm[w0 + wave] : w0 + wave, lane,
                              lds + a.off_act[a.n] + wave * T * a.ld_act[a.n], a.ld_act[a.n], scr, scr + a.escr,
