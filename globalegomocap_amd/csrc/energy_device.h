@@ -114,17 +114,22 @@ __device__ __forceinline__ void energy_window(const EnergyArgs& a, int b, int la
             const float iy = ((gyn + 1.f) / 2.f) * (float)(a.H - 1);
             const float fx0 = floorf(ix), fy0 = floorf(iy);
             const float fx = ix - fx0, fy = iy - fy0;
-            float nw = 0.f, ne = 0.f, sw = 0.f, se = 0.f;
-            // a projection that is not finite (or far outside) samples nothing, like zeros padding
-            if (fx0 >= -1.f && fx0 < (float)a.W && fy0 >= -1.f && fy0 < (float)a.H) {
-                const int x0i = (int)fx0, y0i = (int)fy0;
-                const float* hm = a.heat + ((size_t)(a.frame0[b] + t) * a.H * a.W) * J + j;
-                const bool xl = x0i >= 0, xr = x0i + 1 < a.W, yt = y0i >= 0, yb = y0i + 1 < a.H;
-                if (yt && xl) nw = hm[((size_t)y0i * a.W + x0i) * J];
-                if (yt && xr) ne = hm[((size_t)y0i * a.W + x0i + 1) * J];
-                if (yb && xl) sw = hm[((size_t)(y0i + 1) * a.W + x0i) * J];
-                if (yb && xr) se = hm[((size_t)(y0i + 1) * a.W + x0i + 1) * J];
-            }
+            // a projection that is not finite (or far outside) samples nothing, like zeros padding.  Branch-free: the
+            // four texels are fetched together from clamped (always valid) addresses and masked afterwards.
+            const bool in = fx0 >= -1.f && fx0 < (float)a.W && fy0 >= -1.f && fy0 < (float)a.H;
+            const int x0i = in ? (int)fx0 : 0, y0i = in ? (int)fy0 : 0;
+            const bool xl = in && x0i >= 0, xr = in && x0i + 1 < a.W, yt = y0i >= 0, yb = y0i + 1 < a.H;
+            const int xa = x0i < 0 ? 0 : x0i, xb = x0i + 1 < a.W ? x0i + 1 : a.W - 1;
+            const int ya = y0i < 0 ? 0 : y0i, yc = y0i + 1 < a.H ? y0i + 1 : a.H - 1;
+            const float* hm = a.heat + ((size_t)(a.frame0[b] + t) * a.H * a.W) * J + j;
+            float nw = hm[((size_t)ya * a.W + xa) * J];
+            float ne = hm[((size_t)ya * a.W + xb) * J];
+            float sw = hm[((size_t)yc * a.W + xa) * J];
+            float se = hm[((size_t)yc * a.W + xb) * J];
+            nw = (yt && xl) ? nw : 0.f;
+            ne = (yt && xr) ? ne : 0.f;
+            sw = (yb && xl) ? sw : 0.f;
+            se = (yb && xr) ? se : 0.f;
             const float gxw = 1.f - fx, gyw = 1.f - fy;
             const float val = nw * gxw * gyw + ne * fx * gyw + sw * gxw * fy + se * fx * fy;
             erep -= (double)val;

@@ -160,15 +160,21 @@ __global__ __launch_bounds__(TAIL_THREADS, 2) void decoder_tail_kernel(TailArgs 
     const int R = nwin * T;                                  // valid rows
     const size_t row0 = (size_t)w0 * T;
 
-    // ---- stage the input activation rows
+    // ---- stage the input activation rows: all of a thread's loads in flight before the first LDS store
     {
-        const int K0 = a.fwd[0].K, q4 = K0 / 4;
+        const int K0 = a.fwd[0].K, q4 = K0 / 4, n4 = TAIL_ROWS * q4;      // K0 <= 512: at most 4 float4 per thread
         float* dst = lds + a.off_act[0];
-        for (int i = tid; i < TAIL_ROWS * q4; i += TAIL_THREADS) {
-            const int r = i / q4, c = (i - r * q4) * 4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (r < R) v = *reinterpret_cast<const f32x4*>(a.a_in + (row0 + r) * K0 + c);
-            *reinterpret_cast<f32x4*>(dst + r * a.ld_act[0] + c) = v;
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = tid + u * TAIL_THREADS, r = i / q4, c = (i - r * q4) * 4;
+            v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (i < n4 && r < R) v[u] = *reinterpret_cast<const f32x4*>(a.a_in + (row0 + r) * K0 + c);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = tid + u * TAIL_THREADS, r = i / q4, c = (i - r * q4) * 4;
+            if (i < n4) *reinterpret_cast<f32x4*>(dst + r * a.ld_act[0] + c) = v[u];
         }
     }
     __syncthreads();
