@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_lib", "libgem_hip.so")
+# GEM_HIP_LIB: developer override to A/B two builds of the library on the same box
+LIB_PATH = os.environ.get("GEM_HIP_LIB") or os.path.join(_HERE, "_lib", "libgem_hip.so")
 
 GEM_MAX_HIDDEN, GEM_MAX_POLY, GEM_MAX_JOINTS = 8, 16, 16
 STAGE_LOCAL, STAGE_GLOBAL = 0, 1

@@ -414,7 +414,7 @@ static int evaluate(gem_handle* h, int stage, int B, const float* zp, const Ener
     }
     TailArgs ta;
     plan_tail(net.dec, st, h->T, h->J, &ta);
-    ta.B = B; ta.forward_only = 0;
+    ta.B = B; ta.forward_only = 0; ta.dbg_ts = nullptr;
     for (int i = 0; i < ta.n; ++i) {
         const Layer& f = net.dec[st + i];
         const Layer& g = net.dec_bwd[st + i];

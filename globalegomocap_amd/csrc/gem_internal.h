@@ -215,11 +215,12 @@ constexpr int TAIL_MAX_LAYERS = 6;
 struct TailLayerDev { const float* w4; const float* bias; int K, N; };
 struct TailArgs {
     int n, B, G, forward_only, escr, mask_first;
+    long long* dbg_ts;       // developer probe (tools/tail_bench): [32] {shader clock, 100 MHz wall clock} pairs of workgroup 0, or nullptr
     TailLayerDev fwd[TAIL_MAX_LAYERS], bwd[TAIL_MAX_LAYERS];
     const float* a_in;       // [B*T, K0] input activation of the first fused layer
     float* g_out;            // [B*T, K0] gradient w.r.t. its pre-activation
     float* Xp;               // [B*T, 64] decoded pose
-    int off_act[TAIL_MAX_LAYERS + 1], ld_act[TAIL_MAX_LAYERS + 1], off_g[2], ld_g, off_red, off_escr;   // LDS plan (floats)
+    int off_act[TAIL_MAX_LAYERS + 1], ld_act[TAIL_MAX_LAYERS + 1], off_g[2], ld_g, off_red, off_escr, off_zero;   // LDS plan (floats)
     EnergyArgs e;
 };
 size_t plan_tail(const std::vector<Layer>& dec, int start, int T, int J, TailArgs* out);

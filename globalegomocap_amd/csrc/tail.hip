@@ -59,12 +59,11 @@ __device__ __forceinline__ void tail_prefetch_first(const TailLayerDev L, f32x4 
 // NT = tiles per wave (N / 128, at least 1): the NT tiles of a wave share the 16 rows, so they walk K together:
 // one A fragment feeds NT independent accumulators.
 template <int NT, typename Epi>
-__device__ __forceinline__ void tail_gemm_nt(const float* in, int ld_in, const TailLayerDev L, const TailLayerDev next, bool has_next,
-                                             int T, int R, f32x4 (&bpre)[4], Epi epi) {
+__device__ __forceinline__ void tail_gemm_nt(const float* in, int ld_in, const float* zero_line, const TailLayerDev L,
+                                             const TailLayerDev next, bool has_next, int T, int R, f32x4 (&bpre)[4], Epi epi) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
     const int kb = L.K / 64, nblk = 3 * kb;                   // (tap, 64-wide k block) pairs
-    const int K4N = (L.K / 4) * L.N;                          // float4 per tap
     const f32x4* W4 = reinterpret_cast<const f32x4*>(L.w4);
     const int n0 = wave * 16;                                 // tile i of this wave: columns n0 + 128*i
     if (n0 >= L.N) {                                          // 64-wide layer: waves 4-7 only fetch ahead
@@ -81,23 +80,27 @@ __device__ __forceinline__ void tail_gemm_nt(const float* in, int ld_in, const T
         bv[i] = L.bias ? L.bias[n0 + 128 * i + fr] : 0.f;      // issued now, consumed in the epilogue
         acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    // B: with the [tap][K/4][N][4] layout the (tap, k-block) pairs are consecutive: block blk starts 16*N float4 after
+    // block blk-1, whatever the tap.  A: rows outside the window (the conv's zero padding) and rows past R read a
+    // zero line of LDS instead -- selecting the ADDRESS keeps the ds_reads in flight behind the MFMAs, a select on
+    // the loaded DATA would make the wave wait for them on the spot.
+    const f32x4* pB = W4 + (size_t)fq * L.N + n0 + fr;
+    const int strideB = 16 * L.N;
+    const int a_own = row * ld_in + 4 * fq;                   // this lane's row, tap 1
+    const int a_zero = (int)(zero_line - in) + 4 * fq;
+    const bool ok_m = row_ok && t_row >= 1, ok_p = row_ok && t_row + 1 < T;
 #define TAIL_LOAD_B(blk_, dst_)                                                                        \
     {                                                                                                  \
-        const int tap_ = ((blk_) >= kb) + ((blk_) >= 2 * kb), k0_ = ((blk_) - tap_ * kb) * 64;         \
-        const f32x4* p_ = W4 + (size_t)tap_ * K4N + (size_t)(k0_ / 4 + fq) * L.N + n0 + fr;            \
+        const f32x4* p_ = pB + (size_t)(blk_) * strideB;                                               \
         _Pragma("unroll") for (int i = 0; i < NT; ++i)                                                 \
             _Pragma("unroll") for (int g = 0; g < 4; ++g) dst_[i][g] = p_[(size_t)(4 * g) * L.N + 128 * i]; \
     }
 #define TAIL_LOAD_A(blk_, dst_)                                                                        \
     {                                                                                                  \
         const int tap_ = ((blk_) >= kb) + ((blk_) >= 2 * kb), k0_ = ((blk_) - tap_ * kb) * 64;         \
-        const int tt_ = t_row + tap_ - 1;                                                              \
-        const bool ok_ = row_ok && tt_ >= 0 && tt_ < T;                                                \
-        const float* arow_ = in + (ok_ ? row + tap_ - 1 : 0) * ld_in + k0_ + 4 * fq;                   \
-        _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                \
-            dst_[g] = *reinterpret_cast<const f32x4*>(arow_ + 16 * g);                                 \
-            if (!ok_) dst_[g] = f32x4{0.f, 0.f, 0.f, 0.f};                                             \
-        }                                                                                              \
+        const bool ok_ = tap_ == 0 ? ok_m : (tap_ == 1 ? row_ok : ok_p);                               \
+        const float* arow_ = in + (ok_ ? a_own + (tap_ - 1) * ld_in + k0_ : a_zero);                   \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) dst_[g] = *reinterpret_cast<const f32x4*>(arow_ + 16 * g); \
     }
 #define TAIL_COMPUTE(a_, b_)                                                                           \
     {                                                                                                  \
@@ -141,18 +144,25 @@ __device__ __forceinline__ void tail_gemm_nt(const float* in, int ld_in, const T
 }
 
 template <typename Epi>
-__device__ __forceinline__ void tail_gemm(const float* in, int ld_in, const TailLayerDev L, const TailLayerDev next, bool has_next,
-                                          int T, int R, f32x4 (&bpre)[4], Epi epi) {
+__device__ __forceinline__ void tail_gemm(const float* in, int ld_in, const float* zero_line, const TailLayerDev L,
+                                          const TailLayerDev next, bool has_next, int T, int R, f32x4 (&bpre)[4], Epi epi) {
     // N is 64, 128, 256 or 512 (plan_tail): N/128 tiles per wave, at least one
-    if (L.N > 256) tail_gemm_nt<4>(in, ld_in, L, next, has_next, T, R, bpre, epi);
-    else if (L.N > 128) tail_gemm_nt<2>(in, ld_in, L, next, has_next, T, R, bpre, epi);
-    else tail_gemm_nt<1>(in, ld_in, L, next, has_next, T, R, bpre, epi);
+    if (L.N > 256) tail_gemm_nt<4>(in, ld_in, zero_line, L, next, has_next, T, R, bpre, epi);
+    else if (L.N > 128) tail_gemm_nt<2>(in, ld_in, zero_line, L, next, has_next, T, R, bpre, epi);
+    else tail_gemm_nt<1>(in, ld_in, zero_line, L, next, has_next, T, R, bpre, epi);
 }
 
 __global__ __launch_bounds__(TAIL_THREADS, 2) void decoder_tail_kernel(TailArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int T = a.e.T;
+    int probe = 0;
+#define TAIL_PROBE()                                                                                   \
+    if (a.dbg_ts && blockIdx.x == 0 && tid == 0) {                                                     \
+        a.dbg_ts[2 * probe] = clock64();                                                               \
+        a.dbg_ts[2 * probe + 1] = wall_clock64();                                                      \
+        ++probe;                                                                                       \
+    }
     const int w0 = blockIdx.x * a.G;                         // first slot of this workgroup
     const int B = a.e.n_dev ? *a.e.n_dev : a.B;              // active slots this round
     if (w0 >= B) return;
@@ -176,8 +186,11 @@ __global__ __launch_bounds__(TAIL_THREADS, 2) void decoder_tail_kernel(TailArgs 
             const int i = tid + u * TAIL_THREADS, r = i / q4, c = (i - r * q4) * 4;
             if (i < n4) *reinterpret_cast<f32x4*>(dst + r * a.ld_act[0] + c) = v[u];
         }
+        if (tid < 64) lds[a.off_zero + tid] = 0.f;            // the zero line the padded conv rows read
     }
+    TAIL_PROBE();
     __syncthreads();
+    TAIL_PROBE();
 
     // ---- forward layers
     f32x4 bpre[4];
@@ -189,7 +202,7 @@ __global__ __launch_bounds__(TAIL_THREADS, 2) void decoder_tail_kernel(TailArgs 
         float* Xp = last ? a.Xp : nullptr;
         // (by value: taking the address of a kernel-argument member would put the whole struct in scratch)
         const TailLayerDev nxt = !last ? a.fwd[i + 1] : a.bwd[a.n - 1];
-        tail_gemm(lds + a.off_act[i], a.ld_act[i], a.fwd[i], nxt, !last || !a.forward_only, T, R, bpre,
+        tail_gemm(lds + a.off_act[i], a.ld_act[i], lds + a.off_zero, a.fwd[i], nxt, !last || !a.forward_only, T, R, bpre,
                   [&](const f32x4& acc, int r0, int col, float bv) {
 #pragma unroll
                       for (int e = 0; e < 4; ++e) {
@@ -200,6 +213,7 @@ __global__ __launch_bounds__(TAIL_THREADS, 2) void decoder_tail_kernel(TailArgs 
                       }
                   });
         __syncthreads();
+        TAIL_PROBE();
     }
     if (a.forward_only) return;
 
@@ -218,6 +232,7 @@ __global__ __launch_bounds__(TAIL_THREADS, 2) void decoder_tail_kernel(TailArgs 
                              scr + 2 * a.escr, scr + 3 * a.escr, g_cur + wave * T * a.ld_g, a.ld_g, a.fwd[a.n - 1].N);
     }
     __syncthreads();
+    TAIL_PROBE();
 
     // ---- backward-data layers (adjoint convs), LeakyReLU' from the sign of the LDS activations
     for (int i = a.n - 1; i >= 0; --i) {
@@ -226,7 +241,7 @@ __global__ __launch_bounds__(TAIL_THREADS, 2) void decoder_tail_kernel(TailArgs 
         const int ldg = a.ld_g;
         float* gout = a.g_out;
         const int K0 = a.fwd[0].K;
-        tail_gemm(g_cur, a.ld_g, a.bwd[i], a.bwd[i > 0 ? i - 1 : 0], i > 0, T, R, bpre,
+        tail_gemm(g_cur, a.ld_g, lds + a.off_zero, a.bwd[i], a.bwd[i > 0 ? i - 1 : 0], i > 0, T, R, bpre,
                   [&](const f32x4& acc, int r0, int col, float) {
 #pragma unroll
                       for (int e = 0; e < 4; ++e) {
@@ -238,8 +253,10 @@ __global__ __launch_bounds__(TAIL_THREADS, 2) void decoder_tail_kernel(TailArgs 
                       }
                   });
         __syncthreads();
+        TAIL_PROBE();
         float* t = g_cur; g_cur = g_nxt; g_nxt = t;
     }
+#undef TAIL_PROBE
 }
 
 // LDS plan for a fused chain starting at decoder conv `start` (input = output of conv start-1, or of
@@ -271,6 +288,8 @@ size_t plan_tail(const std::vector<Layer>& dec, int start, int T, int J, TailArg
     a.off_red = off;                       // (unused since the 16x16 tiling needs no k-split scratch)
     a.off_escr = off;
     off += a.G * 4 * a.escr;
+    a.off_zero = off;                      // 64 zero floats
+    off += 64;
     if (out) *out = a;
     return (size_t)off * sizeof(float);
 }

@@ -28,7 +28,7 @@ int main(int argc, char** argv) {
         a.fwd[i] = TailLayerDev{dev_rand((size_t)3 * K * N, 10 + i, 0.05f), dev_rand(N, 20 + i, 0.05f), K, N};
         a.bwd[i] = TailLayerDev{dev_rand((size_t)3 * K * N, 30 + i, 0.05f), nullptr, N, K};
     }
-    a.B = B;
+    a.B = B; a.dbg_ts = nullptr;
     a.a_in = dev_rand((size_t)B * T * 256, 1, 1.f);
     hipMalloc(&a.g_out, (size_t)B * T * 256 * 4);
     hipMalloc(&a.Xp, (size_t)B * T * 256 * 4 + 4096);   // generous: the per-layer probe below writes up to 128 columns at stride 64
@@ -41,7 +41,7 @@ int main(int argc, char** argv) {
     hipMalloc((void**)&e.frame0, B * 4); hipMemcpy((void*)e.frame0, f0.data(), B * 4, hipMemcpyHostToDevice);
     e.mean_bone = dev_rand((size_t)B * 15, 3, 0.3f);
     hipMalloc(&e.f, B * 8); hipMalloc(&e.parts, B * 40);
-    e.w3d = e.ws = e.wb = 0.01f; e.wv = 0; e.wr = 0.01f; e.dw3d = e.dws = e.dwb = 0.01; e.dwr = 0.01;
+    e.w3d = e.ws = e.wb = 0.01f; e.wv = 0; e.wr = getenv("TAIL_NO_REPROJ") ? 0.f : 0.01f; e.dw3d = e.dws = e.dwb = 0.01; e.dwr = 0.01;
     e.T = T; e.J = J; e.H = 64; e.W = 64; e.n_poly = 11;
     const float poly[11] = {478.6f, 350.4f, 79.f, 62.3f, 32.6f, 15.7f, 7.77f, 2.19f, -0.108f, -0.19f, -0.0278f};
     for (int i = 0; i < 11; ++i) e.poly[i] = poly[i];
@@ -66,6 +66,20 @@ int main(int argc, char** argv) {
         printf("B=%d first %d forward layers only: %.1f us\n", B, nn, ms * 1e3 / iters);
     }
     a.n = nfull;
+    {   // phase timestamps of workgroup 0 (staging issued, staged, 5 forward layers, energy, 5 backward layers)
+        long long* d_ts; hipMalloc(&d_ts, 64 * 8); hipMemset(d_ts, 0, 64 * 8);
+        a.forward_only = 0; a.dbg_ts = d_ts;
+        for (int i = 0; i < 20; ++i) launch_tail(&h, a, lds, s);
+        hipStreamSynchronize(s);
+        long long ts[64]; hipMemcpy(ts, d_ts, sizeof(ts), hipMemcpyDeviceToHost);
+        a.dbg_ts = nullptr;
+        const char* names[13] = {"loads issued", "staged", "fwd 256->128", "fwd 128->64", "fwd 64->64", "fwd 64->64", "fwd 64->45",
+                                 "energy", "bwd 45->64", "bwd 64->64", "bwd 64->64", "bwd 64->128", "bwd 128->256"};
+        for (int i = 1; i < 13; ++i)
+            printf("  %-14s %7.2f us  (%6lld shader clocks, %.2f GHz)\n", names[i], (ts[2 * i + 1] - ts[2 * i - 1]) * 0.01,
+                   ts[2 * i] - ts[2 * i - 2], (ts[2 * i] - ts[2 * i - 2]) / ((ts[2 * i + 1] - ts[2 * i - 1]) * 10.0 + 1e-9));
+        printf("  total inside the kernel %.2f us\n", (ts[25] - ts[1]) * 0.01);
+    }
     for (int fo = 1; fo >= 0; --fo) {
         a.forward_only = fo;
         for (int i = 0; i < 3; ++i) launch_tail(&h, a, lds, s);
