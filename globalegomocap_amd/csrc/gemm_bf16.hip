@@ -18,6 +18,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));        // per-thread row tables as native vectors (a plain int[] went to scratch)
 
 __device__ __forceinline__ unsigned int f2bf(float x) {           // round-to-nearest-even, finite inputs
     const unsigned int u = __builtin_bit_cast(unsigned int, x);
@@ -71,13 +72,16 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const float* __restrict_
     // B tile: 64 rows x 64 bf16 = 512 x 16 B   -> 2 per thread (8 threads per row, 32 rows per pass)
     const int a_c4 = (tid & 15) * 4, a_r = tid >> 4;
     const int b_c8 = (tid & 7) * 8, b_r = tid >> 3;
-    int a_row[4], a_t[4], a_src[4];
+    i32x8 a_row, a_t, a_src;
     bool a_ok[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        a_row[i] = m0 + a_r + 16 * i;
-        a_t[i] = (TAPS == 3) ? (a_row[i] % T) : 0;
-        a_src[i] = (TAPS == 1 && row_map && a_row[i] < M) ? row_map[a_row[i]] : a_row[i];
+        const int r_ = m0 + a_r + 16 * i;
+        a_row[i] = r_;
+        a_t[i] = (TAPS == 3) ? (r_ % T) : 0;
+        int s_ = r_;
+        if (TAPS == 1 && row_map) s_ = row_map[r_ < M ? r_ : 0];
+        a_src[i] = s_;
     }
     f32x4 ra[4];
     u32x4 rbh[2], rbl[2];
@@ -165,11 +169,173 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const float* __restrict_
     }
 }
 
+// Large-batch variant: 128x128 output tile, every wave a 64x64 quarter (2x2 MFMA blocks), no split-K.  At 64x64 the
+// kernel above is bound by the CU's 64 B/clk vector-memory path (24 KB of operands per 4 MFMAs per wave); here
+// the operand bytes per MFMA are halved.  Used when the launch has enough 128x128 tiles to fill the chip.
+template <int TAPS, int EPI, int NPROD>
+__global__ __launch_bounds__(256) void gemm_bf16_big_kernel(const float* __restrict__ A, int lda, const uint16_t* __restrict__ Whi,
+                                                            const uint16_t* __restrict__ Wlo, const float* __restrict__ bias,
+                                                            const float* __restrict__ aux, float* __restrict__ C, int ldc, int M,
+                                                            int N, int K, int T, const int* __restrict__ m_dev,
+                                                            const int* __restrict__ row_map) {
+    constexpr int BM = 128, BN = 128, BK = 64;
+    constexpr int LD = BK + 8;
+    constexpr int IMG = BM * LD;
+    constexpr bool SPLIT = NPROD == 3;
+    extern __shared__ __attribute__((aligned(16))) unsigned short ldsb[];
+    unsigned short* a_hi = ldsb;
+    unsigned short* b_hi = ldsb + IMG;
+    unsigned short* a_lo = ldsb + 2 * IMG;           // only touched when SPLIT
+    unsigned short* b_lo = ldsb + 3 * IMG;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    if (m_dev) M = *m_dev;
+    if (m0 >= M) return;
+    const int kTiles = K / BK, nTiles = TAPS * kTiles;
+
+    // A tile: 128 rows x 64 fp32 = 2048 float4 -> 8 per thread; B tile: 128 rows x 64 bf16 = 1024 x 16 B -> 4 per thread
+    const int a_c4 = (tid & 15) * 4, a_r = tid >> 4;
+    const int b_c8 = (tid & 7) * 8, b_r = tid >> 3;
+    i32x8 a_idx, a_t, a_in;          // source row (gathered through row_map for linear layers), its frame index, row < M
+    bool a_ok[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = m0 + a_r + 16 * i;
+        a_in[i] = row < M ? 1 : 0;
+        a_t[i] = (TAPS == 3) ? (row % T) : 0;
+        int s_ = row;
+        if (TAPS == 1 && row_map) s_ = row_map[row < M ? row : 0];
+        a_idx[i] = s_;
+    }
+    f32x4 ra[8];
+    u32x4 rbh[4], rbl[4];
+
+#define GBB_LOAD(kt_)                                                                                    \
+    {                                                                                                    \
+        const int tap_ = (TAPS == 3) ? (kt_) / kTiles : 0;                                               \
+        const int k0_ = ((kt_) - tap_ * kTiles) * BK;                                                    \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                  \
+            bool ok_ = a_in[i] != 0;                                                                     \
+            if (TAPS == 3) { const int tt_ = a_t[i] + tap_ - 1; ok_ = ok_ && tt_ >= 0 && tt_ < T; }      \
+            const int src_ = ok_ ? a_idx[i] + ((TAPS == 3) ? tap_ - 1 : 0) : 0;                          \
+            ra[i] = *reinterpret_cast<const f32x4*>(A + (size_t)src_ * lda + k0_ + a_c4);                \
+            a_ok[i] = ok_;                                                                               \
+        }                                                                                                \
+        const size_t wo_ = ((size_t)tap_ * N + n0 + b_r) * K + k0_ + b_c8;                               \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                  \
+            rbh[i] = *reinterpret_cast<const u32x4*>(Whi + wo_ + (size_t)32 * i * K);                    \
+            if (SPLIT) rbl[i] = *reinterpret_cast<const u32x4*>(Wlo + wo_ + (size_t)32 * i * K);         \
+        }                                                                                                \
+    }
+#define GBB_STORE()                                                                                      \
+    {                                                                                                    \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                  \
+            const f32x4 v_ = a_ok[i] ? ra[i] : f32x4{0.f, 0.f, 0.f, 0.f};                                \
+            unsigned int h_[4], l_[4];                                                                   \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                              \
+                h_[q] = f2bf(v_[q]);                                                                     \
+                l_[q] = SPLIT ? f2bf(v_[q] - bf2f(h_[q])) : 0u;                                          \
+            }                                                                                            \
+            const int o_ = (a_r + 16 * i) * LD + a_c4;                                                   \
+            *reinterpret_cast<u32x2*>(a_hi + o_) = u32x2{h_[0] | (h_[1] << 16), h_[2] | (h_[3] << 16)};  \
+            if (SPLIT) *reinterpret_cast<u32x2*>(a_lo + o_) = u32x2{l_[0] | (l_[1] << 16), l_[2] | (l_[3] << 16)}; \
+        }                                                                                                \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                  \
+            const int o_ = (b_r + 32 * i) * LD + b_c8;                                                   \
+            *reinterpret_cast<u32x4*>(b_hi + o_) = rbh[i];                                               \
+            if (SPLIT) *reinterpret_cast<u32x4*>(b_lo + o_) = rbl[i];                                    \
+        }                                                                                                \
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int ao = (wm * 64 + fr) * LD + 8 * fh, bo = (wn * 64 + fr) * LD + 8 * fh;
+
+    GBB_LOAD(0);
+    GBB_STORE();
+    __syncthreads();
+    for (int kt = 0; kt < nTiles; ++kt) {
+        const bool more = kt + 1 < nTiles;
+        if (more) GBB_LOAD(kt + 1);
+#pragma unroll
+        for (int st = 0; st < BK / 16; ++st) {
+            bf16x8 ah[2], bh[2], al[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = *reinterpret_cast<const bf16x8*>(a_hi + ao + i * 32 * LD + 16 * st);
+                bh[i] = *reinterpret_cast<const bf16x8*>(b_hi + bo + i * 32 * LD + 16 * st);
+                if (SPLIT) {
+                    al[i] = *reinterpret_cast<const bf16x8*>(a_lo + ao + i * 32 * LD + 16 * st);
+                    bl[i] = *reinterpret_cast<const bf16x8*>(b_lo + bo + i * 32 * LD + 16 * st);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (SPLIT) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);     // small terms first
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();                    // every wave has read the tile
+        if (more) GBB_STORE();
+        __syncthreads();
+    }
+#undef GBB_LOAD
+#undef GBB_STORE
+
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + fr;
+            float bv = 0.f;
+            if (EPI == EPI_BIAS || EPI == EPI_BIAS_LRELU) bv = bias[col];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                if (row < M) {
+                    float v = acc[i][j][e] + bv;
+                    if (EPI == EPI_BIAS_LRELU) v = v > 0.f ? v : v * LEAKY_SLOPE;
+                    if (EPI == EPI_MASK) v *= (aux[(size_t)row * ldc + col] > 0.f) ? 1.f : LEAKY_SLOPE;
+                    C[(size_t)row * ldc + col] = v;
+                }
+            }
+        }
+}
+
 template <int TAPS, int EPI, int NPROD>
 static int launch_b(gem_handle* h, const Layer& L, const float* A, int lda, const float* aux, float* C, int ldc, int M, int T,
                     hipStream_t s, const int* row_map) {
     const int* m_dev = h->ws.dyn ? h->ws.n_active + (TAPS == 3 ? 1 : 0) : nullptr;
     constexpr int BK = 64;
+    // 128x128 tiles once they fill the chip (developer override GEM_BF16_TILE=1 / 2 forces 64x64 / 128x128)
+    static const char* force = getenv("GEM_BF16_TILE");
+    const long big_blocks = (long)((M + 127) / 128) * (L.N / 128);
+    if (L.N % 128 == 0 && ((force && force[0] == '2') || (!(force && force[0] == '1') && big_blocks >= 256))) {
+        auto kb = gemm_bf16_big_kernel<TAPS, EPI, NPROD>;
+        const size_t smem = (size_t)(NPROD == 3 ? 4 : 2) * 128 * (BK + 8) * sizeof(unsigned short);
+        static bool big_attr = false;
+        if (!big_attr) {
+            GEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            big_attr = true;
+        }
+        hipLaunchKernelGGL(kb, dim3(L.N / 128, (M + 127) / 128, 1), dim3(256), smem, s, A, lda, L.wb_hi, L.wb_lo, L.bias, aux, C, ldc,
+                           M, L.N, L.K, T, m_dev, row_map);
+        GEM_HIP(hipGetLastError());
+        return 0;
+    }
     size_t shmem = (size_t)(NPROD == 3 ? 4 : 2) * 64 * (BK + 8) * sizeof(unsigned short);
     auto k = gemm_bf16_kernel<TAPS, EPI, NPROD>;
     static bool attr_set = false;

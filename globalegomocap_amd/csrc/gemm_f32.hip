@@ -21,7 +21,8 @@
 namespace gem {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));    // native vector: keeps staged tiles in VGPRs (a float4 struct array went to scratch)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));        // per-thread row tables as NATIVE vectors: a plain int[] went to scratch    // native vector: keeps staged tiles in VGPRs (a float4 struct array went to scratch)
 
 constexpr int BK_MIN = 32;      // K padding granularity
 
@@ -74,12 +75,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     // ---- per-thread global load coordinates (branch-free: out-of-range rows read row 0 and are zeroed)
     const int c4 = (tid % TPR) * 4;
     const int lrow = tid / TPR;
-    int a_row[A_LD4], a_t[A_LD4], a_src[A_LD4];
+    static_assert(A_LD4 <= 8, "row tables hold up to 8 entries");
+    i32x8 a_row, a_t, a_src;
 #pragma unroll
     for (int i = 0; i < A_LD4; ++i) {
-        a_row[i] = m0 + lrow + RPP * i;
-        a_t[i] = (TAPS == 3) ? (a_row[i] % T) : 0;
-        a_src[i] = (TAPS == 1 && row_map && a_row[i] < M) ? row_map[a_row[i]] : a_row[i];    // gathered A rows (linear only)
+        const int r_ = m0 + lrow + RPP * i;
+        a_row[i] = r_;
+        a_t[i] = (TAPS == 3) ? (r_ % T) : 0;
+        int s_ = r_;
+        if (TAPS == 1 && row_map) s_ = row_map[r_ < M ? r_ : 0];           // gathered A rows (linear only)
+        a_src[i] = s_;
     }
     f32x4 ra[A_LD4], rb[B_LD4];
     bool a_ok[A_LD4];

@@ -582,3 +582,40 @@ def test_two_engines_on_two_streams_do_not_interfere(torch_cuda):
     for k in (0, 1):
         for mid, glob, stats in got[k]:
             assert torch.equal(mid, alone[k][0]) and torch.equal(glob, alone[k][1]) and torch.equal(stats, alone[k][2])
+
+
+@pytest.mark.parametrize("mode,tol_x,tol_e,tol_g", [("f32", 5e-5, 2e-4, 2e-3), ("bf16x3", 5e-5, 2e-4, 2e-3), ("bf16", 3e-3, 5e-2, 2e-1)])
+def test_large_batch_tile_kernels_against_oracle(torch_cuda, mode, tol_x, tol_e, tol_g):
+    """BASELINE configs[3] regime (thousands of windows per GPU): the 128x128-tile GEMM kernels that take over at large
+    batch (fp32, split-bf16, bf16) on 1664 windows, spot-checked against the oracle on windows spread over the batch
+    (first / middle / last row tiles, tile edges) plus bitwise agreement between identical windows."""
+    import torch
+    sd = vae_schema.synthetic_state_dict(FULL, 5)
+    B = 1664                                            # 13 x 40 dec_in tiles of 128x128: above every big-tile threshold
+    eng = _engine(FULL, max_windows=B)
+    eng.load_vae(0, sd)
+    eng.set_precision(mode)
+    vae = O.fold_vae(sd)
+    cam = oracle_camera()
+    seq = synth.make_sequence(n_frames=200, seed=34)
+    est = np.asarray(seq["estimated_local_skeleton"], dtype=np.float32)
+    heat = np.asarray(seq["heatmap_list"], dtype=np.float32)
+    rng = np.random.default_rng(6)
+    starts = rng.integers(0, 190, B).astype(np.int32)
+    starts[1] = starts[0]                               # an identical pair inside one tile and one across tiles
+    starts[1000] = starts[0]
+    pose = np.stack([est[s:s + 10] for s in starts])
+    mb = O.mean_bone_length(est)
+    eps = rng.normal(size=(B, 2048)).astype(np.float32)
+    eps[1] = eps[0]; eps[1000] = eps[0]
+    mu_d, lv_d, z_d = eng.encode(0, pose.reshape(B, 10, 45), eps)
+    E, parts, dz, X = eng.energy_grad(0, z_d, pose, mb, _ew(W_ALL), heat, starts)
+    assert torch.equal(X[0], X[1]) and torch.equal(X[0], X[1000]) and torch.equal(dz[0], dz[1]) and torch.equal(dz[0], dz[1000])
+    z = z_d.cpu().numpy()
+    for b in (0, 127, 128, 831, 1535, 1663):
+        Xo, acts = O.decode(vae, z[b:b + 1], keep=True)
+        f, p, dX = O.energy_and_grad(Xo[0], pose[b], mb, O.Weights(*W_ALL), cam, heat[starts[b]:starts[b] + 10])
+        dzo = O.decode_backward(vae, dX[None], acts)[0]
+        assert np.abs(X[b].cpu().numpy() - Xo[0]).max() <= tol_x * max(1.0, np.abs(Xo[0]).max()), b
+        assert abs(float(E[b]) - f) <= tol_e * abs(f) + 1e-7, b
+        assert np.abs(dz[b].cpu().numpy() - dzo).max() <= tol_g * np.abs(dzo).max() + 1e-8, b
