@@ -140,6 +140,24 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         if (more && GEM_ABLATE < 1) GEM_LOAD_TILE(kt + 1);
         const float* as = lds + cur * BUF + (wm * 32 * RM + fr) * LDS_LD + fh * (BK / 2);
         const float* bs = lds + cur * BUF + (BM + wn * 32 * RN + fr) * LDS_LD + fh * (BK / 2);
+        if (RM * RN == 1 && GEM_ABLATE == 0) {
+            // 64x64 tiles: all fragments of the k-tile are requested up front, so that the MFMAs of the first k-steps
+            // cover the LDS latency of the later ones (read-then-wait per group exposed ~100 cycles twice per tile)
+            f32x4 av[BK / 8], bv[BK / 8];
+#pragma unroll
+            for (int q = 0; q < BK / 8; ++q) {
+                av[q] = *reinterpret_cast<const f32x4*>(as + 4 * q);
+                bv[q] = *reinterpret_cast<const f32x4*>(bs + 4 * q);
+            }
+            __builtin_amdgcn_sched_barrier(0);          // (the scheduler would otherwise sink the later reads again)
+#pragma unroll
+            for (int q = 0; q < BK / 8; ++q) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].x, bv[q].x, acc[0][0], 0, 0, 0);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].y, bv[q].y, acc[0][0], 0, 0, 0);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].z, bv[q].z, acc[0][0], 0, 0, 0);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].w, bv[q].w, acc[0][0], 0, 0, 0);
+            }
+        } else {
 #pragma unroll
         for (int q = 0; q < BK / 8; ++q) {
             f32x4 av[RM], bv[RN];
@@ -160,6 +178,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].z, bv[j].z, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, bv[j].w, acc[i][j], 0, 0, 0);
                 }
+        }
         }
         if (GEM_ABLATE >= 2) continue;          // ablation build: MFMA + LDS reads only
         if (DBUF) {
