@@ -179,7 +179,9 @@ int gem_create(const gem_config* cfg, gem_handle** out) {
     float** vecs[] = {&w.x, &w.d, &w.g, &w.gp, &w.bg0, &w.bg1, &w.trial};
     for (float** v : vecs)
         if (dev_alloc(w.allocs, v, (size_t)B * h->Dp)) return 1;
-    w.hist_cap = 32;     // >= max_iter - 1 pairs for the reference's max_iter = 25; checked per call
+    w.hist_cap = 32;     // >= max_iter - 1 pairs for the reference's max_iter = 25 (checked per call); a power of two:
+                         // lbfgs.hip wraps ring indices with a mask
+    static_assert(MAX_HIST >= 32, "ring capacity");
     if (dev_alloc(w.allocs, &w.S, (size_t)B * w.hist_cap * h->Dp)) return 1;
     if (dev_alloc(w.allocs, &w.Y, (size_t)B * w.hist_cap * h->Dp)) return 1;
     if (dev_alloc(w.allocs, &w.state, (size_t)B)) return 1;

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const float* __restrict_
 
 #define GB_LOAD(kt_)                                                                                     \
     {                                                                                                    \
-        const int tap_ = (TAPS == 3) ? (kt_) / kTiles : 0;                                               \
+        const int tap_ = (TAPS == 3) ? ((kt_) >= kTiles) + ((kt_) >= 2 * kTiles) : 0;   /* no runtime division */                                               \
         const int k0_ = ((kt_) - tap_ * kTiles) * BK;                                                    \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                  \
             bool ok_ = a_row[i] < M;                                                                     \
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_big_kernel(const float* __restr
 
 #define GBB_LOAD(kt_)                                                                                    \
     {                                                                                                    \
-        const int tap_ = (TAPS == 3) ? (kt_) / kTiles : 0;                                               \
+        const int tap_ = (TAPS == 3) ? ((kt_) >= kTiles) + ((kt_) >= 2 * kTiles) : 0;   /* no runtime division */                                               \
         const int k0_ = ((kt_) - tap_ * kTiles) * BK;                                                    \
         _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                  \
             bool ok_ = a_in[i] != 0;                                                                     \

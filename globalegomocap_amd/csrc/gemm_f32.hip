@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 
 #define GEM_LOAD_TILE(kt_)                                                                                   \
     {                                                                                                        \
-        const int tap_ = (TAPS == 3) ? (kt_) / kTiles : 0;                                                   \
+        const int tap_ = (TAPS == 3) ? ((kt_) >= kTiles) + ((kt_) >= 2 * kTiles) : 0;   /* no runtime division */                                                   \
         const int k0_ = ((kt_) - tap_ * kTiles) * BK + c4;                                                   \
         _Pragma("unroll") for (int i = 0; i < A_LD4; ++i) {                                                  \
             bool ok_ = a_row[i] < M;                                                                         \

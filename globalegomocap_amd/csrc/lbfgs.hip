@@ -94,6 +94,7 @@ __device__ __forceinline__ void lbfgs_advance_body(const AdvArgs& a) {
     int phase = sp->phase;
     if (phase == PH_DONE) return;
     BlockRed<NT> R{red, 0};
+    const int hmask = a.hist_cap - 1;        // the ring capacity is a power of two (checked on the host): no runtime modulo
     const gem_lbfgs_opts& o = a.o;
     const int Dp = a.Dp;
     const size_t off = (size_t)b * Dp;
@@ -312,10 +313,10 @@ __device__ __forceinline__ void lbfgs_advance_body(const AdvArgs& a) {
             const int limit = o.history < a.hist_cap ? o.history : a.hist_cap;
             if (ys > 1e-10) {
                 if (hist_count == limit) {          // shift history by one (limited memory)
-                    hist_start = (hist_start + 1) % a.hist_cap;
+                    hist_start = (hist_start + 1) & hmask;
                     hist_count--;
                 }
-                const int slot = (hist_start + hist_count) % a.hist_cap;
+                const int slot = (hist_start + hist_count) & hmask;
                 float* Ys = a.Y + ((size_t)b * a.hist_cap + slot) * Dp - off;
                 float* Ss = a.S + ((size_t)b * a.hist_cap + slot) * Dp - off;
                 store(Ys, yv);
@@ -331,7 +332,7 @@ __device__ __forceinline__ void lbfgs_advance_body(const AdvArgs& a) {
             for (int i = 0; i < EPT; ++i) q[i] = -gcur[i];
             // two-loop recursion
             auto pair_ptr = [&](const float* base, int k) {
-                const int slot = (hist_start + k) % a.hist_cap;
+                const int slot = (hist_start + k) & hmask;
                 return base + ((size_t)b * a.hist_cap + slot) * Dp - off;
             };
             // Three (s, y) pairs are kept in flight: pair k lives in ring buffer k % 3, and a buffer is refilled
@@ -346,7 +347,7 @@ __device__ __forceinline__ void lbfgs_advance_body(const AdvArgs& a) {
             };
             auto first_k = [&](int j) { const int k = hc - 1 - ((hc - 1 - j + 3) % 3); return k < 0 ? 0 : k; };
             auto step1 = [&](int k, float (&sb)[EPT], float (&yb)[EPT]) {
-                const int slot = (hist_start + k) % a.hist_cap;
+                const int slot = (hist_start + k) & hmask;
                 const double al = dot(sb, q) * ro_s[slot];
                 if (tid == 0) al_s[k] = al;
                 const float alf = (float)al;
@@ -355,7 +356,7 @@ __device__ __forceinline__ void lbfgs_advance_body(const AdvArgs& a) {
                 ld_pair(k >= 3 ? k - 3 : k, sb, yb);
             };
             auto step2 = [&](int k, float (&sb)[EPT], float (&yb)[EPT]) {
-                const int slot = (hist_start + k) % a.hist_cap;
+                const int slot = (hist_start + k) & hmask;
                 const double be = dot(yb, q) * ro_s[slot];
                 const float cf = (float)(al_s[k] - be);
 #pragma unroll
@@ -469,7 +470,7 @@ static AdvArgs make_args(gem_handle* h, const gem_lbfgs_opts& o) {
     a.state = w.state; a.f = w.f; a.gnew = w.dz;
     a.x = w.x; a.d = w.d; a.g = w.g; a.gp = w.gp; a.bg0 = w.bg0; a.bg1 = w.bg1; a.trial = w.trial; a.S = w.S; a.Y = w.Y;
     a.slot_of = w.dyn ? w.slot_of : nullptr;
-    a.Dp = h->Dp; a.hist_cap = w.hist_cap; a.o = o;
+    a.Dp = h->Dp; a.hist_cap = w.hist_cap; a.o = o;        // hist_cap: power of two (gem_create)
     return a;
 }
 
