@@ -371,7 +371,12 @@ static int decoder_backward(gem_handle* h, int stage, int B, hipStream_t s, int 
         if (launch_gemm(h, L, i > 0 ? EPI_MASK : EPI_NONE, gin, L.K, aux, w.dec_grad[i], L.N, rows, h->T, s, -1)) return 1;
         gin = w.dec_grad[i];
     }
-    return launch_gemm(h, net.dec_in_bwd, EPI_BIAS, gin, net.dec_in_bwd.K, nullptr, w.dz, h->Dp, B, h->T, s, 0);
+    // in the rounds lbfgs_advance sums the slabs of this product itself (its bias is zero)
+    w.defer_reduce = w.dyn;
+    const int rc = launch_gemm(h, net.dec_in_bwd, EPI_BIAS, gin, net.dec_in_bwd.K, nullptr, w.dz, h->Dp, B, h->T, s, 0);
+    w.grad_slab = w.defer_reduce ? w.deferred : SlabSrc{};
+    w.defer_reduce = false;
+    return rc;
 }
 
 static EnergyArgs energy_args(gem_handle* h, const float* X0, const float* heat, const int32_t* frame0, const float* mean_bone,
@@ -410,13 +415,20 @@ static int evaluate(gem_handle* h, int stage, int B, const float* zp, const Ener
     const int st = net.tail_start, rows = B * h->T;
     if (launch_gemm(h, net.dec_in, EPI_BIAS, zp, h->Dp, nullptr, w.h0, net.dec_in.N, B, h->T, s, 0, w.dyn ? w.perm : nullptr)) return 1;
     const float* in = w.h0;
+    SlabSrc in_slab;
     for (int i = 0; i < st; ++i) {
-        if (launch_gemm(h, net.dec[i], EPI_BIAS_LRELU, in, net.dec[i].K, nullptr, w.dec_act[i], net.dec[i].N, rows, h->T, s, -1)) return 1;
+        // in the rounds the last wide conv leaves its split-K slabs to the tail kernel (sum + bias + LeakyReLU while staging)
+        w.defer_reduce = w.dyn && i == st - 1;
+        const int rc = launch_gemm(h, net.dec[i], EPI_BIAS_LRELU, in, net.dec[i].K, nullptr, w.dec_act[i], net.dec[i].N, rows, h->T, s, -1);
+        if (w.defer_reduce) in_slab = w.deferred;
+        w.defer_reduce = false;
+        if (rc) return 1;
         in = w.dec_act[i];
     }
     TailArgs ta;
     plan_tail(net.dec, st, h->T, h->J, &ta);
     ta.B = B; ta.forward_only = 0; ta.dbg_ts = nullptr;
+    ta.in_slab = in_slab; ta.in_bias = st > 0 ? net.dec[st - 1].bias : nullptr;
     for (int i = 0; i < ta.n; ++i) {
         const Layer& f = net.dec[st + i];
         const Layer& g = net.dec_bwd[st + i];

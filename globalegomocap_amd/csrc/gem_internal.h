@@ -60,6 +60,16 @@ struct alignas(16) LbfgsState {
     double ro[MAX_HIST];
 };
 
+// Where a split-K GEMM left its partial slabs for a consumer that sums them itself (the fused tail stages the wide
+// conv's output this way, lbfgs_advance its gradient rows): saves the reduce launch between producer and consumer.
+struct SlabSrc {
+    const float* base = nullptr;   // nullptr: nothing deferred, the consumer reads the finished matrix
+    int nslab = 0;                 // static cut: slab z starts at base + z * stride
+    size_t stride = 0;
+    int dyn_W = 0, n_tiles = 0, ldc = 0, CT = 0;      // device-adaptive cut (dyn_W > 0): see dyn_split
+    const int* m_dev = nullptr;
+};
+
 struct Workspace {
     int Bmax = 0;
     // activations, all [B*T, Cpad] float
@@ -82,6 +92,9 @@ struct Workspace {
     float* pose_a = nullptr;            // [B,T,J,3] gathered local poses / stage outputs
     float* pose_b = nullptr;
     float* splitk = nullptr;            // partial slabs of the split-K GEMM launches
+    bool defer_reduce = false;          // next launch_gemm: leave the slabs to the consumer, describe them in `deferred`
+    SlabSrc deferred;
+    SlabSrc grad_slab;                  // dE/dz of the current round as left by the decoder_input backward product
     size_t splitk_elems = 0;
     // active-window compaction (lbfgs.hip compact_kernel): windows still iterating occupy slots [0, n_active)
     int* perm = nullptr;                // [B] slot -> window
@@ -176,6 +189,15 @@ __host__ __device__ inline DynSplit dyn_split(int M, int BM, int CT, int W, int 
     d.slab = (size_t)d.RT * BM * ldc;
     return d;
 }
+__device__ inline void slab_layout(const SlabSrc& s, int& nslab, size_t& stride) {
+    nslab = s.nslab;
+    stride = s.stride;
+    if (s.dyn_W > 0) {
+        const DynSplit d = dyn_split(*s.m_dev, 64, s.CT, s.dyn_W, s.n_tiles, s.ldc);
+        nslab = d.SK;
+        stride = d.slab;
+    }
+}
 int launch_splitk_reduce(gem_handle* h, int epi, int nslab, size_t slab, const float* bias, const float* aux, float* C, int M, int N,
                          int ldc, const int* m_dev, hipStream_t s, int dyn_W = 0, int n_tiles = 0);
 // bf16-input MFMA variant of launch_gemm (gemm_bf16.hip): nprod = 1 (plain bf16) or 3 (hi/lo split, fp32-grade)
@@ -215,6 +237,8 @@ constexpr int TAIL_MAX_LAYERS = 6;
 struct TailLayerDev { const float* w4; const float* bias; int K, N; };
 struct TailArgs {
     int n, B, G, forward_only, escr, mask_first;
+    SlabSrc in_slab;         // a_in still lies in split-K slabs (+ in_bias, LeakyReLU to apply) when in_slab.base != nullptr
+    const float* in_bias;
     long long* dbg_ts;       // developer probe (tools/tail_bench): [32] {shader clock, 100 MHz wall clock} pairs of workgroup 0, or nullptr
     TailLayerDev fwd[TAIL_MAX_LAYERS], bwd[TAIL_MAX_LAYERS];
     const float* a_in;       // [B*T, K0] input activation of the first fused layer

@@ -360,6 +360,12 @@ static int launch_b(gem_handle* h, const Layer& L, const float* A, int lda, cons
                        grid.z == 1 ? n_tiles : per, grid.z == 1 ? (size_t)0 : slab, m_dev, row_map, dyn_W);
     GEM_HIP(hipGetLastError());
     if (grid.z == 1) return 0;
+    if (h->ws.defer_reduce) {                       // the consumer sums the slabs (and applies the epilogue) itself
+        SlabSrc& d = h->ws.deferred;
+        d.base = h->ws.splitk; d.nslab = (int)grid.z; d.stride = slab;
+        d.dyn_W = dyn_W; d.n_tiles = n_tiles; d.ldc = ldc; d.CT = L.N / 64; d.m_dev = m_dev;
+        return 0;
+    }
     return launch_splitk_reduce(h, EPI, (int)grid.z, slab, L.bias, aux, C, M, L.N, ldc, m_dev, s, dyn_W, n_tiles);
 }
 

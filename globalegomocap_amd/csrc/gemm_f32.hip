@@ -320,6 +320,12 @@ static int launch_one(gem_handle* h, const Layer& L, const float* A, int lda, co
     hipLaunchKernelGGL(k, grid, dim3(256), shmem, s, A, lda, L.w, L.bias, aux, h->ws.splitk, ldc, M, L.N, L.K, T, per, slab, m_dev,
                        row_map, dyn ? (int)wgs : 0);
     GEM_HIP(hipGetLastError());
+    if (h->ws.defer_reduce && BM == 64) {           // the consumer sums the slabs (and applies the epilogue) itself
+        SlabSrc& d = h->ws.deferred;
+        d.base = h->ws.splitk; d.nslab = (int)grid.z; d.stride = slab;
+        d.dyn_W = dyn ? (int)wgs : 0; d.n_tiles = n_tiles; d.ldc = ldc; d.CT = L.N / BN; d.m_dev = m_dev;
+        return 0;
+    }
     return launch_splitk_reduce(h, EPI, (int)grid.z, slab, L.bias, aux, C, M, L.N, ldc, m_dev, s, dyn ? (int)wgs : 0, n_tiles);
 }
 
@@ -345,6 +351,7 @@ int launch_gemm(gem_handle* h, const Layer& L, int epi, const float* A, int lda,
         return 1;
     }
     if (M <= 0) return 0;
+    h->ws.deferred = SlabSrc{};
     Profile::Rec rec;
     const bool prof = h->prof.on && family >= 0;
     if (prof) {

@@ -31,6 +31,7 @@ struct AdvArgs {
     const float* gnew;
     float *x, *d, *g, *gp, *bg0, *bg1, *trial, *S, *Y;
     const int* slot_of;       // window -> slot of its gradient row (nullptr: identity)
+    SlabSrc gslab;            // base != nullptr: the gradient rows still lie in split-K slabs (summed here, in slab order)
     int Dp, hist_cap;
     gem_lbfgs_opts o;
 };
@@ -160,7 +161,27 @@ __device__ __forceinline__ void lbfgs_advance_body(const AdvArgs& a) {
         for (int i = 0; i < EPT; ++i) { const float w = fabsf(u[i] * scale); p = (w > p || w != w) ? w : p; }
         return R.max((double)p);
     };
-    load(gsrc - off, gn);
+    if (a.gslab.base) {
+        int nslab;
+        size_t stride;
+        slab_layout(a.gslab, nslab, stride);
+        const float* gs = a.gslab.base + (size_t)(a.slot_of ? a.slot_of[b] : b) * Dp;
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) gn[i] = 0.f;
+        for (int z0 = 0; z0 < nslab; z0 += 4) {                 // four slabs in flight per trip
+            float t[4][EPT];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) load(gs + (size_t)min(z0 + k, nslab - 1) * stride - off, t[k]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (z0 + k < nslab) {
+#pragma unroll
+                    for (int i = 0; i < EPT; ++i) gn[i] += t[k][i];
+                }
+        }
+    } else {
+        load(gsrc - off, gn);
+    }
     // d and x are needed on every path but the very first evaluation: fetch them with the gradient instead of one
     // dependent round trip later
     if (phase != PH_INIT) { load(a.d, dv); load(a.x, xv); have_d = have_x = true; }
@@ -470,6 +491,7 @@ static AdvArgs make_args(gem_handle* h, const gem_lbfgs_opts& o) {
     a.state = w.state; a.f = w.f; a.gnew = w.dz;
     a.x = w.x; a.d = w.d; a.g = w.g; a.gp = w.gp; a.bg0 = w.bg0; a.bg1 = w.bg1; a.trial = w.trial; a.S = w.S; a.Y = w.Y;
     a.slot_of = w.dyn ? w.slot_of : nullptr;
+    a.gslab = w.dyn ? w.grad_slab : SlabSrc{};
     a.Dp = h->Dp; a.hist_cap = w.hist_cap; a.o = o;        // hist_cap: power of two (gem_create)
     return a;
 }

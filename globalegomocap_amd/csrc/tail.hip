@@ -170,21 +170,49 @@ __global__ __launch_bounds__(TAIL_THREADS, 2) void decoder_tail_kernel(TailArgs 
     const int R = nwin * T;                                  // valid rows
     const size_t row0 = (size_t)w0 * T;
 
-    // ---- stage the input activation rows: all of a thread's loads in flight before the first LDS store
+    // ---- stage the input activation rows: all of a thread's loads in flight before the first LDS store.  In the
+    // rounds the producer GEMM leaves its split-K slabs here: they are summed in slab order (bitwise what the reduce
+    // kernel would have written), bias and LeakyReLU applied on the way into LDS.
     {
         const int K0 = a.fwd[0].K, q4 = K0 / 4, n4 = TAIL_ROWS * q4;      // K0 <= 512: at most 4 float4 per thread
         float* dst = lds + a.off_act[0];
-        f32x4 v[4];
+        if (a.in_slab.base) {
+            int nslab;
+            size_t stride;
+            slab_layout(a.in_slab, nslab, stride);
+            for (int u = 0; u < 4; ++u) {
+                const int i = tid + u * TAIL_THREADS, r = i / q4, c = (i - r * q4) * 4;
+                if (i >= n4) break;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (r < R) {
+                    const float* p = a.in_slab.base + (row0 + r) * K0 + c;
+                    for (int z0 = 0; z0 < nslab; z0 += 8) {
+                        f32x4 t[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = tid + u * TAIL_THREADS, r = i / q4, c = (i - r * q4) * 4;
-            v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (i < n4 && r < R) v[u] = *reinterpret_cast<const f32x4*>(a.a_in + (row0 + r) * K0 + c);
-        }
+                        for (int k = 0; k < 8; ++k) t[k] = *reinterpret_cast<const f32x4*>(p + (size_t)min(z0 + k, nslab - 1) * stride);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = tid + u * TAIL_THREADS, r = i / q4, c = (i - r * q4) * 4;
-            if (i < n4) *reinterpret_cast<f32x4*>(dst + r * a.ld_act[0] + c) = v[u];
+                        for (int k = 0; k < 8; ++k)
+                            if (z0 + k < nslab) v += t[k];
+                    }
+                    v += *reinterpret_cast<const f32x4*>(a.in_bias + c);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : v[q] * LEAKY_SLOPE;
+                }
+                *reinterpret_cast<f32x4*>(dst + r * a.ld_act[0] + c) = v;
+            }
+        } else {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = tid + u * TAIL_THREADS, r = i / q4, c = (i - r * q4) * 4;
+                v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (i < n4 && r < R) v[u] = *reinterpret_cast<const f32x4*>(a.a_in + (row0 + r) * K0 + c);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = tid + u * TAIL_THREADS, r = i / q4, c = (i - r * q4) * 4;
+                if (i < n4) *reinterpret_cast<f32x4*>(dst + r * a.ld_act[0] + c) = v[u];
+            }
         }
         if (tid < 64) lds[a.off_zero + tid] = 0.f;            // the zero line the padded conv rows read
     }
