@@ -396,7 +396,8 @@ static EnergyArgs energy_args(gem_handle* h, const float* X0, const float* heat,
     return a;
 }
 
-static int evaluate(gem_handle* h, int stage, int B, const float* zp, const EnergyArgs& ea, hipStream_t s) {
+// forward_only: decode to w.dec_act.back() only (the final pose of a stage), same kernels
+static int evaluate(gem_handle* h, int stage, int B, const float* zp, const EnergyArgs& ea, hipStream_t s, bool forward_only = false) {
     StageNet& net = h->net[stage];
     Workspace& w = h->ws;
     // The fused tail trades throughput for latency (~60-80 us per workgroup whatever the batch): it wins while
@@ -408,6 +409,7 @@ static int evaluate(gem_handle* h, int stage, int B, const float* zp, const Ener
     const int tail_cap = h->n_cu;          // one workgroup per CU (the kernel's VGPR budget admits no second one)
     if (net.tail_start < 0 || (tail_wgs > tail_cap && !force_tail)) {
         if (decoder_forward(h, stage, B, zp, s)) return 1;
+        if (forward_only) return 0;
         if (launch_energy(h, ea, B, s)) return 1;
         return decoder_backward(h, stage, B, s, (int)net.dec.size() - 1, w.dXp);
     }
@@ -427,7 +429,7 @@ static int evaluate(gem_handle* h, int stage, int B, const float* zp, const Ener
     }
     TailArgs ta;
     plan_tail(net.dec, st, h->T, h->J, &ta);
-    ta.B = B; ta.forward_only = 0; ta.dbg_ts = nullptr;
+    ta.B = B; ta.forward_only = forward_only ? 1 : 0; ta.dbg_ts = nullptr;
     ta.in_slab = in_slab; ta.in_bias = st > 0 ? net.dec[st - 1].bias : nullptr;
     for (int i = 0; i < ta.n; ++i) {
         const Layer& f = net.dec[st + i];
@@ -435,9 +437,10 @@ static int evaluate(gem_handle* h, int stage, int B, const float* zp, const Ener
         ta.fwd[i] = TailLayerDev{f.w4, f.bias, f.K, f.N};
         ta.bwd[i] = TailLayerDev{g.w4, nullptr, g.K, g.N};
     }
-    ta.a_in = st > 0 ? w.dec_act[st - 1] : w.h0; ta.g_out = w.dec_grad[st]; ta.Xp = w.dyn ? nullptr : w.dec_act.back();     // the pose is only read back outside the rounds
+    ta.a_in = st > 0 ? w.dec_act[st - 1] : w.h0; ta.g_out = w.dec_grad[st]; ta.Xp = (w.dyn && !forward_only) ? nullptr : w.dec_act.back();     // the pose is only read back outside the rounds
     ta.e = ea;
     if (launch_tail(h, ta, net.tail_lds, s)) return 1;
+    if (forward_only) return 0;
     return decoder_backward(h, stage, B, s, st - 1, w.dec_grad[st]);
 }
 
@@ -470,8 +473,8 @@ static int optimize_stage_impl(gem_handle* h, int stage, int B, const float* d_p
     }
     w.dyn = false;
     if (rc) return 1;
-    // every window is finished now: trial == x*
-    if (decoder_forward(h, stage, B, w.trial, s)) return 1;
+    // every window is finished now: trial == x*; decode it with the same kernels as the rounds (all windows again)
+    if (evaluate(h, stage, B, w.trial, energy_args(h, d_pose_in, d_heat, d_frame0, d_mean_bone, wt), s, true)) return 1;
     if (launch_unpack_pose(w.dec_act.back(), d_pose_out, B * h->T, h->C, s)) return 1;
     if (d_stats && launch_lbfgs_stats(h, B, d_stats, s)) return 1;
     return 0;
