@@ -168,12 +168,12 @@ __device__ __forceinline__ void lbfgs_advance_body(const AdvArgs& a) {
         const float* gs = a.gslab.base + (size_t)(a.slot_of ? a.slot_of[b] : b) * Dp;
 #pragma unroll
         for (int i = 0; i < EPT; ++i) gn[i] = 0.f;
-        for (int z0 = 0; z0 < nslab; z0 += 4) {                 // four slabs in flight per trip
-            float t[4][EPT];
+        for (int z0 = 0; z0 < nslab; z0 += 8) {                 // eight slabs in flight per trip (the usual cut is 8)
+            float t[8][EPT];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) load(gs + (size_t)min(z0 + k, nslab - 1) * stride - off, t[k]);
+            for (int k = 0; k < 8; ++k) load(gs + (size_t)min(z0 + k, nslab - 1) * stride - off, t[k]);
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < 8; ++k)
                 if (z0 + k < nslab) {
 #pragma unroll
                     for (int i = 0; i < EPT; ++i) gn[i] += t[k][i];
