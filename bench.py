@@ -211,6 +211,34 @@ def main():
             other[mode] = (dt, g2.cpu().numpy() if rank == 0 else None)
         eng.set_precision("f32")
 
+    # ---- side measurement (not `value`): several sequences in flight on one GPU (BASELINE configs[2]'s regime): one engine
+    # and one HIP stream per sequence, the kernels of different sequences overlap on the device
+    in_flight = None
+    if a.precision == "f32" and not a.no_extra and world == 1 and a.workload == "seq2k":
+        in_flight = {}
+        engines = [eng]
+        for _ in range(2):
+            e2 = WindowEngine(shape, cam, max_windows=B)
+            e2.load_vae(LOCAL_STAGE, sd_local)
+            e2.load_vae(GLOBAL_STAGE, sd_global)
+            engines.append(e2)
+        streams = [torch.cuda.Stream() for _ in engines]
+        for n in (2, 3):
+            def multi():
+                for e, st_ in zip(engines[:n], streams[:n]):
+                    with torch.cuda.stream(st_):
+                        e.optimize_windows(seqd["est_local"], seqd["cams"], seqd["heat"], f0, mb_w, eps_l, eps_g, w_local, w_global,
+                                           want_stats=False)
+            multi()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(a.steps):
+                multi()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            in_flight[str(n)] = {"windows_per_s": round(B * n * a.steps / dt, 2), "ms_per_sequence": round(dt / (a.steps * n) * 1e3, 3)}
+        del engines[1:]
+
     if rank == 0:
         st = stats_to_numpy(stats)
         assert (st["status"] == 1).all(), "a window did not finish"
@@ -337,6 +365,7 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
             "other_precisions": other_modes or None,
+            "sequences_in_flight": in_flight,
         }
         print(json.dumps(line), flush=True)
     if world > 1:
