@@ -400,7 +400,7 @@ static EnergyArgs energy_args(gem_handle* h, const float* X0, const float* heat,
 static int evaluate(gem_handle* h, int stage, int B, const float* zp, const EnergyArgs& ea, hipStream_t s, bool forward_only = false) {
     StageNet& net = h->net[stage];
     Workspace& w = h->ws;
-    // The fused tail trades throughput for latency (~60-80 us per workgroup whatever the batch): it wins while
+    // The fused tail trades throughput for latency (~45 us per workgroup whatever the batch): it wins while
     // all its workgroups (one per 16/T windows) are resident at once; beyond that the batched GEMMs are faster
     // (8196 windows, bf16: 73 k vs 59 k windows/s).  GEM_FORCE_TAIL=1 keeps it on for any batch.
     static const bool force_tail = getenv("GEM_FORCE_TAIL") != nullptr;

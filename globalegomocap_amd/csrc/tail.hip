@@ -8,14 +8,15 @@
 // window per workgroup, so a 240-window round spreads over 240 CUs instead of piling 3 windows on each of 80):
 //
 //   a_in rows -> LDS;  for each fused layer:  act[i+1] = lrelu(conv3(act[i]) + b)   (v_mfma_f32_16x16x4_f32)
-//   X = act[n] -> energy terms + dE/dX per window (one wave per window, energy_device.h)
+//   X = act[n] -> energy terms + dE/dX per window (all eight waves when G = 1, else one wave per window; energy_device.h)
 //   backward-data through the same layers with the LeakyReLU' masks taken from the LDS activations
 //   -> gradient w.r.t. a_in written to HBM for the remaining (wide) backward layers.
 //
 // A operands come from LDS (rows are (window, frame); the k=3 conv reads rows t-1, t, t+1 of the same
-// window, zero outside).  B operands (weights) are read straight from L2 into registers: fp32 MFMA is
-// slow enough (64 cycles per instruction) that one coalesced 16-byte load per 4 MFMAs is free; the tail
-// weights are stored [tap][K/4][N][4] so that the 32 lanes of a half-wave read 512 contiguous bytes.
+// window; rows outside it read a zero line).  B operands (weights) are read straight from L2 into registers, one
+// k-block ahead; the tail weights are stored [tap][K/4][N][4] so that 16 lanes read 256 contiguous bytes.  Every
+// workgroup streams the same weights (1.3 MB per launch): with 30 workgroups per XCD the two 256<->128 layers run
+// at about half the MFMA rate, bound by L2 -> CU bandwidth; the 64-wide layers are latency chains of ~2 us.
 // Output tiles are 16x16 (v_mfma_f32_16x16x4_f32), wave w owns columns 16w..16w+15 (+128 per extra tile) with the
 // full K walk: a 128-wide layer is one tile per wave, a 64-wide layer keeps waves 0-3 busy.
 //
