@@ -308,11 +308,10 @@ int launch_errors(gem_handle* h, const double* est, const double* mid, const dou
         a.bone_mm[j] = j < h->J ? bone_mm[j] : 0.0;
     }
     const size_t lds = errors_frame_lds_bytes(h->J);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;
+    if (attr_once.need(h->cfg.device)) {
         GEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(errors_frame_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)errors_frame_lds_bytes(MAXJ_ERR)));
-        attr_set = true;
     }
     hipLaunchKernelGGL(errors_frame_kernel, dim3((unsigned)(((long)F * 6 + ERR_FT - 1) / ERR_FT)), dim3(ERR_FT), lds, s, a);
     GEM_HIP(hipGetLastError());

@@ -22,9 +22,9 @@ template <typename T>
 static int dev_alloc(std::vector<void*>& owner, T** p, size_t n) {
     void* q = nullptr;
     GEM_HIP(hipMalloc(&q, (n ? n : 1) * sizeof(T)));
-    GEM_HIP(hipMemset(q, 0, (n ? n : 1) * sizeof(T)));
-    owner.push_back(q);
+    owner.push_back(q);                 // owned from here on, whatever happens next
     *p = static_cast<T*>(q);
+    GEM_HIP(hipMemset(q, 0, (n ? n : 1) * sizeof(T)));
     return 0;
 }
 static void free_all(std::vector<void*>& owner) {
@@ -145,7 +145,7 @@ int gem_create(const gem_config* cfg, gem_handle** out) {
     }
     if (cfg->n_poly < 1 || cfg->n_poly > GEM_MAX_POLY || cfg->max_windows < 1) { set_error("gem_create: bad n_poly / max_windows"); return 1; }
     GEM_HIP(hipSetDevice(cfg->device));
-    std::unique_ptr<gem_handle> h(new gem_handle());
+    std::unique_ptr<gem_handle, void (*)(gem_handle*)> h(new gem_handle(), gem_destroy);     // frees the device memory on any early return
     h->cfg = *cfg;
     h->T = cfg->seq_len; h->J = cfg->n_joints; h->C = cfg->n_joints * 3; h->Cp = pad64(h->C);
     h->D = cfg->latent_dim; h->Dp = pad64(cfg->latent_dim);
@@ -242,6 +242,7 @@ int gem_load_vae(gem_handle* h, int stage, int n_blobs, const float* const* blob
         if (expect[i] != n_elem[i] || !blobs[i]) { set_error("gem_load_vae: size mismatch for blob " + std::to_string(i)); return 1; }
 
     StageNet& net = h->net[stage];
+    if (net.loaded) GEM_HIP(hipDeviceSynchronize());      // reloading: launches that still read the old weights must be done
     free_all(net.allocs);
     net = StageNet();
     int bi = 0;

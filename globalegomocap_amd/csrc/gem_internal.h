@@ -106,6 +106,13 @@ struct Workspace {
     std::vector<void*> allocs;
 };
 
+// "done once" flag per device ordinal: hipFuncSetAttribute is a per-device setting and a process may own handles on
+// several devices (one thread per handle; a handle itself is not thread-safe)
+struct PerDeviceOnce {
+    bool done[64] = {};
+    bool need(int dev) { if (dev < 0 || dev >= 64) return true; if (done[dev]) return false; done[dev] = true; return true; }
+};
+
 struct Profile {
     bool on = false;
     struct Rec { hipEvent_t a, b; int family; double flops; long log_idx = -1; double flops_per_window = 0; };

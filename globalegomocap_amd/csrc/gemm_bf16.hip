@@ -326,10 +326,9 @@ static int launch_b(gem_handle* h, const Layer& L, const float* A, int lda, cons
     if (L.N % 128 == 0 && ((force && force[0] == '2') || (!(force && force[0] == '1') && big_blocks >= 256))) {
         auto kb = gemm_bf16_big_kernel<TAPS, EPI, NPROD>;
         const size_t smem = (size_t)(NPROD == 3 ? 4 : 2) * 128 * (BK + 8) * sizeof(unsigned short);
-        static bool big_attr = false;
-        if (!big_attr) {
+        static PerDeviceOnce big_once;
+        if (big_once.need(h->cfg.device)) {
             GEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            big_attr = true;
         }
         hipLaunchKernelGGL(kb, dim3(L.N / 128, (M + 127) / 128, 1), dim3(256), smem, s, A, lda, L.wb_hi, L.wb_lo, L.bias, aux, C, ldc,
                            M, L.N, L.K, T, m_dev, row_map);
@@ -338,10 +337,9 @@ static int launch_b(gem_handle* h, const Layer& L, const float* A, int lda, cons
     }
     size_t shmem = (size_t)(NPROD == 3 ? 4 : 2) * 64 * (BK + 8) * sizeof(unsigned short);
     auto k = gemm_bf16_kernel<TAPS, EPI, NPROD>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;
+    if (attr_once.need(h->cfg.device)) {
         GEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
     }
     const int n_tiles = TAPS * (L.K / BK);
     dim3 grid(L.N / 64, (M + 63) / 64, 1);

@@ -291,10 +291,9 @@ static int launch_one(gem_handle* h, const Layer& L, const float* A, int lda, co
     constexpr int BM = 64 * RM, BN = 64 * RN;
     size_t shmem = (RM * RN > 1 ? 2 : 1) * (size_t)(BM + BN) * (BK + 4) * sizeof(float);
     auto k = gemm_f32_kernel<TAPS, EPI, RM, RN, TAG, BK>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;
+    if (attr_once.need(h->cfg.device)) {
         GEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_PER_CU));
-        attr_set = true;
     }
     const int n_tiles = TAPS * (L.K / BK);
     dim3 grid(L.N / BN, (M + BM - 1) / BM, 1);

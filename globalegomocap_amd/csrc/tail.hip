@@ -324,11 +324,10 @@ size_t plan_tail(const std::vector<Layer>& dec, int start, int T, int J, TailArg
 }
 
 int launch_tail(gem_handle* h, const TailArgs& a, size_t lds_bytes, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;
+    if (attr_once.need(h->cfg.device)) {
         GEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024));
-        attr_set = true;
     }
     Profile::Rec rec;
     const bool prof = h->prof.on;
