@@ -666,3 +666,39 @@ def test_zero_weights_stop_at_the_first_evaluation_and_return_the_decoded_start(
     np.testing.assert_allclose(out.cpu().numpy(), eng.decode(0, z0).cpu().numpy(), rtol=0, atol=2e-6)
     one, s1 = eng.optimize_stage(0, poses[:1], mb, eps[:1], _ew((0, 0, 0, 0, 0)))
     np.testing.assert_allclose(one.cpu().numpy(), out[:1].cpu().numpy(), rtol=0, atol=2e-6)
+
+
+def test_mid_size_batch_runs_the_fused_tail_in_several_waves(torch_cuda):
+    """300..1280 windows: more tail workgroups than CUs.  One evaluation against the same windows in a small batch, and a
+    whole stage whose duplicated windows (first 40 = last 40, i.e. different workgroup waves) must agree bitwise."""
+    import torch
+    from globalegomocap_amd.engine import stats_to_numpy
+    sd = vae_schema.synthetic_state_dict(FULL, 5)
+    B, n_dup = 300, 40
+    eng = _engine(FULL, max_windows=B)
+    eng.load_vae(0, sd)
+    seq = synth.make_sequence_device(400, seed=78, device=eng.device)
+    rng = np.random.default_rng(11)
+    starts = rng.integers(0, 390, B).astype(np.int32)
+    starts[B - n_dup:] = starts[:n_dup]
+    est = seq["est_local_np"].astype(np.float32)
+    pose = np.stack([est[s:s + 10] for s in starts])
+    mb = eng.mean_bone_length(est[:100])
+    eps = rng.normal(size=(B, 2048)).astype(np.float32)
+    eps[B - n_dup:] = eps[:n_dup]
+    w = _ew((1e-1, 1e-1, 1.0, 1e-3, 1e-2))
+    _, _, z0 = eng.encode(0, pose.reshape(B, 10, 45), eps)
+    E, parts, dz, X = eng.energy_grad(0, z0, pose, mb, w, seq["heat"], starts)
+    small = _engine(FULL, max_windows=64)
+    small.load_vae(0, sd)
+    Es, _, dzs, Xs = small.energy_grad(0, z0[:64], pose[:64], mb, w, seq["heat"], starts[:64])
+    np.testing.assert_allclose(X[:64].cpu().numpy(), Xs.cpu().numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(E[:64].cpu().numpy(), Es.cpu().numpy(), rtol=2e-5)
+    assert np.abs((dz[:64] - dzs).cpu().numpy()).max() <= 2e-3 * np.abs(dzs.cpu().numpy()).max()
+    assert torch.equal(X[:n_dup], X[B - n_dup:]) and torch.equal(dz[:n_dup], dz[B - n_dup:])
+    out, stats = eng.optimize_stage(0, pose, mb, eps, w, seq["heat"], starts)
+    st = stats_to_numpy(stats)
+    assert (st["status"] == 1).all() and st["func_evals"].mean() > 20
+    assert torch.equal(out[:n_dup], out[B - n_dup:]) and torch.equal(stats[:n_dup], stats[B - n_dup:])
+    assert (st["final_loss"] <= E.cpu().numpy().astype(np.float32) * (1 + 1e-6) + 1e-6).all()
+    assert np.isfinite(out.cpu().numpy()).all()
