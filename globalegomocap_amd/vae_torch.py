@@ -93,3 +93,35 @@ def fit_vae(shape, windows, steps=2000, batch=128, lr=2e-3, kl_weight=0.01, seed
         sd["fc_mu.weight"], sd["fc_mu.bias"] = sd["fc_mu.weight"] / g, sd["fc_mu.bias"] / g
         sd["fc_var.bias"] = sd["fc_var.bias"] - 2.0 * float(np.log(g))
     return sd, err
+
+
+def _cli():
+    """Fit the two motion VAEs on synthetic motion and write them where the reference looks for its checkpoints
+    (`optimizer.py:334,344`, schema of `networks/train.py:102-108`), so that `main()` / `whole_sequence` run end to end
+    without the external weight download.  Accuracy experiments only: real weights come from the authors."""
+    import argparse
+    import os
+    from . import synth, vae as V
+    from .optimizer import GLOBAL_VAE_PATH, LOCAL_VAE_PATH
+    p = argparse.ArgumentParser(description=_cli.__doc__)
+    p.add_argument("--root", default=".", help="directory the relative checkpoint paths are resolved against")
+    p.add_argument("--steps", type=int, default=2000)
+    p.add_argument("--latent_dim", type=int, default=2048)
+    p.add_argument("--seed", type=int, default=101)
+    a = p.parse_args()
+    shape = V.VAEShape(latent_dim=a.latent_dim)
+    for path, relative, seed in ((LOCAL_VAE_PATH, False, a.seed), (GLOBAL_VAE_PATH, True, a.seed + 1)):
+        windows = synth.make_training_windows(4096, shape.seq_len, seed)
+        if relative:        # relative-global poses drift with the camera: 4 mm / frame along x (synth.make_sequence)
+            windows = windows.reshape(-1, shape.seq_len, 15, 3).copy()
+            windows[..., 0] += (0.004 * np.arange(shape.seq_len))[None, :, None]
+            windows = windows.reshape(-1, shape.seq_len, 45)
+        sd, err = fit_vae(shape, windows, steps=a.steps, seed=seed, latent_gain=8.0)
+        out = os.path.join(a.root, path)
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        V.save_checkpoint(out, sd)
+        print("%s: reconstruction %.1f mm -> %s" % ("global" if relative else "local", err * 1e3, out))
+
+
+if __name__ == "__main__":
+    _cli()
