@@ -349,7 +349,7 @@ static int launch_b(gem_handle* h, const Layer& L, const float* A, int lda, cons
     grid.z = (n_tiles + per - 1) / per;
     const long wgs = (long)grid.x * grid.y * grid.z, per_cu = (wgs + 255) / 256;
     if (per_cu <= 8) {
-        const size_t want = ((size_t)160 * 1024 / per_cu) & ~(size_t)1023;
+        const size_t want = (((size_t)160 * 1024 - 8192) / per_cu) & ~(size_t)1023;      // see gemm_f32.hip
         if (want > shmem) shmem = want;
     }
     float* out = grid.z == 1 ? C : h->ws.splitk;

@@ -26,6 +26,16 @@ typedef int i32x8 __attribute__((ext_vector_type(8)));        // per-thread row 
 
 constexpr int BK_MIN = 32;      // K padding granularity
 
+#ifdef GEM_TRACE
+// tools/gemm_bench.hip only: per-workgroup {start, first MFMA possible, loop end, end} on the 100 MHz wall clock
+__device__ long long* g_gemm_trace = nullptr;
+#define GEM_TRACE_MARK(slot_)                                                                            \
+    if (g_gemm_trace && threadIdx.x == 0)                                                                \
+        g_gemm_trace[4 * (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) + (slot_)] = wall_clock64();
+#else
+#define GEM_TRACE_MARK(slot_)
+#endif
+
 template <int TAPS, int EPI, int RM, int RN, int TAG, int BK>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, int lda,
                                                        const float* __restrict__ W,
@@ -46,6 +56,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
+    GEM_TRACE_MARK(0);
     int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     if (m_dev) M = *m_dev;                 // rows in use this round (active windows are compacted to the front)
     const int kTiles = K / BK;
@@ -131,6 +142,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     GEM_LOAD_TILE(kt_begin);
     GEM_STORE_TILE(0);
     __syncthreads();
+    GEM_TRACE_MARK(1);
     int cur = 0;
 #ifndef GEM_ABLATE
 #define GEM_ABLATE 0
@@ -193,6 +205,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     }
 #undef GEM_LOAD_TILE
 #undef GEM_STORE_TILE
+    GEM_TRACE_MARK(2);
 
     // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
@@ -213,6 +226,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                 }
             }
         }
+    GEM_TRACE_MARK(3);
 }
 
 // sums the split-K slabs and applies the epilogue: C = epi(sum_z slab[z] + bias)
@@ -305,7 +319,9 @@ static int launch_one(gem_handle* h, const Layer& L, const float* A, int lda, co
     const long wgs = (long)grid.x * grid.y * grid.z;
     const long per_cu = (wgs + N_CU - 1) / N_CU;
     if (per_cu <= 8) {
-        const size_t want = ((size_t)LDS_PER_CU / per_cu) & ~(size_t)1023;
+        // (a few KB below the even share: exactly 160 KB / per_cu each did NOT fit per_cu workgroups -- the stragglers
+        // ran as a second wave, see tools/gemm_trace.hip)
+        const size_t want = (((size_t)LDS_PER_CU - 8192) / per_cu) & ~(size_t)1023;
         if (want > shmem) shmem = want;
     }
     // evaluation rounds on small batches: slices re-cut on the device for the rows that are still active
