@@ -269,6 +269,8 @@ constexpr int N_CU = 256;
 constexpr int LDS_PER_CU = 160 * 1024;
 int pick_splitk(const gem_handle* h, long blocks, int n_tiles, size_t slab_elems) {
     if (!h->ws.splitk || blocks >= 3 * N_CU) return 1;
+    static const int force = getenv("GEM_FORCE_SK") ? atoi(getenv("GEM_FORCE_SK")) : 0;      // developer override (sweeps)
+    if (force > 0 && n_tiles / force >= 4 && (size_t)force * slab_elems <= h->ws.splitk_elems) return force;
     int best = 1;
     double best_score = -1.0;
     for (int sk = 1; sk <= 8; ++sk) {
