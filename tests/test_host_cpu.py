@@ -158,3 +158,32 @@ def test_chunk_listing_and_background_reader(tmp_path):
         pickle.dump({"estimated_local_skeleton": []}, f)
     with pytest.raises(KeyError):                      # a broken chunk surfaces in the consumer, like the reference's KeyError
         list(ws.ChunkStream(ws.list_chunks(str(tmp_path))))
+
+
+def test_slam_trajectory_conversion_against_reference_golden(golden):
+    """MakeDataForOptimization/slam_reader.py: frame selection, relative poses, scaled translation (golden from the
+    reference's read_trajectory) and the Umeyama scale of read_trajectory_new on a trajectory with a known scale."""
+    from globalegomocap_amd import slam
+    g = golden("slam")
+    lines = [" ".join("%.9f" % v for v in r) for r in g["rows"]]
+    for tag in ("a", "b", "c"):
+        a, b, scale = g["range_" + tag]
+        t, q = slam.parse_trajectory(lines, int(a), int(b))
+        mats = np.asarray(slam.scaled_trajectory(t, q, float(scale)))
+        assert mats.shape == g["mats_" + tag].shape
+        np.testing.assert_allclose(mats, g["mats_" + tag], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(mats[0], np.eye(4), atol=1e-12)
+    # known scale: ground-truth head = 1.8 x (SLAM head), rotated and shifted
+    t, q = slam.parse_trajectory(lines, 0, 40)
+    rt, rq = slam.relative_poses(t, q)
+    rng = np.random.default_rng(1)
+    local = rng.normal(0, 0.2, (40, 15, 3))
+    head = np.stack([slam.pose_matrix(a, b)[:3, :3] @ local[i, 0] + a for i, (a, b) in enumerate(zip(rt, rq))])
+    Rz = np.array([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])
+    gt = np.zeros((40, 15, 3))
+    gt[:, 0] = 1.8 * head @ Rz + np.array([0.3, -0.1, 2.0])
+    mats, R1, t1 = slam.camera_pose_list(lines, local, gt, 0, 40)
+    for i in range(40):
+        np.testing.assert_allclose(mats[i][:3, 3], 1.8 * rt[i], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(mats[i][:3, :3], slam.pose_matrix(rt[i], rq[i])[:3, :3], atol=1e-12)
+    np.testing.assert_allclose(gt[:, 0] @ R1 / 1.8 + t1, head, atol=1e-9)
