@@ -120,18 +120,26 @@ def _batches(stream, chunks_per_batch):
         yield batch
 
 
-def optimize_directory(data_dir, camera_model_path, vae_weight=0.0, gmm_weight=0.0, smoothness_weight=0.001,
+def optimize_sequences(data_dirs, camera_model_path, vae_weight=0.0, gmm_weight=0.0, smoothness_weight=0.001,
                        bone_length_weight=0.01, weight_3d=0.01, reproj_weight=0.01, final_smooth=True, merge=True,
                        global_vae_path=GLOBAL_VAE_PATH, local_vae_path=LOCAL_VAE_PATH, chunks_per_batch=None, optimizer=None,
                        device_metrics=True, verbose=True, seq_len=SEQ_LEN, overlap=OVERLAP):
-    """Returns (summary OrderedDict, per-chunk error dicts, estimated_pose, optimized_pose, gt_pose) -- the three pose
-    lists are the concatenations `optimize_whole_sequence.py:65-67` builds."""
+    """Several sequences in ONE batched device call (BASELINE configs[2]: all test sequences concurrently on one GPU):
+    the chunks of every directory of `data_dirs` go through the optimiser together, the reports are per sequence.
+    Returns a list of (summary, per-chunk error dicts, estimated_pose, optimized_pose, gt_pose), one per directory, each
+    exactly what `optimize_directory` returns; the noise is drawn sequence by sequence, chunk by chunk."""
     del gmm_weight, merge                       # accepted and unused, as in the reference (SURVEY D4)
-    paths = list_chunks(data_dir)
-    if not paths:
-        raise FileNotFoundError("no chunk directories under %s" % data_dir)
+    paths, group_of = [], {}
+    for gi, d in enumerate(data_dirs):
+        ps = list_chunks(d)
+        if not ps:
+            raise FileNotFoundError("no chunk directories under %s" % d)
+        for q in ps:
+            group_of[q] = gi
+        paths += ps
+    n_groups = len(data_dirs)
     opt = optimizer
-    results, est_all, opt_all, gt_all = [], [], [], []
+    results, est_all, opt_all, gt_all = ([[] for _ in range(n_groups)] for _ in range(4))
     device = torch.device("cuda", torch.cuda.current_device())
     for batch in _batches(ChunkStream(paths, device=device), chunks_per_batch):
         starts, chunk_of, bounds, f_off, eps = [], [], [], 0, []
@@ -183,19 +191,33 @@ def optimize_directory(data_dir, camera_model_path, vae_weight=0.0, gmm_weight=0
                 if final_smooth:
                     opt_seq = _smooth(opt_seq)
                 res = calculate_errors(est_seq, mid_seq, opt_seq, gt_seq)
-            results.append(res)
-            est_all.extend(list(est_seq)); opt_all.extend(list(opt_seq)); gt_all.extend(list(gt_seq))
+            gi = group_of[c["path"]]
+            results[gi].append(res)
+            est_all[gi].extend(list(est_seq)); opt_all[gi].extend(list(opt_seq)); gt_all[gi].extend(list(gt_seq))
             if verbose and res["bone_length_aligned_optimized_mpjpe"] > res["bone_length_aligned_mid_optimized_mpjpe"]:
                 print(res)
-    summary = OrderedDict()
-    for k in results[0]:
-        summary[k] = np.mean([r[k] for r in results], axis=0) if k == "joints_error" else float(np.average([r[k] for r in results]))
-    if verbose:
-        for line in SUMMARY_LINES:
-            print("-----------------------------------------" if line is None else "{}: {}".format(line[0], summary[line[1]]))
-        print("joints error is: {}".format(summary["joints_error"]))
-        print("-------------------------------------------------------------")
-    return summary, results, est_all, opt_all, gt_all
+    out = []
+    for gi in range(n_groups):
+        summary = OrderedDict()
+        for k in results[gi][0]:
+            summary[k] = (np.mean([r[k] for r in results[gi]], axis=0) if k == "joints_error"
+                          else float(np.average([r[k] for r in results[gi]])))
+        if verbose:
+            if n_groups > 1:
+                print("sequence: {}".format(data_dirs[gi]))
+            for line in SUMMARY_LINES:
+                print("-----------------------------------------" if line is None else "{}: {}".format(line[0], summary[line[1]]))
+            print("joints error is: {}".format(summary["joints_error"]))
+            print("-------------------------------------------------------------")
+        out.append((summary, results[gi], est_all[gi], opt_all[gi], gt_all[gi]))
+    return out
+
+
+def optimize_directory(data_dir, camera_model_path, *args, **kwargs):
+    """One sequence = the reference's `optimize_whole_sequence.py`.  Returns (summary OrderedDict, per-chunk error
+    dicts, estimated_pose, optimized_pose, gt_pose) -- the three pose lists are the concatenations
+    `optimize_whole_sequence.py:65-67` builds.  Arguments as `optimize_sequences`."""
+    return optimize_sequences([data_dir], camera_model_path, *args, **kwargs)[0]
 
 
 def _cli():

@@ -207,3 +207,36 @@ def test_whole_sequence_driver_matches_per_chunk_main(golden, tmp_path, capsys):
     s2 = ws.optimize_directory(str(tmp_path), DEFAULT_CALIBRATION, chunks_per_batch=2, device_metrics=False, verbose=False, **kw)[0]
     for k in summary:
         np.testing.assert_allclose(s2[k], summary[k], rtol=0, atol=0.5e-3, err_msg=k)
+
+
+def test_several_sequences_in_one_batch_match_sequence_by_sequence_runs(golden, tmp_path):
+    """BASELINE configs[2] regime: the chunks of several sequences through the optimiser together; per-sequence reports
+    must be those of running the sequences one after the other (same noise stream)."""
+    import pickle
+    import torch
+    from globalegomocap_amd import whole_sequence as ws
+    from helpers import sd_from_npz
+    lt = golden("lbfgs_tiny")
+    kw = dict(global_vae_path=sd_from_npz(lt, "global/"), local_vae_path=sd_from_npz(lt, "local/"), verbose=False)
+    dirs = []
+    for s, chunks in (("seqA", ((1, 100), (2, 60))), ("seqB", ((1, 100),)), ("seqC", ((1, 40), (2, 100), (3, 100)))):
+        root = tmp_path / s
+        root.mkdir()
+        dirs.append(str(root))
+        for i, n in chunks:
+            d = root / ("chunk_%d" % i)
+            d.mkdir()
+            data = synth.make_sequence(n_frames=n, seed=100 * (ord(s[-1]) - ord("A")) + i)
+            with open(d / "test_data.pkl", "wb") as f:
+                pickle.dump({k: data[k] for k in ("estimated_local_skeleton", "gt_global_skeleton", "camera_pose_list", "heatmap_list")}, f)
+    torch.manual_seed(5)
+    one_by_one = [ws.optimize_directory(d, DEFAULT_CALIBRATION, **kw) for d in dirs]
+    torch.manual_seed(5)
+    together = ws.optimize_sequences(dirs, DEFAULT_CALIBRATION, **kw)
+    assert len(together) == 3
+    for a, b in zip(one_by_one, together):
+        assert len(a[1]) == len(b[1]) and len(a[3]) == len(b[3])
+        assert np.linalg.norm(np.asarray(a[3]) - np.asarray(b[3]), axis=-1).mean() < 0.5e-3
+        for k in a[0]:
+            tol = 1e-9 if k.startswith("original") or k in ("aligned_original_mpjpe", "bone_length_aligned_original_mpjpe") else 0.5e-3
+            np.testing.assert_allclose(b[0][k], a[0][k], rtol=0, atol=tol, err_msg=k)
