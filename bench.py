@@ -37,8 +37,8 @@ CAM_JITTER = (0.3, 0.002)           # SLAM-like camera noise: 0.3 deg, 2 mm per 
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=10)
-    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--steps", type=int, default=50)
+    p.add_argument("--warmup", type=int, default=10)
     p.add_argument("--workload", default="seq2k", help="seq2k (20 chunks, 240 windows) | w8192 | <number of chunks>")
     p.add_argument("--fit-steps", type=int, default=2000, help="Adam steps to fit the synthetic VAEs (untimed)")
     p.add_argument("--cpu-windows", type=int, default=12, help="windows of the CPU baseline sample (0 = skip)")
