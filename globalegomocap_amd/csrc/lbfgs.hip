@@ -85,7 +85,8 @@ struct BlockRed {
     }
 };
 
-template <int EPT, int NT>
+// FULL: Dp == EPT * NT exactly (D = 2048 with 8 x 256): no bounds predicate around the strip loads / stores
+template <int EPT, int NT, bool FULL>
 __device__ __forceinline__ void lbfgs_advance_body(const AdvArgs& a) {
     __shared__ double red[8];
     __shared__ double ro_s[MAX_HIST];
@@ -123,12 +124,12 @@ __device__ __forceinline__ void lbfgs_advance_body(const AdvArgs& a) {
             for (int i = 0; i < EPT / 4; ++i) {
                 const int e = (tid + NT * i) * 4;
                 f32x4 w = {0.f, 0.f, 0.f, 0.f};
-                if (e < Dp) w = *reinterpret_cast<const f32x4*>(p + off + e);
+                if (FULL || e < Dp) w = *reinterpret_cast<const f32x4*>(p + off + e);
                 v[4 * i] = w[0]; v[4 * i + 1] = w[1]; v[4 * i + 2] = w[2]; v[4 * i + 3] = w[3];
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < EPT; ++i) { const int e = tid + NT * i; v[i] = e < Dp ? p[off + e] : 0.f; }
+            for (int i = 0; i < EPT; ++i) { const int e = tid + NT * i; v[i] = (FULL || e < Dp) ? p[off + e] : 0.f; }
         }
     };
     auto store = [&](float* p, const float (&v)[EPT]) {
@@ -137,11 +138,11 @@ __device__ __forceinline__ void lbfgs_advance_body(const AdvArgs& a) {
             for (int i = 0; i < EPT / 4; ++i) {
                 const int e = (tid + NT * i) * 4;
                 const f32x4 w = {v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
-                if (e < Dp) *reinterpret_cast<f32x4*>(p + off + e) = w;
+                if (FULL || e < Dp) *reinterpret_cast<f32x4*>(p + off + e) = w;
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < EPT; ++i) { const int e = tid + NT * i; if (e < Dp) p[off + e] = v[i]; }
+            for (int i = 0; i < EPT; ++i) { const int e = tid + NT * i; if (FULL || e < Dp) p[off + e] = v[i]; }
         }
     };
     auto copy = [&](float* dst, const float* src) {
@@ -460,8 +461,8 @@ __device__ __forceinline__ void lbfgs_advance_body(const AdvArgs& a) {
     }
 }
 
-template <int EPT>
-__global__ __launch_bounds__(256) void lbfgs_advance_kernel(AdvArgs a) { lbfgs_advance_body<EPT, 256>(a); }
+template <int EPT, bool FULL>
+__global__ __launch_bounds__(256) void lbfgs_advance_kernel(AdvArgs a) { lbfgs_advance_body<EPT, 256, FULL>(a); }
 
 __global__ void lbfgs_init_kernel(LbfgsState* st, const float* __restrict__ trial, float* __restrict__ x, int B, int Dp) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -515,11 +516,12 @@ int launch_lbfgs_advance(gem_handle* h, int B, const gem_lbfgs_opts& o, hipStrea
         GEM_HIP(hipEventRecord(rec.a, s));
     }
     const int ept = (h->Dp + 255) / 256;
-    if (ept <= 1) hipLaunchKernelGGL(lbfgs_advance_kernel<1>, dim3(B), dim3(256), 0, s, a);
-    else if (ept <= 2) hipLaunchKernelGGL(lbfgs_advance_kernel<2>, dim3(B), dim3(256), 0, s, a);
-    else if (ept <= 4) hipLaunchKernelGGL(lbfgs_advance_kernel<4>, dim3(B), dim3(256), 0, s, a);
-    else if (ept <= 8) hipLaunchKernelGGL(lbfgs_advance_kernel<8>, dim3(B), dim3(256), 0, s, a);
-    else if (ept <= 16) hipLaunchKernelGGL(lbfgs_advance_kernel<16>, dim3(B), dim3(256), 0, s, a);
+    if (ept <= 1) hipLaunchKernelGGL((lbfgs_advance_kernel<1, false>), dim3(B), dim3(256), 0, s, a);
+    else if (ept <= 2) hipLaunchKernelGGL((lbfgs_advance_kernel<2, false>), dim3(B), dim3(256), 0, s, a);
+    else if (ept <= 4) hipLaunchKernelGGL((lbfgs_advance_kernel<4, false>), dim3(B), dim3(256), 0, s, a);
+    else if (h->Dp == 2048) hipLaunchKernelGGL((lbfgs_advance_kernel<8, true>), dim3(B), dim3(256), 0, s, a);       // the reference's latent size
+    else if (ept <= 8) hipLaunchKernelGGL((lbfgs_advance_kernel<8, false>), dim3(B), dim3(256), 0, s, a);
+    else if (ept <= 16) hipLaunchKernelGGL((lbfgs_advance_kernel<16, false>), dim3(B), dim3(256), 0, s, a);
     else { set_error("latent_dim > 4096 is not supported by the L-BFGS kernel"); return 1; }
     GEM_HIP(hipGetLastError());
     if (prof) { GEM_HIP(hipEventRecord(rec.b, s)); h->prof.recs.push_back(rec); }
