@@ -128,8 +128,10 @@ struct Profile {
 template <int CTRL>
 __device__ __forceinline__ double dpp_move(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    // (mov_dpp = update_dpp with an undefined "old" operand: every lane has a valid source for these permutes, and the
+    // compiler does not have to copy the source into the destination first)
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double read_lane(double v, int lane) {
