@@ -58,6 +58,7 @@ struct alignas(16) LbfgsState {
     double t_prev, f_prev, gtd_prev;
     double br_t[2], br_f[2], br_gtd[2];
     double ro[MAX_HIST];
+    double cadj[MAX_HIST];     // s_k . y_(k+1) of ring slot k (the next newer pair): lets the two-loop recursion take two pairs per reduction
 };
 
 // Where a split-K GEMM left its partial slabs for a consumer that sums them itself (the fused tail stages the wide

@@ -63,33 +63,46 @@ __device__ __forceinline__ double cubic_interpolate(double x1, double f1, double
 // reduction cannot overwrite values a slow wave has not read yet (a slot is reused two barriers later).
 template <int NT>
 struct BlockRed {
-    double* red;      // [2][4]
+    double* red;      // [2][4][3]
     int parity;
     __device__ __forceinline__ double sum(double v) {
-        v = wave_sum_dpp(v);
-        if (NT == 64) return v;
-        double* r = red + 4 * parity;
+        double w[1] = {v};
+        sumN<1>(w);
+        return w[0];
+    }
+    // N sums with ONE barrier (independent DPP chains overlap)
+    template <int N>
+    __device__ __forceinline__ void sumN(double (&v)[N]) {
+#pragma unroll
+        for (int n = 0; n < N; ++n) v[n] = wave_sum_dpp(v[n]);
+        if (NT == 64) return;
+        double* r = red + 12 * parity;
         parity ^= 1;
-        if ((threadIdx.x & 63) == 0) r[threadIdx.x >> 6] = v;
+        if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+            for (int n = 0; n < N; ++n) r[(threadIdx.x >> 6) * 3 + n] = v[n];
+        }
         __syncthreads();
-        return r[0] + r[1] + r[2] + r[3];
+#pragma unroll
+        for (int n = 0; n < N; ++n) v[n] = r[n] + r[3 + n] + r[6 + n] + r[9 + n];
     }
     __device__ __forceinline__ double max(double v) {
         v = wave_max_dpp(v);
         if (NT == 64) return v;
-        double* r = red + 4 * parity;
+        double* r = red + 12 * parity;
         parity ^= 1;
-        if ((threadIdx.x & 63) == 0) r[threadIdx.x >> 6] = v;
+        if ((threadIdx.x & 63) == 0) r[(threadIdx.x >> 6) * 3] = v;
         __syncthreads();
-        return nan_max(nan_max(nan_max(r[0], r[1]), r[2]), r[3]);
+        return nan_max(nan_max(nan_max(r[0], r[3]), r[6]), r[9]);
     }
 };
 
 // FULL: Dp == EPT * NT exactly (D = 2048 with 8 x 256): no bounds predicate around the strip loads / stores
 template <int EPT, int NT, bool FULL>
 __device__ __forceinline__ void lbfgs_advance_body(const AdvArgs& a) {
-    __shared__ double red[8];
+    __shared__ double red[24];
     __shared__ double ro_s[MAX_HIST];
+    __shared__ double cadj_s[MAX_HIST];
     __shared__ double al_s[MAX_HIST];
     const int b = blockIdx.x, tid = threadIdx.x;
     LbfgsState* sp = a.state + b;
@@ -108,7 +121,7 @@ __device__ __forceinline__ void lbfgs_advance_body(const AdvArgs& a) {
     double t_prev = sp->t_prev, f_prev = sp->f_prev, gtd_prev = sp->gtd_prev;
     double br_t[2] = {sp->br_t[0], sp->br_t[1]}, br_f[2] = {sp->br_f[0], sp->br_f[1]};
     double br_gtd[2] = {sp->br_gtd[0], sp->br_gtd[1]};
-    for (int i = tid; i < a.hist_cap; i += NT) ro_s[i] = sp->ro[i];
+    for (int i = tid; i < a.hist_cap; i += NT) { ro_s[i] = sp->ro[i]; cadj_s[i] = sp->cadj[i]; }
     __syncthreads();
 
     const double f_new = a.f[b];
@@ -331,9 +344,30 @@ __device__ __forceinline__ void lbfgs_advance_body(const AdvArgs& a) {
             H_diag = 1.0;
         } else {
             (void)have_ys;
-            const double ys = dot(yv, sv);
+            auto pair_ptr = [&](const float* base, int k) {
+                const int slot = (hist_start + k) & hmask;
+                return base + ((size_t)b * a.hist_cap + slot) * Dp - off;
+            };
+            // y.s, y.y and (for the pairwise two-loop below) s_prev.y of the newest stored pair, in ONE reduction
+            float sprev[EPT];
+            const bool has_prev = hist_count >= 1;
+            if (has_prev) load(pair_ptr(a.S, hist_count - 1), sprev);
+            double r3[3] = {0.0, 0.0, 0.0};
+            {
+                float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < EPT; ++i) {
+                    p0 += yv[i] * sv[i];
+                    p1 += yv[i] * yv[i];
+                    if (has_prev) p2 += sprev[i] * yv[i];
+                }
+                r3[0] = (double)p0; r3[1] = (double)p1; r3[2] = (double)p2;
+            }
+            R.template sumN<3>(r3);
+            const double ys = r3[0];
             const int limit = o.history < a.hist_cap ? o.history : a.hist_cap;
             if (ys > 1e-10) {
+                const int prev_slot = (hist_start + hist_count - 1) & hmask;      // (the newest pair keeps its slot when the oldest goes)
                 if (hist_count == limit) {          // shift history by one (limited memory)
                     hist_start = (hist_start + 1) & hmask;
                     hist_count--;
@@ -343,66 +377,85 @@ __device__ __forceinline__ void lbfgs_advance_body(const AdvArgs& a) {
                 float* Ss = a.S + ((size_t)b * a.hist_cap + slot) * Dp - off;
                 store(Ys, yv);
                 store(Ss, sv);
+                const bool link = has_prev && hist_count >= 1;                     // a previous pair survives: record s_prev . y_new
                 hist_count++;
-                const double yy = dot(yv, yv);
-                H_diag = ys / yy;
-                if (tid == 0) { ro_s[slot] = 1.0 / ys; sp->ro[slot] = 1.0 / ys; }
+                H_diag = ys / r3[1];
+                if (tid == 0) {
+                    ro_s[slot] = 1.0 / ys; sp->ro[slot] = 1.0 / ys;
+                    if (link) { cadj_s[prev_slot] = r3[2]; sp->cadj[prev_slot] = r3[2]; }
+                }
                 __syncthreads();
             }
             float q[EPT];
 #pragma unroll
             for (int i = 0; i < EPT; ++i) q[i] = -gcur[i];
-            // two-loop recursion
-            auto pair_ptr = [&](const float* base, int k) {
-                const int slot = (hist_start + k) & hmask;
-                return base + ((size_t)b * a.hist_cap + slot) * Dp - off;
+            // Two-loop recursion, TWO pairs per reduction: with c = s_B . y_A known (A the next newer pair of B),
+            //   alpha_A = ro_A (s_A . q),  alpha_B = ro_B (s_B . (q - alpha_A y_A)) = ro_B (s_B . q - alpha_A c)
+            // needs both dot products against the SAME q, so they share one barrier (and their DPP chains overlap);
+            // the second loop likewise (y_B . (d + cf_A s_A) = y_B . d + cf_A c).  Same arithmetic as torch's loop up to
+            // rounding.  Two pairs are in flight while two are being used (sets X and Z).
+            const int hc = hist_count, np2 = (hc + 1) / 2;
+            float sXa[EPT], yXa[EPT], sXb[EPT], yXb[EPT], sZa[EPT], yZa[EPT], sZb[EPT], yZb[EPT];
+            auto clampk = [&](int k) { return k < 0 ? 0 : (k >= hc ? hc - 1 : k); };
+            auto ld2 = [&](int kA, int kB, float (&sA)[EPT], float (&yA)[EPT], float (&sB)[EPT], float (&yB)[EPT]) {
+                load(pair_ptr(a.S, clampk(kA)), sA); load(pair_ptr(a.Y, clampk(kA)), yA);
+                load(pair_ptr(a.S, clampk(kB)), sB); load(pair_ptr(a.Y, clampk(kB)), yB);
             };
-            // Three (s, y) pairs are kept in flight: pair k lives in ring buffer k % 3, and a buffer is refilled
-            // with pair k-3 (first loop) / k+3 (second loop) right after its step, so every reduction overlaps
-            // two outstanding fetches.  The last three steps of the first loop reload their own pair, which
-            // leaves pairs 0,1,2 where the second loop wants them.
-            float s0[EPT], y0[EPT], s1[EPT], y1[EPT], s2[EPT], y2[EPT];
-            const int hc = hist_count;
-            auto ld_pair = [&](int k, float (&sb)[EPT], float (&yb)[EPT]) {
-                load(pair_ptr(a.S, k), sb);
-                load(pair_ptr(a.Y, k), yb);
-            };
-            auto first_k = [&](int j) { const int k = hc - 1 - ((hc - 1 - j + 3) % 3); return k < 0 ? 0 : k; };
-            auto step1 = [&](int k, float (&sb)[EPT], float (&yb)[EPT]) {
-                const int slot = (hist_start + k) & hmask;
-                const double al = dot(sb, q) * ro_s[slot];
-                if (tid == 0) al_s[k] = al;
-                const float alf = (float)al;
+            auto dstep1 = [&](int kA, float (&sA)[EPT], float (&yA)[EPT], float (&sB)[EPT], float (&yB)[EPT]) {
+                const int kB = kA - 1;
+                const bool vB = kB >= 0;
+                const int slA = (hist_start + kA) & hmask, slB = (hist_start + clampk(kB)) & hmask;
+                double r2[2];
+                {
+                    float pa = 0.f, pb = 0.f;
 #pragma unroll
-                for (int i = 0; i < EPT; ++i) q[i] -= alf * yb[i];
-                ld_pair(k >= 3 ? k - 3 : k, sb, yb);
-            };
-            auto step2 = [&](int k, float (&sb)[EPT], float (&yb)[EPT]) {
-                const int slot = (hist_start + k) & hmask;
-                const double be = dot(yb, q) * ro_s[slot];
-                const float cf = (float)(al_s[k] - be);
+                    for (int i = 0; i < EPT; ++i) { pa += sA[i] * q[i]; pb += sB[i] * q[i]; }
+                    r2[0] = (double)pa; r2[1] = (double)pb;
+                }
+                R.template sumN<2>(r2);
+                const double alA = r2[0] * ro_s[slA];
+                const double alB = vB ? (r2[1] - (double)(float)alA * cadj_s[slB]) * ro_s[slB] : 0.0;
+                if (tid == 0) { al_s[kA] = alA; if (vB) al_s[kB] = alB; }
+                const float fa = (float)alA, fb = (float)alB;
 #pragma unroll
-                for (int i = 0; i < EPT; ++i) q[i] += cf * sb[i];
-                ld_pair(k + 3 < hc ? k + 3 : hc - 1, sb, yb);
+                for (int i = 0; i < EPT; ++i) q[i] -= fa * yA[i] + fb * yB[i];
             };
-            if (hc > 0) {
-                ld_pair(first_k(2), s2, y2);
-                ld_pair(first_k(1), s1, y1);
-                ld_pair(first_k(0), s0, y0);
-            }
-            for (int kk = (hc + 2) / 3 * 3 - 1; kk >= 0; kk -= 3) {
-                if (kk < hc) step1(kk, s2, y2);
-                if (kk - 1 < hc) step1(kk - 1, s1, y1);
-                if (kk - 2 < hc) step1(kk - 2, s0, y0);
+            auto dstep2 = [&](int kA, float (&sA)[EPT], float (&yA)[EPT], float (&sB)[EPT], float (&yB)[EPT]) {
+                const int kB = kA + 1;
+                const bool vB = kB < hc;
+                const int slA = (hist_start + kA) & hmask, slB = (hist_start + clampk(kB)) & hmask;
+                double r2[2];
+                {
+                    float pa = 0.f, pb = 0.f;
+#pragma unroll
+                    for (int i = 0; i < EPT; ++i) { pa += yA[i] * q[i]; pb += yB[i] * q[i]; }
+                    r2[0] = (double)pa; r2[1] = (double)pb;
+                }
+                R.template sumN<2>(r2);
+                const float cfA = (float)(al_s[kA] - r2[0] * ro_s[slA]);
+                const float cfB = vB ? (float)(al_s[clampk(kB)] - (r2[1] + (double)cfA * cadj_s[slA]) * ro_s[slB]) : 0.f;
+#pragma unroll
+                for (int i = 0; i < EPT; ++i) q[i] += cfA * sA[i] + cfB * sB[i];
+            };
+            if (hc > 0) ld2(hc - 1, hc - 2, sXa, yXa, sXb, yXb);
+            for (int p2 = 0; p2 < np2; p2 += 2) {
+                const int kA = hc - 1 - 2 * p2;
+                ld2(kA - 2, kA - 3, sZa, yZa, sZb, yZb);
+                dstep1(kA, sXa, yXa, sXb, yXb);
+                ld2(kA - 4, kA - 5, sXa, yXa, sXb, yXb);
+                if (p2 + 1 < np2) dstep1(kA - 2, sZa, yZa, sZb, yZb);
             }
             __syncthreads();
             const float hd = (float)H_diag;
 #pragma unroll
             for (int i = 0; i < EPT; ++i) q[i] *= hd;
-            for (int kk = 0; kk < hc; kk += 3) {
-                step2(kk, s0, y0);
-                if (kk + 1 < hc) step2(kk + 1, s1, y1);
-                if (kk + 2 < hc) step2(kk + 2, s2, y2);
+            if (hc > 0) ld2(0, 1, sXa, yXa, sXb, yXb);
+            for (int p2 = 0; p2 < np2; p2 += 2) {
+                const int kA = 2 * p2;
+                ld2(kA + 2, kA + 3, sZa, yZa, sZb, yZb);
+                dstep2(kA, sXa, yXa, sXb, yXb);
+                ld2(kA + 4, kA + 5, sXa, yXa, sXb, yXb);
+                if (p2 + 1 < np2) dstep2(kA + 2, sZa, yZa, sZb, yZb);
             }
 #pragma unroll
             for (int i = 0; i < EPT; ++i) dv[i] = q[i];
