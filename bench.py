@@ -95,15 +95,40 @@ def cpu_baseline(sd_local, sd_global, cam, seqd, starts, mean_bone, eps_l, eps_g
     return np.asarray(out), dt, nthreads
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh ranks (one per GPU) under torch.distributed.run and
+    relay their exit code.  Runs before this process touches torch.cuda or HIP: the parent only waits."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this pool (RCCL needs it)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     a = parse()
+    if a.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(spawn_ranks(a.gpus))
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (a.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # GEM_BENCH_REHEARSAL=1: several ranks on ONE card with gloo, to rehearse the multi-rank code path on a 1-GPU box
     rehearsal = os.environ.get("GEM_BENCH_REHEARSAL") == "1"
+    if not rehearsal and torch.cuda.device_count() < world:
+        sys.exit("bench.py: %d ranks but only %d GPUs visible (GEM_BENCH_REHEARSAL=1 shares one card over gloo)"
+                 % (world, torch.cuda.device_count()))
     dev_index = local_rank % torch.cuda.device_count() if rehearsal else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
@@ -275,6 +300,8 @@ def main():
                 peak = {"f32": PEAK_F32_MATRIX_TFLOPS, "bf16x3": PEAK_BF16_MATRIX_TFLOPS / 3, "bf16": PEAK_BF16_MATRIX_TFLOPS}[a.precision]
                 roof = {"bound": "mfma", "achieved": round(achieved, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
                         "frac": round(achieved / peak, 4), "traffic": traffic if a.precision == "f32" else None,
+                        "traffic_source": "profiles/traffic_dominant_kernel.json (separate rocprofv3 --pmc passes of this "
+                                          "command, committed; NOT measured in this run)" if traffic and a.precision == "f32" else None,
                         "kernel": "gemm_f32_kernel<1,EPI_BIAS,*,*,1> (decoder_input forward + backward-data)",
                         "launches": int(n), "avg_us": round(ms * 1e3 / n, 2),
                         "flop_per_launch": fl / n}
@@ -353,9 +380,14 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"f32": "f32", "bf16x3": "f32 via 3x bf16 split MFMA (wide products), f32 elsewhere",
                       "bf16": "bf16 wide products / f32 accumulate, tail and energies"}[a.precision], "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1] shape: %d-frame sequence per GPU = %d chunks x %d windows = %d windows, "
-                                   "fp32, local+global stage, L-BFGS max_iter 25 / max_eval 31" % (n_frames, n_chunks, per, B),
+            "config": {"workload": "%s: %d-frame sequence per GPU = %d chunks x %d windows = %d windows, %s wide products, "
+                                   "local+global stage, L-BFGS max_iter 25 / max_eval 31"
+                                   % ({"seq2k": "BASELINE configs[1] (one ~2k-frame sequence, all windows in one batch)",
+                                       "w8192": "BASELINE configs[3] per-GPU shard (8192 windows; 683 chunks = 8196)"}
+                                      .get(a.workload, "custom workload (--workload %s)" % a.workload),
+                                      n_frames, n_chunks, per, B, a.precision),
                        "windows_per_gpu": B, "latent_dim": shape.latent_dim, "parallelism": "window-shards x%d" % world,
+                       "ranks": world, "backend": dist.get_backend() if world > 1 else None,
                        "vae": "synthetic, fitted %d Adam steps (recon %.1f / %.1f mm)" % (a.fit_steps, err_l * 1e3, err_g * 1e3)},
             "evals_per_stage": {"local_mean": float(evals[0].mean()), "global_mean": float(evals[1].mean()),
                                 "min": int(evals.min()), "max": int(evals.max())},

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -110,8 +111,9 @@ struct Workspace {
 // "done once" flag per device ordinal: hipFuncSetAttribute is a per-device setting and a process may own handles on
 // several devices (one thread per handle; a handle itself is not thread-safe)
 struct PerDeviceOnce {
-    bool done[64] = {};
-    bool need(int dev) { if (dev < 0 || dev >= 64) return true; if (done[dev]) return false; done[dev] = true; return true; }
+    std::atomic<bool> done[64] = {};
+    // exchange: exactly one of several threads (one per handle) sees "need" for a device; the setting itself is idempotent
+    bool need(int dev) { if (dev < 0 || dev >= 64) return true; return !done[dev].exchange(true); }
 };
 
 struct Profile {

@@ -347,7 +347,7 @@ static int launch_b(gem_handle* h, const Layer& L, const float* A, int lda, cons
     const int sk = pick_splitk(h, (long)grid.x * grid.y, n_tiles, slab);
     const int per = (n_tiles + sk - 1) / sk;
     grid.z = (n_tiles + per - 1) / per;
-    const long wgs = (long)grid.x * grid.y * grid.z, per_cu = (wgs + 255) / 256;
+    const long wgs = (long)grid.x * grid.y * grid.z, per_cu = (wgs + h->n_cu - 1) / h->n_cu;
     if (per_cu <= 8) {
         const size_t want = (((size_t)160 * 1024 - 8192) / per_cu) & ~(size_t)1023;      // see gemm_f32.hip
         if (want > shmem) shmem = want;

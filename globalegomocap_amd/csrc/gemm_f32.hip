@@ -265,9 +265,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // 1280 small workgroups lands on 183 of the 256 CUs; the launch below therefore also pads the LDS request
 // so that exactly ceil(workgroups/256) fit per CU.  Pick the slice count whose workgroup total fills those
 // slots best (workgroups / (256 * per_cu)), preferring >= 2 per CU and fewer slices.
-constexpr int N_CU = 256;
 constexpr int LDS_PER_CU = 160 * 1024;
 int pick_splitk(const gem_handle* h, long blocks, int n_tiles, size_t slab_elems) {
+    const int N_CU = h->n_cu;             // compute units of this handle's device
     if (!h->ws.splitk || blocks >= 3 * N_CU) return 1;
     static const int force = getenv("GEM_FORCE_SK") ? atoi(getenv("GEM_FORCE_SK")) : 0;      // developer override (sweeps)
     if (force > 0 && n_tiles / force >= 4 && (size_t)force * slab_elems <= h->ws.splitk_elems) return force;
@@ -319,7 +319,7 @@ static int launch_one(gem_handle* h, const Layer& L, const float* A, int lda, co
     grid.z = (n_tiles + per - 1) / per;
     // occupancy cap = even spread: LDS request sized so that only ceil(workgroups/256) fit on a CU
     const long wgs = (long)grid.x * grid.y * grid.z;
-    const long per_cu = (wgs + N_CU - 1) / N_CU;
+    const long per_cu = (wgs + h->n_cu - 1) / h->n_cu;
     if (per_cu <= 8) {
         // (a few KB below the even share: exactly 160 KB / per_cu each did NOT fit per_cu workgroups -- the stragglers
         // ran as a second wave, see tools/gemm_trace.hip)

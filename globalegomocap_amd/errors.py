@@ -1,8 +1,9 @@
 """Pose-error metrics of the sequence pipeline (host, numpy float64).
 
 Mirror of the reference's `calculate_errors` (`calculate_errors.py:114-179`): same 18 keys, same
-definitions.  It is the reporting side of the hot path ("MPJPE vs ref"), not accelerated
-(SURVEY.md section 8f.1 lists a device version as a later step).
+definitions.  This numpy version is the host CHECKER of the device implementation
+(`gem_calculate_errors`, csrc/errors.hip, reached through `WindowEngine.calculate_errors` or
+`main(..., device_metrics=True)`), and what `main()` uses when device metrics are off.
 """
 from collections import OrderedDict
 
