@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""Full-size (D = 2048) golden run of the UNMODIFIED reference `main()` -> tests/golden/pipeline_full.npz.
+
+TEST INFRASTRUCTURE.  Runs only where /root/reference exists (never on the GPU box, never from tests).
+Like oracle/make_golden.py it imports the reference's own modules after registering inert stand-ins for
+open3d / cv2 / natsort (never touched on the path), and feeds them inputs built by this repo:
+
+  * the two motion VAEs are `globalegomocap_amd.vae.structured_state_dict(FULL, seed)` -- full size, well
+    conditioned, regenerated bit-identically from a seed on any machine (only seed + SHA-256 are stored),
+    written in the reference's checkpoint schema at the paths `main()` hard-codes (optimizer.py:334,344);
+  * one 100-frame chunk with SLAM-like jittered cameras (`synth.make_sequence(..., cam_jitter=...)`): exactly the
+    kind of chunk bench.py times (BASELINE configs[1] = 20 of them), at the CLI's default energy weights
+    (optimize_whole_sequence.py:14-19).
+
+Stored: the inputs (poses, cameras, ground truth, heat-map centres), the 24 latent noise draws in the reference's
+order (window i: local, then global), per stage and window the closure trace, torch.optim.LBFGS's
+(n_iter, func_evals) and the stage's input / output pose, the merged [98,15,3] outputs and the 18-entry error dict -- with and without the final
+smoothing -- and the reference's own 1-vs-8-thread self-noise on optimized_global_mpjpe.
+
+    python oracle/make_golden_full.py        # about 2 minutes
+"""
+import os
+import pickle
+import sys
+import tempfile
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "oracle"))
+sys.dont_write_bytecode = True
+
+from globalegomocap_amd import synth, vae as vae_schema                         # noqa: E402
+from globalegomocap_amd.camera import FisheyeCamera, DEFAULT_CALIBRATION        # noqa: E402
+from make_golden import import_reference, to_torch_sd, LOCAL_CKPT, GLOBAL_CKPT, OUT   # noqa: E402
+
+FULL = vae_schema.VAEShape()
+SEED_LOCAL, SEED_GLOBAL, SEQ_SEED, EPS_SEED = 7, 8, 2, 4321
+FEATURE_OFFSET_LOCAL, FEATURE_OFFSET_GLOBAL = 0.0, 3.0
+CAM_JITTER = (0.3, 0.002)           # the bench's camera noise: 0.3 deg, 2 mm per frame
+CLI = dict(vae_weight=0.0, gmm_weight=0.0, smoothness_weight=0.001, bone_length_weight=0.01, weight_3d=0.01,
+           reproj_weight=0.01)      # optimize_whole_sequence.py:14-19
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    work = tempfile.mkdtemp(prefix="gem_golden_full_")
+    torch, ref_opt, ConvVAE, FishEye = import_reference(work)
+    cam_json = DEFAULT_CALIBRATION
+    cam = FisheyeCamera.from_json(cam_json)
+    # local VAE: mildly non-linear (its stage has the kinks of the bilinear heat-map sampling anyway); global VAE: affine, so
+    # that the global stage's energy is smooth and its L-BFGS trajectory can be pinned to rounding (FEATURE_OFFSET_*)
+    sd_l = vae_schema.structured_state_dict(FULL, SEED_LOCAL, feature_offset=FEATURE_OFFSET_LOCAL)
+    sd_g = vae_schema.structured_state_dict(FULL, SEED_GLOBAL, feature_offset=FEATURE_OFFSET_GLOBAL)
+    for rel, sdx in ((LOCAL_CKPT, sd_l), (GLOBAL_CKPT, sd_g)):
+        os.makedirs(os.path.dirname(os.path.join(work, rel)), exist_ok=True)
+        torch.save({"state_dict": to_torch_sd(torch, sdx)}, os.path.join(work, rel))
+    seq = synth.make_sequence(n_frames=100, seed=SEQ_SEED, camera=cam, cam_jitter=CAM_JITTER)
+    os.makedirs(os.path.join(work, "data", "chunk0"))
+    with open(os.path.join(work, "data", "chunk0", "test_data.pkl"), "wb") as f:
+        pickle.dump({k: seq[k] for k in ("estimated_local_skeleton", "gt_global_skeleton", "camera_pose_list", "heatmap_list")}, f)
+
+    # ---- instrumentation around the reference (nothing inside it is changed)
+    RealConvVAE, RealLBFGS = ConvVAE, ref_opt.LBFGS
+    log = {"eps": [], "calls": [], "stage_io": []}
+
+    def vae_factory(**kw):
+        # module construction draws init weights from the global RNG (before load_state_dict overwrites them):
+        # re-seeding after the last construction makes the noise stream start at window 0
+        net = RealConvVAE(**kw)
+        torch.manual_seed(EPS_SEED)
+        return net
+
+    class SpyLBFGS(RealLBFGS):
+        def step(self, closure):
+            trace = []
+
+            def spy():
+                v = closure()
+                trace.append(float(v))
+                return v
+            out = super().step(spy)
+            st = self.state[self._params[0]]
+            log["calls"].append({"trace": np.array(trace), "n_iter": int(st["n_iter"]), "func_evals": int(st["func_evals"])})
+            return out
+
+    real_randn_like = torch.randn_like
+
+    def spy_randn_like(t, *a, **k):
+        r = real_randn_like(t, *a, **k)
+        log["eps"].append(r.detach().cpu().numpy().reshape(-1).copy())
+        return r
+
+    real_stage = ref_opt.BodyPoseOptimizer.optimize_pose_seq_pytorch_LBFGS
+
+    def spy_stage(self, pose, heatmaps, smoothed):
+        res = real_stage(self, pose, heatmaps, smoothed)
+        log["stage_io"].append((np.array(pose, dtype=np.float64), np.array(res, dtype=np.float32).reshape(-1, 15, 3)))
+        return res
+
+    ref_opt.BodyPoseOptimizer.optimize_pose_seq_pytorch_LBFGS = spy_stage
+    ref_opt.ConvVAE = vae_factory
+    ref_opt.LBFGS = SpyLBFGS
+    torch.randn_like = spy_randn_like
+
+    out = {"seed_local": SEED_LOCAL, "seed_global": SEED_GLOBAL, "feature_offset_local": FEATURE_OFFSET_LOCAL,
+           "feature_offset_global": FEATURE_OFFSET_GLOBAL, "seq_seed": SEQ_SEED, "eps_seed": EPS_SEED,
+           "sha_local": vae_schema.state_dict_sha256(sd_l, FULL), "sha_global": vae_schema.state_dict_sha256(sd_g, FULL),
+           "cam_jitter": np.asarray(CAM_JITTER),
+           "est_local": np.asarray(seq["estimated_local_skeleton"]), "gt_global": np.asarray(seq["gt_global_skeleton"]),
+           "cams": np.asarray(seq["camera_pose_list"]), "heat_centres": seq["heatmap_centres"]}
+    for k, v in CLI.items():
+        out["cli/" + k] = v
+
+    def run(final_smooth, threads):
+        torch.set_num_threads(threads)
+        log["eps"].clear(); log["calls"].clear(); log["stage_io"].clear()
+        torch.manual_seed(EPS_SEED)
+        return ref_opt.main(os.path.join("data", "chunk0"), camera_model_path=cam_json, final_smooth=final_smooth, **CLI)
+
+    for tag, fs in (("smooth", True), ("raw", False)):
+        errors, est_seq, mid_local, opt_seq, gt_seq = run(fs, 1)
+        out["opt_" + tag] = np.asarray(opt_seq)
+        out["mid_local_" + tag] = np.asarray(mid_local)
+        out["est_" + tag] = np.asarray(est_seq)
+        out["gt_" + tag] = np.asarray(gt_seq)
+        for k, v in errors.items():
+            out["err_%s/%s" % (tag, k)] = np.asarray(v)
+        print("  main(final_smooth=%s): optimized_global_mpjpe %.3f mm (mid %.3f, input %.3f mm)"
+              % (fs, errors["optimized_global_mpjpe"] * 1000, errors["mid_global_mpjpe"] * 1000, errors["original_global_mpjpe"] * 1000))
+        if tag == "smooth":
+            eps = np.stack(log["eps"])                 # [24, 2048]: local_0, global_0, local_1, ...
+            assert eps.shape == (24, 2048) and len(log["calls"]) == 24
+            torch.manual_seed(EPS_SEED)
+            assert np.array_equal(eps, torch.randn(24, 2048).numpy()), "noise stream is not torch.randn(24, 2048) of the seed"
+            out["eps"] = eps.astype(np.float32)
+            nmax = max(len(c["trace"]) for c in log["calls"])
+            tr = np.full((24, nmax), np.nan)
+            for i, c in enumerate(log["calls"]):
+                tr[i, :len(c["trace"])] = c["trace"]
+            out["trace"] = tr                          # row 2i = local stage of window i, row 2i+1 = its global stage
+            out["n_iter"] = np.array([c["n_iter"] for c in log["calls"]])
+            out["func_evals"] = np.array([c["func_evals"] for c in log["calls"]])
+            # per-call inputs / outputs of optimize_pose_seq_pytorch_LBFGS (call 2i = local stage of window i, 2i+1 = global):
+            # lets a test run every stage in isolation from the deviations of the stage before it
+            out["stage_in"] = np.stack([a for a, _ in log["stage_io"]])            # [24,10,15,3] f64
+            out["stage_out"] = np.stack([b for _, b in log["stage_io"]])           # [24,10,15,3] f32
+            print("  local  evals", out["func_evals"][0::2], "n_iter", out["n_iter"][0::2])
+            print("  global evals", out["func_evals"][1::2], "n_iter", out["n_iter"][1::2])
+    errors8 = run(True, 8)[0]
+    out["err_smooth_8threads/optimized_global_mpjpe"] = np.asarray(errors8["optimized_global_mpjpe"])
+    out["func_evals_8threads"] = np.array([c["func_evals"] for c in log["calls"]])
+    print("  reference self-noise 1 vs 8 threads: %.4f mm on optimized_global_mpjpe"
+          % (abs(errors8["optimized_global_mpjpe"] - float(out["err_smooth/optimized_global_mpjpe"])) * 1000))
+    path = os.path.join(OUT, "pipeline_full.npz")
+    np.savez_compressed(path, **out)
+    print("%8.1f KB  %s" % (os.path.getsize(path) / 1024, path))
+
+
+if __name__ == "__main__":
+    main()

@@ -20,3 +20,19 @@ def heat_from_centres(centres):
 
 def sd_from_npz(npz, prefix):
     return {k[len(prefix):]: npz[k] for k in npz.files if k.startswith(prefix)}
+
+
+def full_golden_case(g):
+    """Inputs of tests/golden/pipeline_full.npz (oracle/make_golden_full.py): the pickle-schema dict of the 100-frame
+    jittered-camera chunk, the two regenerated full-size state dicts (SHA-256 pinned) and the CLI weight tuples."""
+    sd_l = vae_schema.structured_state_dict(FULL, int(g["seed_local"]), feature_offset=float(g["feature_offset_local"]))
+    sd_g = vae_schema.structured_state_dict(FULL, int(g["seed_global"]), feature_offset=float(g["feature_offset_global"]))
+    assert vae_schema.state_dict_sha256(sd_l, FULL) == str(g["sha_local"]), "regenerated local VAE differs from the golden run's"
+    assert vae_schema.state_dict_sha256(sd_g, FULL) == str(g["sha_global"]), "regenerated global VAE differs from the golden run's"
+    data = {"estimated_local_skeleton": g["est_local"], "gt_global_skeleton": g["gt_global"], "camera_pose_list": g["cams"],
+            "heatmap_list": heat_from_centres(g["heat_centres"])}
+    w3d, sm = float(g["cli/weight_3d"]), float(g["cli/smoothness_weight"])
+    bone, rep, wv = float(g["cli/bone_length_weight"]), float(g["cli/reproj_weight"]), float(g["cli/vae_weight"])
+    w_local = (w3d / 10000, sm / 100, bone, wv, rep)            # optimizer.py:355-358
+    w_global = (w3d, sm, 0.01, wv, 0.0)                         # optimizer.py:352-353
+    return data, sd_l, sd_g, w_local, w_global
