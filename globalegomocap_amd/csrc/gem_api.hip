@@ -1,6 +1,7 @@
 // C-ABI entry points of libgem_hip.so (see include/gem_hip.h) and the host-side orchestration of the
 // evaluation rounds.  Host code only: weight folding / packing, workspace management and kernel
 // sequencing; all arithmetic of the path runs in the HIP kernels of gemm_f32.hip, energy.hip, lbfgs.hip.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -187,6 +188,7 @@ int gem_create(const gem_config* cfg, gem_handle** out) {
     if (dev_alloc(w.allocs, &w.state, (size_t)B)) return 1;
     if (dev_alloc(w.allocs, &w.f, (size_t)B)) return 1;
     if (dev_alloc(w.allocs, &w.parts, (size_t)B * 5)) return 1;
+    if (dev_alloc(w.allocs, &w.trace, (size_t)TRACE_ROUNDS * B)) return 1;
     if (dev_alloc(w.allocs, &w.pose_a, rows * h->C)) return 1;
     if (dev_alloc(w.allocs, &w.pose_b, rows * h->C)) return 1;
     if (dev_alloc(w.allocs, &w.n_log, (size_t)N_LOG)) return 1;
@@ -468,11 +470,15 @@ static int optimize_stage_impl(gem_handle* h, int stage, int B, const float* d_p
     }
     const EnergyArgs ea = energy_args(h, d_pose_in, d_heat, d_frame0, d_mean_bone, wt);
     const int rounds = opt.max_eval + 1;          // upper bound on evaluations per window (see lbfgs.hip)
+    // closure values of this stage, one row per round (0xFF bytes = NaN: "window took no evaluation in this round")
+    GEM_HIP(hipMemsetAsync(w.trace, 0xFF, (size_t)TRACE_ROUNDS * w.Bmax * sizeof(double), s));
     int rc = 0;
     for (int r = 0; r < rounds && !rc; ++r) {
+        w.round = r;
         rc = evaluate(h, stage, B, w.trial, ea, s) || launch_lbfgs_advance(h, B, opt, s);
         if (!rc && w.dyn) rc = launch_compact(h, B, 0, s);
     }
+    w.round = -1;
     w.dyn = false;
     if (rc) return 1;
     // every window is finished now: trial == x*; decode it with the same kernels as the rounds (all windows again)
@@ -563,6 +569,17 @@ int gem_optimize_windows(gem_handle* h, int B, const float* d_local_pose, const 
     if (optimize_stage_impl(h, GEM_STAGE_GLOBAL, B, w.pose_a, d_heat, d_frame0, d_mean_bone, d_eps_global, *w_global, *opt, out_b,
                             d_stats ? d_stats + B : nullptr, s)) return 1;
     return launch_to_global(out_b, d_cams, d_frame0, d_global, B, T, J, s);
+}
+
+int gem_read_trace(gem_handle* h, int B, int n_rounds, double* d_out, void* stream) {
+    if (!h || !d_out || B < 0 || B > h->ws.Bmax || n_rounds < 0 || n_rounds > TRACE_ROUNDS) {
+        set_error("gem_read_trace: need 0 <= B <= max_windows and 0 <= n_rounds <= 64"); return 1;
+    }
+    GEM_HIP(hipSetDevice(h->cfg.device));
+    if (B == 0 || n_rounds == 0) return 0;
+    GEM_HIP(hipMemcpy2DAsync(d_out, (size_t)B * sizeof(double), h->ws.trace, (size_t)h->ws.Bmax * sizeof(double),
+                             (size_t)B * sizeof(double), (size_t)n_rounds, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
 }
 
 int gem_set_precision(gem_handle* h, int mode) {

@@ -16,6 +16,7 @@ constexpr double BN_EPS = 1e-5;            // torch.nn.BatchNorm1d default
 constexpr int MAX_HIST = 128;              // capacity of the per-window (s,y) ring
 constexpr int MAXJ_ERR = GEM_MAX_JOINTS;   // joints handled by the error-report kernels (errors.hip)
 constexpr int N_LOG = 1 << 16;             // ring of active-window counts kept for the profiling hook
+constexpr int TRACE_ROUNDS = 64;           // evaluation rounds whose closure values are kept per stage (gem_read_trace)
 
 inline int pad64(int x) { return (x + PAD - 1) / PAD * PAD; }
 
@@ -90,6 +91,8 @@ struct Workspace {
     LbfgsState* state = nullptr;        // [B]
     double* f = nullptr;                // [B] energy of the trial point
     double* parts = nullptr;            // [B,5]
+    double* trace = nullptr;            // [TRACE_ROUNDS][Bmax] closure value each window consumed in round r of the last stage (NaN: none)
+    int round = -1;                     // evaluation round being enqueued (-1: outside the rounds)
     // pipeline scratch
     float* pose_a = nullptr;            // [B,T,J,3] gathered local poses / stage outputs
     float* pose_b = nullptr;

@@ -28,6 +28,7 @@ enum { PH_INIT = 0, PH_BRACKET = 1, PH_ZOOM = 2, PH_DONE = 3 };
 struct AdvArgs {
     LbfgsState* state;
     const double* f;
+    double* trace;            // [B] closure values consumed in this round (nullptr: not recorded)
     const float* gnew;
     float *x, *d, *g, *gp, *bg0, *bg1, *trial, *S, *Y;
     const int* slot_of;       // window -> slot of its gradient row (nullptr: identity)
@@ -125,6 +126,7 @@ __device__ __forceinline__ void lbfgs_advance_body(const AdvArgs& a) {
     __syncthreads();
 
     const double f_new = a.f[b];
+    if (a.trace && tid == 0) a.trace[b] = f_new;
     const float* gsrc = a.gnew + (size_t)(a.slot_of ? a.slot_of[b] : b) * Dp;
     float gn[EPT], xv[EPT], dv[EPT], gcur[EPT], yv[EPT], sv[EPT];
     bool have_x = false, have_d = false;
@@ -543,6 +545,7 @@ static AdvArgs make_args(gem_handle* h, const gem_lbfgs_opts& o) {
     Workspace& w = h->ws;
     AdvArgs a;
     a.state = w.state; a.f = w.f; a.gnew = w.dz;
+    a.trace = (w.round >= 0 && w.round < TRACE_ROUNDS) ? w.trace + (size_t)w.round * w.Bmax : nullptr;
     a.x = w.x; a.d = w.d; a.g = w.g; a.gp = w.gp; a.bg0 = w.bg0; a.bg1 = w.bg1; a.trial = w.trial; a.S = w.S; a.Y = w.Y;
     a.slot_of = w.dyn ? w.slot_of : nullptr;
     a.gslab = w.dyn ? w.grad_slab : SlabSrc{};

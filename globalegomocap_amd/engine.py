@@ -56,6 +56,7 @@ class WindowEngine:
         self._h = C.c_void_p()
         _capi.check(self.lib.gem_create(C.byref(cfg), C.byref(self._h)), self.lib)
         self.T, self.D = self.shape.seq_len, self.shape.latent_dim
+        self.precision = "f32"
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -71,6 +72,7 @@ class WindowEngine:
     def set_precision(self, mode):
         """'f32' (default) | 'bf16x3' (split-bf16 MFMA, fp32-grade) | 'bf16' for the wide decoder/encoder products."""
         _capi.check(self.lib.gem_set_precision(self._h, _capi.PRECISION[mode]), self.lib)
+        self.precision = mode
 
     # ------------------------------------------------------------------ weights
     def load_vae(self, stage, state_dict):
@@ -171,6 +173,14 @@ class WindowEngine:
                                                   C.byref(w_global), C.byref(opts), _ptr(mid), _ptr(glob), _ptr(stats),
                                                   _stream()), self.lib)
         return mid, glob, stats
+
+    def read_trace(self, B, n_rounds=33):
+        """Closure values of the last stage run on this engine: numpy [B, n_rounds] f64, NaN after a window's last
+        evaluation (column r = evaluation round r).  For parity tests against the reference's closure traces."""
+        self._check_B(B)
+        out = torch.empty(n_rounds, B, device=self.device, dtype=torch.float64)
+        _capi.check(self.lib.gem_read_trace(self._h, B, n_rounds, _ptr(out), _stream()), self.lib)
+        return out.cpu().numpy().T.copy()
 
     # ------------------------------------------------------------------ sequence post-processing (SURVEY 8f.1)
     def _f64(self, a):

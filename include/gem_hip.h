@@ -129,6 +129,12 @@ int gem_optimize_stage(gem_handle* h, int stage, int B, const float* d_pose_in, 
                        const gem_energy_weights* w, const gem_lbfgs_opts* opt, float* d_pose_out,
                        gem_window_stats* d_stats, void* stream);
 
+/* Closure values of the LAST stage run on this handle (the `total_loss` values torch.optim.LBFGS.step's closure returned,
+ * optimizer.py:263-268): d_out [n_rounds][B] f64, row r = the value window b's optimiser consumed in evaluation round r,
+ * NaN once the window had finished (a window's evaluations are rounds 0..func_evals-1).  n_rounds <= 64.  For parity
+ * tests against the reference's closure traces; after gem_optimize_windows it holds the global stage's values. */
+int gem_read_trace(gem_handle* h, int B, int n_rounds, double* d_out, void* stream);
+
 /* The window loop body of main() (optimizer.py:370-423) for B windows at once: local stage,
  * relative-global transform X_rel[t] = C0^-1 C_t X_loc[t] in float64 (utils/utils.py:99-112), global
  * stage, X_glob = C0 X_rel (optimizer.py:302-308).

@@ -36,3 +36,18 @@ def full_golden_case(g):
     w_local = (w3d / 10000, sm / 100, bone, wv, rep)            # optimizer.py:355-358
     w_global = (w3d, sm, 0.01, wv, 0.0)                         # optimizer.py:352-353
     return data, sd_l, sd_g, w_local, w_global
+
+
+def oracle_stage_losses(vae, cam, w, pose, heat, mean_bone, eps, opt=None):
+    """O.optimize_stage that also returns the closure value of every evaluation (what gem_read_trace records)."""
+    X0 = pose.astype(np.float32)
+    z0 = O.latent_from_pose(vae, X0.reshape(1, X0.shape[0], 45), eps.reshape(1, -1))[0]
+    losses = []
+
+    def fun(z):
+        X, acts = O.decode(vae, z[None], keep=True)
+        f, _, dX = O.energy_and_grad(X[0], X0, mean_bone, w, cam, heat)
+        losses.append(f)
+        return f, O.decode_backward(vae, dX[None], acts)[0]
+    z, stats = O.lbfgs_strong_wolfe(fun, z0, opt)
+    return O.decode(vae, z[None])[0].astype(np.float32), stats, np.array(losses)

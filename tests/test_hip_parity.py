@@ -9,7 +9,7 @@ import pytest
 from globalegomocap_amd import synth, vae as vae_schema
 from globalegomocap_amd.camera import FisheyeCamera, DEFAULT_CALIBRATION
 from oracle import np_oracle as O
-from helpers import TINY, FULL, oracle_camera, heat_from_centres, sd_from_npz
+from helpers import TINY, FULL, oracle_camera, heat_from_centres, sd_from_npz, oracle_stage_losses
 
 pytestmark = pytest.mark.gpu
 
@@ -159,13 +159,21 @@ def test_lbfgs_stage_full_size_against_oracle_and_golden(torch_cuda, golden):
         st = stats.cpu().numpy()[0]
         assert st[1] == 1 and st[3] == 1
         np.testing.assert_allclose(out[0].cpu().numpy(), g[tag + "_out"], rtol=2e-3, atol=2e-5)
-    # strong weights: a long run on a random-init network is chaotic; compare the achieved loss
+    # strong weights: a long run on a random-init network (late iterates are chaotic): the closure values follow the
+    # reference's trace while the trajectories are still together, and the run achieves the reference's energy
     for tag, w in (("localstrong", (1e-1, 1e-1, 1.0, 1e-3, 1e-2)), ("globalstrong", (1.0, 1e-1, 1.0, 0.0, 0.0))):
         out, stats = eng.optimize_stage(0, pose[None], mb, g[tag + "_eps"][None], _ew(w), heat, np.zeros(1, np.int32))
+        tr = eng.read_trace(1)[0]
         st = stats.cpu().numpy()[0]
         loss = np.array([st[2]], dtype=np.int32).view(np.float32)[0]
         ref = g[tag + "_trace"]
-        assert st[3] == 1 and st[1] >= 20
+        assert st[3] == 1 and st[1] >= 20 and int(np.isfinite(tr).sum()) == st[1]
+        # (random-init weights: the directional derivatives are cancellation-dominated, the third trial step already
+        # depends on their last digits; the tight full-size trace checks are in test_hip_full_size.py)
+        np.testing.assert_allclose(tr[:2], ref[:2], rtol=2e-5, atol=1e-7, err_msg=tag)
+        np.testing.assert_allclose(tr[:4], ref[:4], rtol=2e-3, atol=1e-7, err_msg=tag)
+        print("full-size random-init %s: evals %d / %d, final loss %.6e / %.6e" % (tag, st[1], len(ref), loss, ref.min()))
+        assert abs(int(st[1]) - len(ref)) <= 3, (tag, st[1], len(ref))
         assert abs(loss - ref.min()) <= 0.05 * abs(ref.min()), (tag, loss, ref.min())
 
 
@@ -540,8 +548,12 @@ def test_other_window_length_and_camera(torch_cuda):
     # random-init weights + strong energy weights: a long chaotic run, so compare what it achieves, not where it ends
     from globalegomocap_amd.engine import stats_to_numpy
     sn = stats_to_numpy(stats)
+    tr = eng.read_trace(B)
     for b in (0, B - 1):
-        ref, so = O.optimize_stage(vae, cam, O.Weights(*w), pose[b], heat[starts[b]:starts[b] + 8], mb, eps[b])
+        ref, so, losses = oracle_stage_losses(vae, cam, O.Weights(*w), pose[b], heat[starts[b]:starts[b] + 8], mb, eps[b])
+        np.testing.assert_allclose(tr[b, :4], losses[:4], rtol=2e-4, atol=1e-7)
+        np.testing.assert_allclose(tr[b, :6], losses[:6], rtol=5e-3, atol=1e-6)
+        print("seq_len 8 window %d: evals %d / %d, final loss %.6e / %.6e" % (b, sn["func_evals"][b], so["func_evals"], sn["final_loss"][b], so["loss"]))
         assert abs(sn["final_loss"][b] - so["loss"]) <= 0.05 * abs(so["loss"]), (b, sn["final_loss"][b], so["loss"])
         assert abs(int(sn["func_evals"][b]) - so["func_evals"]) <= 6
 
@@ -741,4 +753,6 @@ def test_stage_sweep_against_oracle(torch_cuda, golden, seed):
     # 8 threads): the achieved energy has to agree tightly, the pose to within a few millimetres; the 0.5 mm criterion is
     # on MPJPE over a sequence (tested on the golden pipeline runs)
     assert abs(loss - st["loss"]) <= 2e-3 * abs(st["loss"]) + 1e-7
-    assert diff < 3e-3
+    # measured (gpurun_out/r02_pytest3.log): local stages 0.000-0.001 mm; global stages of the fitted tiny VAEs (LeakyReLU
+    # kinks in a flat landscape, 22-27 evaluations) 0.7-1.5 mm, one or two evaluations apart
+    assert diff < (0.05e-3 if local else 2e-3)
