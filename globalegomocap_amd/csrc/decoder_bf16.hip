@@ -1,0 +1,233 @@
+// "bf16 VAE decoder / fp32 energy" (BASELINE configs[2..4]): one evaluation round with every decoder activation and
+// gradient kept in bf16 in HBM, all wide products on the bf16-activation MFMA kernel of gemm_bf16a.h.
+//
+//   trial (bf16 copy written by lbfgs_advance) -> decoder_input -> h0 (bf16) -> temporal convs (bf16) -> pose X (fp32)
+//   -> energy terms + dE/dX (fp32 arithmetic, energy_device.h) -> adjoint convs (bf16) -> decoder_input^T -> dE/dz (fp32)
+//
+// Small batches keep the fused fp32 tail kernel for the narrow layers (tail.hip; its input arrives as the wide conv's fp32
+// split-K slabs, its output gradient leaves as bf16); large batches run every layer as a batched bf16 GEMM.
+// Reference semantics: ConvVAE.decode_to_bodypose (SeqConvVAE.py:131-140) + total_loss.backward() (optimizer.py:226-240,
+// 264-268), backward-DATA only (the VAE is frozen).
+#include <cstdlib>
+
+#include "gem_internal.h"
+#include "gemm_bf16a.h"
+
+namespace gem {
+
+using bf16a::Args;
+
+__global__ void f32_to_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, size_t n4) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const bf16a::f32x4 v = reinterpret_cast<const bf16a::f32x4*>(src)[i];
+    reinterpret_cast<bf16a::u32x2*>(dst)[i] = bf16a::u32x2{bf16a::pack_bf16(v[0], v[1]), bf16a::pack_bf16(v[2], v[3])};
+}
+int launch_f32_to_bf16(const float* src, uint16_t* dst, size_t n, hipStream_t s) {      // n % 4 == 0 (padded rows)
+    const size_t n4 = n / 4;
+    if (!n4) return 0;
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, src, dst, n4);
+    GEM_HIP(hipGetLastError());
+    return 0;
+}
+
+// sums fp32 split-K slabs, applies bias / LeakyReLU, writes bf16 (the fp32-output reduce is splitk_reduce_kernel)
+template <int EPI>
+__global__ __launch_bounds__(256) void splitk_reduce_bf16_kernel(const float* __restrict__ slabs, int nslab, size_t slab_stride,
+                                                                 const float* __restrict__ bias, uint16_t* __restrict__ C, int M, int N,
+                                                                 int ldc, const int* __restrict__ m_dev) {
+    if (m_dev) M = *m_dev;
+    const int n4 = N / 4;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)M * n4) return;
+    const int row = (int)(i / n4), c = (int)(i - (size_t)row * n4) * 4;
+    const size_t off = (size_t)row * ldc + c;
+    bf16a::f32x4 v = *reinterpret_cast<const bf16a::f32x4*>(slabs + off);
+    for (int z = 1; z < nslab; ++z) v += *reinterpret_cast<const bf16a::f32x4*>(slabs + (size_t)z * slab_stride + off);
+    if (EPI == EPI_BIAS || EPI == EPI_BIAS_LRELU) v += *reinterpret_cast<const bf16a::f32x4*>(bias + c);
+    if (EPI == EPI_BIAS_LRELU) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : v[q] * LEAKY_SLOPE;
+    }
+    *reinterpret_cast<bf16a::u32x2*>(C + off) = bf16a::u32x2{bf16a::pack_bf16(v[0], v[1]), bf16a::pack_bf16(v[2], v[3])};
+}
+
+template <int TAPS, int EPI, int BN, bool OUT_BF16>
+static int launch_k(gem_handle* h, const Args& a, int grid, hipStream_t s) {
+    constexpr int BM = 128;
+    auto k = bf16a::gemm_bf16a_kernel<TAPS, EPI, BM, BN, OUT_BF16, 16>;
+    constexpr int BUF = (BM + BN) * 128;
+    constexpr size_t smem = (size_t)(2 * BUF > BM * BN * 4 ? 2 * BUF : BM * BN * 4);
+    static PerDeviceOnce once;
+    if (once.need(h->cfg.device))
+        GEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(k, dim3(grid), dim3((BM / 64) * (BN / 64) * 64), smem, s, a);
+    GEM_HIP(hipGetLastError());
+    return 0;
+}
+
+template <int TAPS, int EPI>
+static int launch_bn(gem_handle* h, const Args& a, int grid, bool bn128, bool out_bf16, hipStream_t s) {
+    if (bn128) return out_bf16 ? launch_k<TAPS, EPI, 128, true>(h, a, grid, s) : launch_k<TAPS, EPI, 128, false>(h, a, grid, s);
+    return out_bf16 ? launch_k<TAPS, EPI, 64, true>(h, a, grid, s) : launch_k<TAPS, EPI, 64, false>(h, a, grid, s);
+}
+
+// C = epi(conv/linear(A)) with bf16 operands.  `out_bf16`: activation / gradient for the next bf16 layer; otherwise fp32.
+// allow_split: small row counts cut K over several workgroups (fp32 slabs in ws.splitk); with `defer` the slabs are left to
+// the consumer (described in ws.deferred), otherwise a reduce pass applies the epilogue.
+static int gemm_bf16a(gem_handle* h, const Layer& L, int epi, const uint16_t* A, int lda, const uint16_t* aux, void* C, bool out_bf16,
+                      int ldc, int M, hipStream_t s, int family, const int* row_map, bool allow_split, bool defer) {
+    Workspace& w = h->ws;
+    if (M <= 0) return 0;
+    if (L.K % 64 != 0 || L.N % 64 != 0 || !L.wb_hi) { set_error("gemm_bf16a: layer is not padded to 64 or has no bf16 weights"); return 1; }
+    w.deferred = SlabSrc{};
+    const bool bn128 = L.N % 128 == 0;
+    const int BN = bn128 ? 128 : 64;
+    const int tiles = ((M + 127) / 128) * (L.N / BN);
+    const int k_tiles = L.taps * (L.K / 64);
+    Args a{};
+    a.A = A; a.W = L.wb_hi; a.bias = L.bias; a.aux = aux; a.C = C; a.zero16 = w.zero16;
+    a.m_dev = w.dyn ? w.n_active + (L.taps == 3 ? 1 : 0) : nullptr;
+    a.row_map = row_map;
+    a.lda = lda; a.ldc = ldc; a.M = M; a.N = L.N; a.K = L.K; a.T = h->T;
+    a.n_split = 1; a.tiles_per_split = k_tiles; a.slab_stride = (size_t)M * ldc;
+    if (allow_split && epi != EPI_MASK) {
+        // fill the chip: about three workgroups per CU while every slice keeps >= 4 k-tiles and the slabs fit
+        int sk = (3 * h->n_cu) / tiles;
+        if (sk > k_tiles / 4) sk = k_tiles / 4;
+        if (sk > 8) sk = 8;
+        while (sk > 1 && (size_t)sk * a.slab_stride > w.splitk_elems) --sk;
+        if (sk > 1) {
+            a.tiles_per_split = (k_tiles + sk - 1) / sk;
+            a.n_split = (k_tiles + a.tiles_per_split - 1) / a.tiles_per_split;
+            a.C = w.splitk;
+        }
+    }
+    Profile::Rec rec;
+    const bool prof = h->prof.on && family >= 0;
+    if (prof) {
+        GEM_HIP(hipEventCreate(&rec.a)); GEM_HIP(hipEventCreate(&rec.b));
+        rec.family = family;
+        rec.flops = 2.0 * M * (double)L.N * L.K * L.taps;
+        if (w.dyn && L.taps == 1) { rec.log_idx = w.cur_log; rec.flops_per_window = 2.0 * (double)L.N * L.K; }
+        GEM_HIP(hipEventRecord(rec.a, s));
+    }
+    const int grid = tiles * a.n_split;
+    const bool kernel_bf16 = out_bf16 && a.n_split == 1;
+    int rc = 1;
+    if (L.taps == 1) {
+        if (epi == EPI_BIAS) rc = launch_bn<1, EPI_BIAS>(h, a, grid, bn128, kernel_bf16, s);
+        else if (epi == EPI_NONE) rc = launch_bn<1, EPI_NONE>(h, a, grid, bn128, kernel_bf16, s);
+        else set_error("gemm_bf16a: unsupported epilogue for a linear layer");
+    } else if (L.taps == 3) {
+        if (epi == EPI_BIAS) rc = launch_bn<3, EPI_BIAS>(h, a, grid, bn128, kernel_bf16, s);
+        else if (epi == EPI_BIAS_LRELU) rc = launch_bn<3, EPI_BIAS_LRELU>(h, a, grid, bn128, kernel_bf16, s);
+        else if (epi == EPI_MASK) rc = launch_bn<3, EPI_MASK>(h, a, grid, bn128, kernel_bf16, s);
+        else if (epi == EPI_NONE) rc = launch_bn<3, EPI_NONE>(h, a, grid, bn128, kernel_bf16, s);
+    } else {
+        set_error("gemm_bf16a: taps must be 1 or 3");
+    }
+    if (rc) return rc;
+    if (a.n_split > 1) {
+        if (defer) {
+            SlabSrc& d = w.deferred;
+            d.base = w.splitk; d.nslab = a.n_split; d.stride = a.slab_stride; d.dyn_W = 0; d.m_dev = a.m_dev;
+        } else if (out_bf16) {
+            const size_t n4 = (size_t)M * (L.N / 4);
+            const dim3 grid_r((unsigned)((n4 + 255) / 256));
+            uint16_t* Cb = static_cast<uint16_t*>(C);
+            if (epi == EPI_BIAS) hipLaunchKernelGGL(splitk_reduce_bf16_kernel<EPI_BIAS>, grid_r, dim3(256), 0, s, w.splitk, a.n_split, a.slab_stride, L.bias, Cb, M, L.N, ldc, a.m_dev);
+            else if (epi == EPI_BIAS_LRELU) hipLaunchKernelGGL(splitk_reduce_bf16_kernel<EPI_BIAS_LRELU>, grid_r, dim3(256), 0, s, w.splitk, a.n_split, a.slab_stride, L.bias, Cb, M, L.N, ldc, a.m_dev);
+            else hipLaunchKernelGGL(splitk_reduce_bf16_kernel<EPI_NONE>, grid_r, dim3(256), 0, s, w.splitk, a.n_split, a.slab_stride, L.bias, Cb, M, L.N, ldc, a.m_dev);
+            GEM_HIP(hipGetLastError());
+        } else {
+            if (launch_splitk_reduce(h, epi, a.n_split, a.slab_stride, L.bias, nullptr, static_cast<float*>(C), M, L.N, ldc, a.m_dev, s)) return 1;
+        }
+    }
+    if (prof) { GEM_HIP(hipEventRecord(rec.b, s)); h->prof.recs.push_back(rec); }
+    return 0;
+}
+
+// One evaluation in the bf16 decoder mode: decodes ws.trial_b, leaves the pose in ws.dec_act.back() (fp32), the energies in
+// ws.f / ws.parts and dE/dz in ws.dz (or in ws.grad_slab for lbfgs_advance, in the rounds).
+int evaluate_bf16(gem_handle* h, int stage, int B, const EnergyArgs& ea_in, hipStream_t s, bool forward_only) {
+    StageNet& net = h->net[stage];
+    Workspace& w = h->ws;
+    const int T = h->T, rows = B * T, n_dec = (int)net.dec.size();
+    static const bool force_tail = getenv("GEM_FORCE_TAIL") != nullptr;
+    const int tail_g = T <= 16 ? 16 / T : 1;
+    const int tail_wgs = (B + tail_g - 1) / tail_g;
+    const bool use_tail = net.tail_start >= 1 && (tail_wgs <= 5 * h->n_cu || force_tail);
+    const int* perm = w.dyn ? w.perm : nullptr;
+    w.grad_slab = SlabSrc{};
+    // decoder_input: [B, Dp] x [Dp, T*topp] -> h0 [B*T, topp] bf16 (rows of finished windows are skipped through perm)
+    if (gemm_bf16a(h, net.dec_in, EPI_BIAS, w.trial_b, h->Dp, nullptr, w.h0_b, true, net.dec_in.N, B, s, 0, perm, true, false)) return 1;
+    const uint16_t* in = w.h0_b;
+    EnergyArgs ea = ea_in;
+    int back_from;                     // first layer of the batched backward chain
+    const uint16_t* gin;
+    if (use_tail) {
+        const int st = net.tail_start;
+        SlabSrc in_slab;
+        for (int i = 0; i < st; ++i) {
+            const bool last_wide = i == st - 1;
+            if (last_wide) {           // feeds the fp32 tail: fp32 slabs in the rounds, a finished fp32 matrix otherwise
+                if (gemm_bf16a(h, net.dec[i], EPI_BIAS_LRELU, in, net.dec[i].K, nullptr, w.dec_act[i], false, net.dec[i].N, rows, s, -1,
+                               nullptr, true, w.dyn)) return 1;
+                in_slab = w.deferred;
+            } else {
+                if (gemm_bf16a(h, net.dec[i], EPI_BIAS_LRELU, in, net.dec[i].K, nullptr, w.dec_act_b[i], true, net.dec[i].N, rows, s, -1,
+                               nullptr, true, false)) return 1;
+                in = w.dec_act_b[i];
+            }
+        }
+        TailArgs ta;
+        plan_tail(net.dec, st, T, h->J, &ta);
+        ta.B = B; ta.forward_only = forward_only ? 1 : 0; ta.dbg_ts = nullptr;
+        ta.in_slab = in_slab; ta.in_bias = net.dec[st - 1].bias;
+        for (int i = 0; i < ta.n; ++i) {
+            const Layer& f = net.dec[st + i];
+            const Layer& g = net.dec_bwd[st + i];
+            ta.fwd[i] = TailLayerDev{f.w4, f.bias, f.K, f.N};
+            ta.bwd[i] = TailLayerDev{g.w4, nullptr, g.K, g.N};
+        }
+        ta.a_in = w.dec_act[st - 1]; ta.g_out = nullptr; ta.g_out_b = w.dec_grad_b[st];
+        ta.Xp = (w.dyn && !forward_only) ? nullptr : w.dec_act.back();
+        ta.e = ea;
+        if (launch_tail(h, ta, net.tail_lds, s)) return 1;
+        if (forward_only) return 0;
+        back_from = st - 1;
+        gin = w.dec_grad_b[st];
+    } else {
+        for (int i = 0; i < n_dec; ++i) {
+            const bool last = i + 1 == n_dec;
+            if (last) {                // the pose itself: fp32
+                if (gemm_bf16a(h, net.dec[i], EPI_BIAS, in, net.dec[i].K, nullptr, w.dec_act[i], false, net.dec[i].N, rows, s, -1, nullptr,
+                               false, false)) return 1;
+            } else {
+                if (gemm_bf16a(h, net.dec[i], EPI_BIAS_LRELU, in, net.dec[i].K, nullptr, w.dec_act_b[i], true, net.dec[i].N, rows, s, -1,
+                               nullptr, false, false)) return 1;
+                in = w.dec_act_b[i];
+            }
+        }
+        if (forward_only) return 0;
+        ea.Xp = w.dec_act.back();
+        ea.dXp_b = w.dXp_b;
+        if (launch_energy(h, ea, B, s)) return 1;
+        back_from = n_dec - 1;
+        gin = w.dXp_b;
+    }
+    // backward-data through the batched layers: gradient w.r.t. the input of conv i, masked by LeakyReLU' of that input
+    for (int i = back_from; i >= 0; --i) {
+        const Layer& L = net.dec_bwd[i];
+        if (gemm_bf16a(h, L, i > 0 ? EPI_MASK : EPI_NONE, gin, L.K, i > 0 ? w.dec_act_b[i - 1] : nullptr, w.dec_grad_b[i], true, L.N, rows, s,
+                       -1, nullptr, i == 0, false)) return 1;
+        gin = w.dec_grad_b[i];
+    }
+    // decoder_input^T: dE/dz fp32; in the rounds lbfgs_advance sums the slabs itself
+    if (gemm_bf16a(h, net.dec_in_bwd, EPI_NONE, gin, net.dec_in_bwd.K, nullptr, w.dz, false, h->Dp, B, s, 0, nullptr, true, w.dyn)) return 1;
+    w.grad_slab = w.deferred;
+    return 0;
+}
+
+}  // namespace gem

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(64) void energy_kernel(EnergyArgs a) {
     if (a.n_dev && slot >= *a.n_dev) return;
     const int b = a.perm ? a.perm[slot] : slot;
     energy_window<true>(a, b, threadIdx.x, a.Xp + (size_t)slot * a.T * PAD, PAD, xs, gs, bs, as, a.dXp + (size_t)slot * a.T * PAD,
-                        PAD, PAD);
+                        PAD, PAD, a.dXp_b ? a.dXp_b + (size_t)slot * a.T * PAD : nullptr);
 }
 
 int launch_energy(gem_handle* h, const EnergyArgs& a, int B, hipStream_t s) {

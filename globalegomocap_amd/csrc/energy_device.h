@@ -32,7 +32,8 @@ __device__ __forceinline__ void energy_sync() {
 // once instead of once per 64-lane pass.
 template <bool BLOCK_SYNC, int NT = 64>
 __device__ __forceinline__ void energy_window(const EnergyArgs& a, int b, int lane, const float* xsrc, int ldx, float* xs,
-                                              float* gs, float* bs, float* as, float* gdst, int ldg, int gcols) {
+                                              float* gs, float* bs, float* as, float* gdst, int ldg, int gcols,
+                                              uint16_t* gdst_b = nullptr) {
     static_assert(NT == 64 || BLOCK_SYNC, "more than one wavefront per window needs workgroup barriers");
     const int T = a.T, J = a.J, JC = J * 3, n = T * JC;
     const float* x0 = a.X0 + (size_t)b * n;
@@ -156,7 +157,9 @@ __device__ __forceinline__ void energy_window(const EnergyArgs& a, int b, int la
     // gradient rows, zero-padded
     for (int i = lane; i < T * gcols; i += NT) {
         const int t = i / gcols, c = i - t * gcols;
-        gdst[t * ldg + c] = c < JC ? gs[t * JC + c] : 0.f;
+        const float v = c < JC ? gs[t * JC + c] : 0.f;
+        if (gdst_b) gdst_b[t * ldg + c] = (uint16_t)(__builtin_bit_cast(unsigned int, (float)(__bf16)v) >> 16);
+        else gdst[t * ldg + c] = v;
     }
     e3d = wave_sum(e3d); esm = wave_sum(esm); ebone = wave_sum(ebone); evae = wave_sum(evae); erep = wave_sum(erep);
     if (NT > 64) {                   // combine the wavefronts' partial sums in wave order (as[] is free by now)

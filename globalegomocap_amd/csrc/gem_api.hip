@@ -176,6 +176,19 @@ int gem_create(const gem_config* cfg, gem_handle** out) {
         cin = outs[i];
     }
     if (dev_alloc(w.allocs, &w.dXp, rows * PAD)) return 1;
+    // bf16 twins (gemm_bf16a.h / decoder_bf16.hip)
+    w.dec_act_b.assign(outs.size(), nullptr);
+    w.dec_grad_b.assign(outs.size(), nullptr);
+    {
+        int ci = h->top;
+        for (size_t i = 0; i < outs.size(); ++i) {
+            if (i + 1 < outs.size() && dev_alloc(w.allocs, &w.dec_act_b[i], rows * pad64(outs[i]))) return 1;
+            if (dev_alloc(w.allocs, &w.dec_grad_b[i], rows * pad64(ci))) return 1;
+            ci = outs[i];
+        }
+    }
+    if (dev_alloc(w.allocs, &w.trial_b, (size_t)B * h->Dp) || dev_alloc(w.allocs, &w.h0_b, rows * h->topp) ||
+        dev_alloc(w.allocs, &w.dXp_b, rows * PAD) || dev_alloc(w.allocs, &w.zero16, (size_t)128)) return 1;
     if (dev_alloc(w.allocs, &w.dz, (size_t)B * h->Dp)) return 1;
     float** vecs[] = {&w.x, &w.d, &w.g, &w.gp, &w.bg0, &w.bg1, &w.trial};
     for (float** v : vecs)
@@ -194,7 +207,9 @@ int gem_create(const gem_config* cfg, gem_handle** out) {
     if (dev_alloc(w.allocs, &w.n_log, (size_t)N_LOG)) return 1;
     if (dev_alloc(w.allocs, &w.perm, (size_t)B) || dev_alloc(w.allocs, &w.slot_of, (size_t)B) || dev_alloc(w.allocs, &w.n_active, 2))
         return 1;
-    w.splitk_elems = (size_t)8 << 20;      // 32 MB: split-K is only used while a layer has < 640 output tiles
+    // split-K slabs: only launches with few output tiles cut K; 64 MB, more when mid-size batches need it for the
+    // decoder_input backward product (rows x Dp x up to 4 slices)
+    w.splitk_elems = std::max((size_t)16 << 20, (size_t)std::min(B, 4096) * h->Dp * 4);
     if (dev_alloc(w.allocs, &w.splitk, w.splitk_elems)) return 1;
     std::vector<int> parents(cfg->parents, cfg->parents + cfg->n_joints);
     std::vector<int> children((size_t)GEM_MAX_JOINTS * GEM_MAX_JOINTS, -1);
@@ -387,7 +402,7 @@ static EnergyArgs energy_args(gem_handle* h, const float* X0, const float* heat,
     Workspace& w = h->ws;
     EnergyArgs a;
     a.Xp = w.dec_act.back(); a.X0 = X0; a.heat = heat; a.frame0 = frame0; a.mean_bone = mean_bone;
-    a.dXp = w.dXp; a.f = w.f; a.parts = w.parts;
+    a.dXp = w.dXp; a.dXp_b = nullptr; a.f = w.f; a.parts = w.parts;
     a.w3d = (float)wt.w3d; a.ws = (float)wt.smooth; a.wb = (float)wt.bone; a.wv = (float)wt.vae; a.wr = (float)wt.reproj;
     a.dw3d = wt.w3d; a.dws = wt.smooth; a.dwb = wt.bone; a.dwv = wt.vae; a.dwr = wt.reproj;
     a.T = h->T; a.J = h->J; a.H = h->cfg.heat_h; a.W = h->cfg.heat_w; a.n_poly = h->cfg.n_poly;
@@ -407,6 +422,7 @@ static int evaluate(gem_handle* h, int stage, int B, const float* zp, const Ener
     // time): measured against the batched GEMMs for the narrow layers it wins up to about five waves of workgroups
     // (fp32, windows/s: 480 windows 19.6 k vs 16.7 k, 960 windows 21.7 k vs 20.6 k, 1500 windows 23.4 k vs 23.7 k).
     // GEM_FORCE_TAIL=1 keeps it on for any batch.
+    if (h->precision == GEM_PRECISION_BF16) return evaluate_bf16(h, stage, B, ea, s, forward_only);      // zp == ws.trial, mirrored in ws.trial_b
     static const bool force_tail = getenv("GEM_FORCE_TAIL") != nullptr;
     const int tail_g = h->T <= 16 ? 16 / h->T : 1;
     const int tail_wgs = (B + tail_g - 1) / tail_g;
@@ -441,7 +457,7 @@ static int evaluate(gem_handle* h, int stage, int B, const float* zp, const Ener
         ta.fwd[i] = TailLayerDev{f.w4, f.bias, f.K, f.N};
         ta.bwd[i] = TailLayerDev{g.w4, nullptr, g.K, g.N};
     }
-    ta.a_in = st > 0 ? w.dec_act[st - 1] : w.h0; ta.g_out = w.dec_grad[st]; ta.Xp = (w.dyn && !forward_only) ? nullptr : w.dec_act.back();     // the pose is only read back outside the rounds
+    ta.a_in = st > 0 ? w.dec_act[st - 1] : w.h0; ta.g_out = w.dec_grad[st]; ta.g_out_b = nullptr; ta.Xp = (w.dyn && !forward_only) ? nullptr : w.dec_act.back();     // the pose is only read back outside the rounds
     ta.e = ea;
     if (launch_tail(h, ta, net.tail_lds, s)) return 1;
     if (forward_only) return 0;
@@ -460,6 +476,7 @@ static int optimize_stage_impl(gem_handle* h, int stage, int B, const float* d_p
     if (B == 0) return 0;
     if (encoder_forward(h, stage, B, d_pose_in, s)) return 1;
     if (launch_reparam(w.mulv, d_eps, nullptr, nullptr, nullptr, w.trial, B, h->D, h->Dp, s)) return 1;
+    if (h->precision == GEM_PRECISION_BF16 && launch_f32_to_bf16(w.trial, w.trial_b, (size_t)B * h->Dp, s)) return 1;
     if (launch_lbfgs_init(h, B, opt, s)) return 1;
     // Rounds run on the windows that are still iterating: after every advance they are re-packed to the front
     // (perm / n_active on the device) and the kernels of the next round read their row count from there.
@@ -527,6 +544,7 @@ int gem_energy_grad(gem_handle* h, int stage, int B, const float* d_z, const flo
     if (B == 0) return 0;
     Workspace& w = h->ws;
     if (launch_pad_latent(d_z, w.trial, B, h->D, h->Dp, s)) return 1;
+    if (h->precision == GEM_PRECISION_BF16 && launch_f32_to_bf16(w.trial, w.trial_b, (size_t)B * h->Dp, s)) return 1;
     const EnergyArgs ea = energy_args(h, d_pose_init, d_heat, d_frame0, d_mean_bone, *wt);
     if (evaluate(h, stage, B, w.trial, ea, s)) return 1;
     if (d_energy) GEM_HIP(hipMemcpyAsync(d_energy, w.f, (size_t)B * sizeof(double), hipMemcpyDeviceToDevice, s));

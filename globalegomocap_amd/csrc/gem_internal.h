@@ -84,6 +84,14 @@ struct Workspace {
     std::vector<float*> dec_grad;       // gradient w.r.t. the input of decoder conv i
     float* dXp = nullptr;               // [B*T, 64]
     float* dz = nullptr;                // [B, Dp]
+    // bf16 twins of the decoder activations / gradients: the "bf16 VAE decoder" mode keeps them in bf16 in HBM
+    // (gemm_bf16a.h); the decoded pose, the latent gradient and the L-BFGS state stay fp32
+    uint16_t* trial_b = nullptr;        // [B, Dp] bf16 copy of `trial` (written by lbfgs_advance / f32_to_bf16)
+    uint16_t* h0_b = nullptr;           // [B*T, topp]
+    std::vector<uint16_t*> dec_act_b;   // outputs of decoder convs but the last
+    std::vector<uint16_t*> dec_grad_b;  // gradient w.r.t. the input of decoder conv i
+    uint16_t* dXp_b = nullptr;          // [B*T, 64]
+    uint16_t* zero16 = nullptr;         // a line of zeros: DMA source of padded / absent rows
     // L-BFGS vectors, each [B, Dp]
     float *x = nullptr, *d = nullptr, *g = nullptr, *gp = nullptr, *bg0 = nullptr, *bg1 = nullptr, *trial = nullptr;
     float *S = nullptr, *Y = nullptr;   // [B, hist_cap, Dp]
@@ -219,6 +227,11 @@ int launch_splitk_reduce(gem_handle* h, int epi, int nslab, size_t slab, const f
 int launch_gemm_bf16(gem_handle* h, const Layer& L, int epi, int nprod, const float* A, int lda, const float* aux, float* Cout,
                      int ldc, int M, int T, hipStream_t s, const int* row_map);
 
+// bf16-activation decoder path (decoder_bf16.hip): one evaluation = decode + energies + backward-data, like evaluate()
+struct EnergyArgs;
+int evaluate_bf16(gem_handle* h, int stage, int B, const EnergyArgs& ea, hipStream_t s, bool forward_only);
+int launch_f32_to_bf16(const float* src, uint16_t* dst, size_t n, hipStream_t s);
+
 int launch_pack_pose(const float* src, float* dst, int rows, int C, hipStream_t s);      // [rows,C] -> [rows,64]
 int launch_unpack_pose(const float* src, float* dst, int rows, int C, hipStream_t s);    // [rows,64] -> [rows,C]
 int launch_reparam(const float* mulv, const float* eps, float* mu, float* logvar, float* z, float* z2, int B, int D, int Dp,
@@ -233,6 +246,7 @@ struct EnergyArgs {
     const int32_t* frame0;    // [B]
     const float* mean_bone;   // [B,J]
     float* dXp;               // [B*T, 64]
+    uint16_t* dXp_b;          // bf16 gradient rows instead of dXp (stand-alone energy kernel, bf16 decoder mode) or nullptr
     double* f;                // [B]
     double* parts;            // [B,5]
     float w3d, ws, wb, wv, wr;
@@ -258,6 +272,7 @@ struct TailArgs {
     TailLayerDev fwd[TAIL_MAX_LAYERS], bwd[TAIL_MAX_LAYERS];
     const float* a_in;       // [B*T, K0] input activation of the first fused layer
     float* g_out;            // [B*T, K0] gradient w.r.t. its pre-activation
+    uint16_t* g_out_b;       // the same as bf16 (bf16 decoder mode: consumed by the bf16 backward GEMMs) or nullptr
     float* Xp;               // [B*T, 64] decoded pose
     int off_act[TAIL_MAX_LAYERS + 1], ld_act[TAIL_MAX_LAYERS + 1], off_g[2], ld_g, off_red, off_escr, off_zero;   // LDS plan (floats)
     EnergyArgs e;

@@ -31,6 +31,7 @@ struct AdvArgs {
     double* trace;            // [B] closure values consumed in this round (nullptr: not recorded)
     const float* gnew;
     float *x, *d, *g, *gp, *bg0, *bg1, *trial, *S, *Y;
+    uint16_t* trial_b;        // bf16 copy of the trial point for the bf16 decoder mode (nullptr: none)
     const int* slot_of;       // window -> slot of its gradient row (nullptr: identity)
     SlabSrc gslab;            // base != nullptr: the gradient rows still lie in split-K slabs (summed here, in slab order)
     int Dp, hist_cap;
@@ -158,6 +159,27 @@ __device__ __forceinline__ void lbfgs_advance_body(const AdvArgs& a) {
         } else {
 #pragma unroll
             for (int i = 0; i < EPT; ++i) { const int e = tid + NT * i; if (FULL || e < Dp) p[off + e] = v[i]; }
+        }
+    };
+    auto store_trial = [&](const float (&v)[EPT]) {       // the next point to evaluate, fp32 and (bf16 decoder mode) bf16
+        store(a.trial, v);
+        if (a.trial_b) {
+            uint16_t* p = a.trial_b + off;
+            if constexpr (EPT % 4 == 0) {
+#pragma unroll
+                for (int i = 0; i < EPT / 4; ++i) {
+                    const int e = (tid + NT * i) * 4;
+                    typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+                    const bf4 w = __builtin_convertvector(f32x4{v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]}, bf4);
+                    if (FULL || e < Dp) *reinterpret_cast<bf4*>(p + e) = w;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < EPT; ++i) {
+                    const int e = tid + NT * i;
+                    if (FULL || e < Dp) p[e] = (uint16_t)(__builtin_bit_cast(unsigned int, (float)(__bf16)v[i]) >> 16);
+                }
+            }
         }
     };
     auto copy = [&](float* dst, const float* src) {
@@ -494,7 +516,7 @@ __device__ __forceinline__ void lbfgs_advance_body(const AdvArgs& a) {
     if (finished) {
         phase = PH_DONE;
         if (!have_x) load(a.x, xv);
-        store(a.trial, xv);
+        store_trial(xv);
     } else if (emit) {
         if (!have_x) load(a.x, xv);
         if (!have_d) load(a.d, dv);
@@ -502,7 +524,7 @@ __device__ __forceinline__ void lbfgs_advance_body(const AdvArgs& a) {
         float tr[EPT];
 #pragma unroll
         for (int i = 0; i < EPT; ++i) tr[i] = xv[i] + tf * dv[i];
-        store(a.trial, tr);
+        store_trial(tr);
         ls_evals++;
     }
     if (tid == 0) {
@@ -547,6 +569,7 @@ static AdvArgs make_args(gem_handle* h, const gem_lbfgs_opts& o) {
     a.state = w.state; a.f = w.f; a.gnew = w.dz;
     a.trace = (w.round >= 0 && w.round < TRACE_ROUNDS) ? w.trace + (size_t)w.round * w.Bmax : nullptr;
     a.x = w.x; a.d = w.d; a.g = w.g; a.gp = w.gp; a.bg0 = w.bg0; a.bg1 = w.bg1; a.trial = w.trial; a.S = w.S; a.Y = w.Y;
+    a.trial_b = h->precision == GEM_PRECISION_BF16 ? w.trial_b : nullptr;
     a.slot_of = w.dyn ? w.slot_of : nullptr;
     a.gslab = w.dyn ? w.grad_slab : SlabSrc{};
     a.Dp = h->Dp; a.hist_cap = w.hist_cap; a.o = o;        // hist_cap: power of two (gem_create)

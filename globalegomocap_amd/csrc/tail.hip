@@ -31,6 +31,12 @@ namespace gem {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// fp32 value rounded to the nearest bf16 (ties to even), still as fp32 bits (low 16 bits zero)
+__device__ __forceinline__ float bf16_round(float x) {
+    const __bf16 b = (__bf16)x;
+    return (float)b;
+}
+
 // 8 waves per workgroup = 2 per SIMD: the per-block latency chain (L2 weight fragment -> LDS fragment -> 16 MFMAs)
 // of one wave overlaps the other's, and K is cut twice as fine (each wave walks half as many blocks).
 constexpr int TAIL_WAVES = 8;
@@ -269,6 +275,7 @@ __global__ __launch_bounds__(TAIL_THREADS, 2) void decoder_tail_kernel(TailArgs 
         const int lda = a.ld_act[i];
         const int ldg = a.ld_g;
         float* gout = a.g_out;
+        uint16_t* gout_b = a.g_out_b;
         const int K0 = a.fwd[0].K;
         tail_gemm(g_cur, a.ld_g, lds + a.off_zero, a.bwd[i], a.bwd[i > 0 ? i - 1 : 0], i > 0, T, R, bpre,
                   [&](const f32x4& acc, int r0, int col, float) {
@@ -278,7 +285,10 @@ __global__ __launch_bounds__(TAIL_THREADS, 2) void decoder_tail_kernel(TailArgs 
                           // (a chain that starts at the first conv reads the linear decoder_input output: no mask)
                           const float v = (i > 0 || a.mask_first) ? acc[e] * (act[row * lda + col] > 0.f ? 1.f : LEAKY_SLOPE) : acc[e];
                           if (i > 0) g_nxt[row * ldg + col] = v;
-                          else if (row < R) gout[(row0 + row) * K0 + col] = v;
+                          else if (row < R) {
+                              if (gout_b) gout_b[(row0 + row) * K0 + col] = (uint16_t)(__builtin_bit_cast(unsigned int, bf16_round(v)) >> 16);
+                              else gout[(row0 + row) * K0 + col] = v;
+                          }
                       }
                   });
         __syncthreads();
