@@ -272,6 +272,63 @@ def main():
             in_flight[str(n)] = {"windows_per_s": round(B * n * a.steps / dt, 2), "ms_per_sequence": round(dt / (a.steps * n) * 1e3, 3)}
         del engines[1:]
 
+    # ---- side record (not `value`): BASELINE configs[2] -- "all 5 test-sequence shapes concurrently on 1 MI355X, bf16 VAE
+    # decoder / fp32 energy": 20 + 27 + 27 + 27 + 27 = 128 chunks = 1536 windows in ONE call, fp32 and bf16, each with the
+    # roofline of its own dominant kernel (decoder_input forward + backward-data, HIP events on the launch stream)
+    configs2 = None
+    if a.precision == "f32" and not a.no_extra and world == 1 and a.workload == "seq2k":
+        configs2 = {}
+        nc2 = 128
+        B2 = nc2 * len(window_starts(CHUNK))
+        seq2 = synth.make_sequence_device(nc2 * CHUNK, seed=2000, device=device, camera=cam, cam_jitter=CAM_JITTER)
+        starts2 = np.concatenate([c * CHUNK + window_starts(CHUNK) for c in range(nc2)]).astype(np.int32)
+        e2 = WindowEngine(shape, cam, max_windows=B2)
+        e2.load_vae(LOCAL_STAGE, sd_local)
+        e2.load_vae(GLOBAL_STAGE, sd_global)
+        mb2 = torch.stack([e2.mean_bone_length(seq2["est_local"][c * CHUNK:(c + 1) * CHUNK]) for c in range(nc2)])
+        mb2 = mb2[torch.as_tensor(np.repeat(np.arange(nc2), B2 // nc2), device=device)].contiguous()
+        g2 = torch.Generator().manual_seed(987)
+        eps2 = torch.randn(B2, 2, shape.latent_dim, generator=g2)
+        el2, eg2 = eps2[:, 0].contiguous().to(device), eps2[:, 1].contiguous().to(device)
+        f02 = torch.as_tensor(starts2, device=device)
+        per2 = B2 // nc2
+        gt2 = np.concatenate([seq2["gt_global"][c * CHUNK:c * CHUNK + 8 * per2 + 2] for c in range(nc2)])
+        n2 = max(3, min(a.steps, 10))
+        for mode in ("f32", "bf16"):
+            e2.set_precision(mode)
+
+            def step2():
+                return e2.optimize_windows(seq2["est_local"], seq2["cams"], seq2["heat"], f02, mb2, el2, eg2, w_local, w_global)
+            step2()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(n2):
+                e2.profile_enable(profile and i == 0)
+                m2, gl2, st2 = step2()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            e2.profile_enable(False)
+            ms_k, n_k, fl_k = e2.profile_read(0) if profile else (0.0, 0, 0.0)
+            sn2 = stats_to_numpy(st2)
+            ev2 = sn2["func_evals"].reshape(2, B2)
+            gl_np = gl2.cpu().numpy()
+            opt2 = np.concatenate([final_smooth(merge_batches(gl_np[c * per2:(c + 1) * per2])) for c in range(nc2)])
+            peak2 = PEAK_F32_MATRIX_TFLOPS if mode == "f32" else PEAK_BF16_MATRIX_TFLOPS
+            rec = {"windows": B2, "windows_per_s": round(B2 * n2 / dt, 1), "ms_per_step": round(dt / n2 * 1e3, 3),
+                   "evals_per_stage": {"local_mean": round(float(ev2[0].mean()), 2), "global_mean": round(float(ev2[1].mean()), 2)},
+                   "mpjpe_optimised_mm": round(mpjpe(opt2, gt2) * 1e3, 3), "all_finished": bool((sn2["status"] == 1).all())}
+            if n_k:
+                ach = fl_k / (ms_k * 1e-3) / 1e12
+                rec["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak2, "unit": "TFLOP/s", "frac": round(ach / peak2, 4),
+                                   "kernel": "decoder_input forward + backward-data (%s)" % ("gemm_f32_kernel" if mode == "f32" else "gemm_bf16a_kernel"),
+                                   "launches": int(n_k), "avg_us": round(ms_k * 1e3 / n_k, 2), "flop_per_launch": fl_k / n_k,
+                                   "traffic": None}
+            configs2[mode] = rec
+        configs2["workload"] = ("BASELINE configs[2]: five sequences of 20+27+27+27+27 chunks = %d windows in one call, local+global "
+                                "stage, bf16 = bf16 decoder activations and products / fp32 accumulate, energies and L-BFGS" % B2)
+        e2.close()
+        del seq2
+
     if rank == 0:
         st = stats_to_numpy(stats)
         assert (st["status"] == 1).all(), "a window did not finish"
@@ -310,7 +367,9 @@ def main():
                         "frac": round(achieved / peak, 4), "traffic": traffic if a.precision == "f32" else None,
                         "traffic_source": "profiles/traffic_dominant_kernel.json (separate rocprofv3 --pmc passes of this "
                                           "command, committed; NOT measured in this run)" if traffic and a.precision == "f32" else None,
-                        "kernel": "gemm_f32_kernel<1,EPI_BIAS,*,*,1> (decoder_input forward + backward-data)",
+                        "kernel": ("gemm_f32_kernel<1,EPI_BIAS,*,*,1>" if a.precision == "f32" else
+                                   "gemm_bf16a_kernel<1,*,128,128>" if a.precision == "bf16" else "gemm_bf16_kernel<1,*,3>")
+                                  + " (decoder_input forward + backward-data)",
                         "launches": int(n), "avg_us": round(ms * 1e3 / n, 2),
                         "flop_per_launch": fl / n}
         cpu = None
@@ -406,6 +465,7 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
             "other_precisions": other_modes or None,
+            "configs2": configs2,
             "sequences_in_flight": in_flight,
         }
         print(json.dumps(line), flush=True)

@@ -1,5 +1,5 @@
 // "bf16 VAE decoder / fp32 energy" (BASELINE configs[2..4]): one evaluation round with every decoder activation and
-// gradient kept in bf16 in HBM, all wide products on the bf16-activation MFMA kernel of gemm_bf16a.h.
+// gradient kept in bf16 in HBM, all wide products on the bf16-activation MFMA kernel of gemm_glds.h.
 //
 //   trial (bf16 copy written by lbfgs_advance) -> decoder_input -> h0 (bf16) -> temporal convs (bf16) -> pose X (fp32)
 //   -> energy terms + dE/dX (fp32 arithmetic, energy_device.h) -> adjoint convs (bf16) -> decoder_input^T -> dE/dz (fp32)
@@ -11,11 +11,12 @@
 #include <cstdlib>
 
 #include "gem_internal.h"
-#include "gemm_bf16a.h"
+#include "gemm_glds.h"
 
 namespace gem {
 
-using bf16a::Args;
+using glds::Args;
+namespace bf16a = glds;
 
 __global__ void f32_to_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, size_t n4) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_bf16_kernel(const float* __
 template <int TAPS, int EPI, int BN, bool OUT_BF16>
 static int launch_k(gem_handle* h, const Args& a, int grid, hipStream_t s) {
     constexpr int BM = 128;
-    auto k = bf16a::gemm_bf16a_kernel<TAPS, EPI, BM, BN, OUT_BF16, 16>;
+    auto k = glds::gemm_glds_kernel<false, TAPS, EPI, BM, BN, OUT_BF16, 16>;
     constexpr int BUF = (BM + BN) * 128;
     constexpr size_t smem = (size_t)(2 * BUF > BM * BN * 4 ? 2 * BUF : BM * BN * 4);
     static PerDeviceOnce once;

@@ -85,7 +85,7 @@ struct Workspace {
     float* dXp = nullptr;               // [B*T, 64]
     float* dz = nullptr;                // [B, Dp]
     // bf16 twins of the decoder activations / gradients: the "bf16 VAE decoder" mode keeps them in bf16 in HBM
-    // (gemm_bf16a.h); the decoded pose, the latent gradient and the L-BFGS state stay fp32
+    // (gemm_glds.h); the decoded pose, the latent gradient and the L-BFGS state stay fp32
     uint16_t* trial_b = nullptr;        // [B, Dp] bf16 copy of `trial` (written by lbfgs_advance / f32_to_bf16)
     uint16_t* h0_b = nullptr;           // [B*T, topp]
     std::vector<uint16_t*> dec_act_b;   // outputs of decoder convs but the last

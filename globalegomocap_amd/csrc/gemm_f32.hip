@@ -17,6 +17,7 @@
 #include <cstdlib>
 
 #include "gem_internal.h"
+#include "gemm_glds.h"
 
 namespace gem {
 
@@ -346,9 +347,38 @@ static int launch_one(gem_handle* h, const Layer& L, const float* A, int lda, co
     return launch_splitk_reduce(h, EPI, (int)grid.z, slab, L.bias, aux, C, M, L.N, ldc, m_dev, s, dyn ? (int)wgs : 0, n_tiles);
 }
 
+// Large batches: the LDS-DMA kernel of gemm_glds.h with fp32 operands (128x128x32 tiles, one wave per 64x64 with 16
+// independent 16x16x4 accumulators, operands global -> LDS by DMA).  Measured on the decoder_input shapes at 8192
+// windows: 133 TFLOP/s = 0.85 of the fp32 matrix peak (tools/gemm_glds_bench), against 113-127 for the register-staged
+// 128x128 kernel above.  No split-K: only used when the launch has >= 2 tiles per CU.
+template <int TAPS, int EPI>
+static int launch_glds_f32(gem_handle* h, const Layer& L, const float* A, int lda, const float* aux, float* C, int ldc, int M, int T,
+                           hipStream_t s, const int* row_map) {
+    constexpr int BM = 128, BN = 128;
+    auto k = glds::gemm_glds_kernel<true, TAPS, EPI, BM, BN, false, 16>;
+    constexpr size_t smem = (size_t)BM * BN * 4;
+    static PerDeviceOnce once;
+    if (once.need(h->cfg.device))
+        GEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_PER_CU));
+    glds::Args a{};
+    a.A = A; a.W = L.w; a.bias = L.bias; a.aux = aux; a.C = C; a.zero16 = h->ws.zero16;
+    a.m_dev = h->ws.dyn ? h->ws.n_active + (TAPS == 3 ? 1 : 0) : nullptr;
+    a.row_map = row_map;
+    a.lda = lda; a.ldc = ldc; a.M = M; a.N = L.N; a.K = L.K; a.T = T;
+    a.n_split = 1; a.tiles_per_split = TAPS * (L.K / 32); a.slab_stride = 0;
+    const int grid = ((M + BM - 1) / BM) * (L.N / BN);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), smem, s, a);
+    GEM_HIP(hipGetLastError());
+    return 0;
+}
+
 template <int TAPS, int EPI, int TAG>
 static int launch_tile(gem_handle* h, const Layer& L, const float* A, int lda, const float* aux, float* C, int ldc, int M, int T,
                        hipStream_t s, const int* row_map) {
+    static const bool no_glds = getenv("GEM_NO_GLDS_F32") != nullptr;          // developer override (A/B runs)
+    if (!no_glds && L.N % 128 == 0 && L.K % 32 == 0 && (long)((M + 127) / 128) * (L.N / 128) >= 2L * h->n_cu && h->ws.zero16 &&
+        !h->ws.defer_reduce)
+        return launch_glds_f32<TAPS, EPI>(h, L, A, lda, aux, C, ldc, M, T, s, row_map);
     // 128x128 tiles only when they still fill the chip (>= 2 workgroups per CU) and divide N
     const long big_blocks = (long)((M + 127) / 128) * (L.N / 128);
     static const char* force = getenv("GEM_FORCE_TILE");       // developer override: "1" = 64x64, "2" = 128x128, "3" = 64x64 BK64

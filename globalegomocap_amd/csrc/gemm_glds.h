@@ -1,18 +1,22 @@
-// bf16-activation MFMA GEMM / temporal-conv kernel (gfx950): the large-batch engine of the "bf16 VAE decoder" mode
-// (BASELINE configs[2..4]).  Same contract as gemm_f32_kernel,
+// MFMA GEMM / temporal-conv kernel fed by LDS-DMA (gfx950): the engine of the "bf16 VAE decoder" mode (BASELINE
+// configs[2..4], bf16 operands) and -- same structure, fp32 operands -- of the fp32 decoder_input products.
+// Same contract as gemm_f32_kernel,
 //
 //   C[M,N] = epi( sum_{tap<TAPS} shift_{tap-1}(A)[M,K] . W[tap][N][K]^T + bias[N] )      (SeqConvVAE.py:36,62-92,131-140)
 //
-// but BOTH operands are bf16 in HBM (activations are written as bf16 by the producing kernel's epilogue, weights are
-// converted once at load time), accumulation is fp32 (v_mfma_f32_32x32x16_bf16), and the output is bf16 (activations /
+// IN_F32 = false: both operands bf16 in HBM (activations are written as bf16 by the producing kernel's epilogue, weights
+// converted once at load time), fp32 accumulation (v_mfma_f32_16x16x32_bf16 / 32x32x16), output bf16 (activations /
 // gradients for the next layer) or fp32 (split-K slabs, the latent gradient, the decoded pose).
+// IN_F32 = true: both operands fp32 (v_mfma_f32_16x16x4_f32 / 32x32x2: exact fp32 FMA chains), fp32 output.
 //
-// Tile: BM x BN x 64, one wave per 64x64 (2x2 MFMA blocks of 32x32, four independent accumulators), 4 waves for
-// 128x128.  Both operand tiles go global -> LDS with global_load_lds_dwordx4 (no VGPR round trip, no convert in the
-// staging path), double-buffered: the DMA of K-step t+1 is issued before the MFMAs of step t.  LDS rows are 128 bytes
-// (64 bf16); the 16-byte chunk c of row r is stored at chunk position c ^ ((r >> 1) & 7), which makes the
-// ds_read_b128 fragment reads of the 32x32x16 operand layout conflict-free (the swizzle is applied to the per-lane
-// SOURCE address of the DMA -- its LDS side is lane-linear -- and to the fragment read address).
+// Tile: BM x BN x (128 bytes of K: 64 bf16 or 32 fp32), one wave per 64x64 of the output (4x4 blocks of 16x16 or 2x2 of
+// 32x32: independent accumulators, one wave keeps its SIMD's matrix pipe busy), 4 waves for 128x128.  Both operand
+// tiles go global -> LDS with global_load_lds_dwordx4 (no VGPR round trip, no convert in the staging path),
+// double-buffered: the DMA of K-step t+1 is issued before the MFMAs of step t.  LDS rows are 128 bytes; the 16-byte
+// chunk c of row r is stored at chunk position c ^ ((r >> 1) & 7), which makes the ds_read_b128 fragment reads of
+// both MFMA operand layouts conflict-free (the swizzle is applied to the per-lane SOURCE address of the DMA -- its
+// LDS side is lane-linear -- and to the fragment read address).  A lane's 16 bytes of a fragment feed several MFMA
+// k-steps; the pairing of k values inside a 128-byte row is a permutation that a sum over k does not care about.
 // The MFMA takes the WEIGHT fragment as its A operand and the activation fragment as B: D[n][m], so a lane ends up
 // with 4 consecutive output columns n of ONE row m per register quad; the epilogue stages the fp32 tile through LDS
 // (16-byte chunks, XOR-swizzled) and leaves as whole rows: bias / LeakyReLU / LeakyReLU'-mask are applied there on
@@ -27,7 +31,7 @@
 
 namespace gem {
 
-namespace bf16a {
+namespace glds {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -48,16 +52,16 @@ __device__ __forceinline__ float bf_lo(unsigned int u) { return __builtin_bit_ca
 __device__ __forceinline__ float bf_hi(unsigned int u) { return __builtin_bit_cast(float, u & 0xFFFF0000u); }
 
 struct Args {
-    const uint16_t* A;        // [rows, lda] bf16
-    const uint16_t* W;        // [TAPS][N][K] bf16, k contiguous
+    const void* A;            // [rows, lda] bf16 or fp32
+    const void* W;            // [TAPS][N][K] bf16 or fp32, k contiguous
     const float* bias;        // [N] or nullptr
-    const uint16_t* aux;      // EPI_MASK: bf16 activation whose sign selects LeakyReLU' (same [M, ldc] layout as the output)
+    const void* aux;          // EPI_MASK: activation (same type as A) whose sign selects LeakyReLU' (same [M, ldc] layout as the output)
     void* C;                  // bf16 or fp32 [M, ldc]; split-K: fp32 slabs, slab z at C + z * slab_stride
-    const uint16_t* zero16;   // >= 16 zero bytes in HBM: source of rows that lie outside the window / past M
+    const void* zero16;       // >= 16 zero bytes in HBM: source of rows that lie outside the window / past M
     const int* m_dev;         // device row count (evaluation rounds) or nullptr
     const int* row_map;       // gathered A rows (TAPS == 1 only) or nullptr
     int lda, ldc, M, N, K, T;
-    int n_split, tiles_per_split;     // split-K over the TAPS*K/64 k-tiles (1: none)
+    int n_split, tiles_per_split;     // split-K over the TAPS*K/BK k-tiles (1: none)
     size_t slab_stride;
 };
 
@@ -79,11 +83,13 @@ __device__ __forceinline__ bool tile_of_block(int id, int n_mt, int n_nt, int n_
     return true;
 }
 
-template <int TAPS, int EPI, int BM, int BN, bool OUT_BF16, int MF = 32>
-__global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_bf16a_kernel(const Args a) {
-    constexpr int BK = 64;
+template <bool IN_F32, int TAPS, int EPI, int BM, int BN, bool OUT_BF16, int MF = 16>
+__global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_glds_kernel(const Args a) {
+    static_assert(!(IN_F32 && OUT_BF16), "fp32 operands write fp32");
+    constexpr int ES = IN_F32 ? 4 : 2;           // operand element size
+    constexpr int BK = 128 / ES;                 // one K-step = 128 bytes of every row
     constexpr int WAVES_M = BM / 64, WAVES_N = BN / 64, NW = WAVES_M * WAVES_N, NT = NW * 64;
-    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, BUF = A_BYTES + B_BYTES;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF = A_BYTES + B_BYTES;
     constexpr int A_INSTR = A_BYTES / 1024 / NW, B_INSTR = B_BYTES / 1024 / NW;      // 1 KB DMA pieces per wave
     static_assert(A_BYTES % (1024 * NW) == 0 && B_BYTES % (1024 * NW) == 0, "tile must split into whole DMA pieces per wave");
     static_assert(2 * BUF >= BM * BN * 4 || true, "epilogue staging");
@@ -114,7 +120,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_bf16a_kernel(
         const bool ok = row < M;
         int src = row;
         if (TAPS == 1 && a.row_map) src = a.row_map[ok ? row : 0];
-        a_src[j] = reinterpret_cast<const unsigned char*>(a.A) + (size_t)src * a.lda * 2;
+        a_src[j] = reinterpret_cast<const unsigned char*>(a.A) + (size_t)src * a.lda * ES;
         a_t[j] = ok ? (TAPS == 3 ? row % a.T : 0) : -1;
         a_sw[j] = (lchunk ^ ((r >> 1) & 7)) * 16;
     }
@@ -122,21 +128,21 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_bf16a_kernel(
 #pragma unroll
     for (int j = 0; j < B_INSTR; ++j) {
         const int r = (wave * B_INSTR + j) * 8 + lrow;
-        b_src[j] = reinterpret_cast<const unsigned char*>(a.W) + ((size_t)(n0 + r) * a.K) * 2 + (lchunk ^ ((r >> 1) & 7)) * 16;
+        b_src[j] = reinterpret_cast<const unsigned char*>(a.W) + ((size_t)(n0 + r) * a.K) * ES + (lchunk ^ ((r >> 1) & 7)) * 16;
     }
     const unsigned char* zsrc = reinterpret_cast<const unsigned char*>(a.zero16);
-    const size_t tap_stride = (size_t)a.N * a.K * 2;
+    const size_t tap_stride = (size_t)a.N * a.K * ES;
 
     auto stage = [&](int buf, int kt) {
         const int tap = (TAPS == 3) ? (kt >= kTiles) + (kt >= 2 * kTiles) : 0;
-        const int kb = (kt - tap * kTiles) * (BK * 2);            // byte offset inside the row
+        const int kb = (kt - tap * kTiles) * 128;                 // byte offset inside the row
         unsigned char* la = smem + buf * BUF + wave * (A_INSTR * 1024);
         unsigned char* lb = smem + buf * BUF + A_BYTES + wave * (B_INSTR * 1024);
 #pragma unroll
         for (int j = 0; j < A_INSTR; ++j) {
             bool ok = a_t[j] >= 0;
             if (TAPS == 3) { const int tt = a_t[j] + tap - 1; ok = ok && tt >= 0 && tt < a.T; }
-            const unsigned char* p = ok ? a_src[j] + (ptrdiff_t)((TAPS == 3) ? (tap - 1) : 0) * a.lda * 2 + kb + a_sw[j] : zsrc;
+            const unsigned char* p = ok ? a_src[j] + (ptrdiff_t)((TAPS == 3) ? (tap - 1) : 0) * a.lda * ES + kb + a_sw[j] : zsrc;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
                                              (__attribute__((address_space(3))) void*)(la + j * 1024), 16, 0, 0);
         }
@@ -148,10 +154,12 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_bf16a_kernel(
         }
     };
 
-    // ---- main loop.  MF = 32: 2x2 blocks of v_mfma_f32_32x32x16_bf16 per wave; MF = 16: 4x4 blocks of v_mfma_f32_16x16x32_bf16
-    // (same LDS bytes and MFMA cycles per K-step; the chip holds a higher clock on the 16x16 shape).
+    // ---- main loop.  MF = 32: 2x2 blocks of 32x32 MFMAs per wave; MF = 16: 4x4 blocks of 16x16 (same LDS bytes and MFMA
+    // cycles per K-step; for bf16 the chip holds a higher clock on the 16x16 shape).  A lane reads 16 bytes of a row per
+    // fragment: 8 bf16 = the k values of ONE bf16 MFMA, or 4 fp32 = one k value each for FOUR fp32 MFMAs.
     constexpr int NB = 64 / MF;                  // blocks per wave and dimension
-    constexpr int KS = MF == 32 ? 16 : 32;       // k depth of one MFMA
+    constexpr int LG = 64 / MF;                  // lane groups along k (2 for 32x32, 4 for 16x16): group g reads chunk LG*s + g
+    constexpr int NSUB = 8 / LG;                 // fragment reads per K-step and block
     typedef float accv __attribute__((ext_vector_type(MF == 32 ? 16 : 4)));
     accv acc[NB][NB];      // [n block][m block]
 #pragma unroll
@@ -161,7 +169,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_bf16a_kernel(
 #pragma unroll
             for (int e = 0; e < (MF == 32 ? 16 : 4); ++e) acc[i][j][e] = 0.f;
 
-    // fragment read addresses: row R = wave base + MF*blk + (lane % MF), 16-byte chunk (KS/8)*s + lane / MF of k-substep s
+    // fragment read addresses: row R = wave base + MF*blk + (lane % MF), 16-byte chunk LG*s + lane / MF of sub-step s
     const int fr = lane % MF, fh = lane / MF;
     int a_off[NB], b_off[NB], a_x[NB], b_x[NB];
 #pragma unroll
@@ -178,20 +186,38 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_bf16a_kernel(
         if (kt + 1 < kt_end) stage(cur ^ 1, kt + 1);
         const unsigned char* base = smem + cur * BUF;
 #pragma unroll
-        for (int s = 0; s < BK / KS; ++s) {
-            bf16x8 af[NB], wf[NB];
+        for (int s = 0; s < NSUB; ++s) {
+            if constexpr (IN_F32) {
+                f32x4 af[NB], wf[NB];
 #pragma unroll
-            for (int q = 0; q < NB; ++q) {
-                af[q] = *reinterpret_cast<const bf16x8*>(base + a_off[q] + ((((KS / 8) * s + fh) ^ a_x[q]) << 4));
-                wf[q] = *reinterpret_cast<const bf16x8*>(base + b_off[q] + ((((KS / 8) * s + fh) ^ b_x[q]) << 4));
-            }
-#pragma unroll
-            for (int i = 0; i < NB; ++i)
-#pragma unroll
-                for (int j = 0; j < NB; ++j) {
-                    if constexpr (MF == 32) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
-                    else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+                for (int q = 0; q < NB; ++q) {
+                    af[q] = *reinterpret_cast<const f32x4*>(base + a_off[q] + (((LG * s + fh) ^ a_x[q]) << 4));
+                    wf[q] = *reinterpret_cast<const f32x4*>(base + b_off[q] + (((LG * s + fh) ^ b_x[q]) << 4));
                 }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < NB; ++i)
+#pragma unroll
+                        for (int j = 0; j < NB; ++j) {
+                            if constexpr (MF == 32) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[i][e], af[j][e], acc[i][j], 0, 0, 0);
+                            else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i][e], af[j][e], acc[i][j], 0, 0, 0);
+                        }
+            } else {
+                bf16x8 af[NB], wf[NB];
+#pragma unroll
+                for (int q = 0; q < NB; ++q) {
+                    af[q] = *reinterpret_cast<const bf16x8*>(base + a_off[q] + (((LG * s + fh) ^ a_x[q]) << 4));
+                    wf[q] = *reinterpret_cast<const bf16x8*>(base + b_off[q] + (((LG * s + fh) ^ b_x[q]) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < NB; ++i)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) {
+                        if constexpr (MF == 32) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+                    }
+            }
         }
         __syncthreads();          // (waits for this wave's DMA as well: the next tile is complete for everybody)
         cur ^= 1;
@@ -241,11 +267,21 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_bf16a_kernel(
                 for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * SLOPE;
             }
             if (EPI == EPI_MASK) {
-                const u32x4 m4 = *reinterpret_cast<const u32x4*>(a.aux + off);
+                if constexpr (IN_F32) {
+                    const f32x4 ma = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.aux) + off);
+                    const f32x4 mb = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.aux) + off + 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[2 * e] *= bf_lo(m4[e]) > 0.f ? 1.f : SLOPE;
-                    v[2 * e + 1] *= bf_hi(m4[e]) > 0.f ? 1.f : SLOPE;
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] *= ma[e] > 0.f ? 1.f : SLOPE;
+                        v[4 + e] *= mb[e] > 0.f ? 1.f : SLOPE;
+                    }
+                } else {
+                    const u32x4 m4 = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint16_t*>(a.aux) + off);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[2 * e] *= bf_lo(m4[e]) > 0.f ? 1.f : SLOPE;
+                        v[2 * e + 1] *= bf_hi(m4[e]) > 0.f ? 1.f : SLOPE;
+                    }
                 }
             }
         }
@@ -259,5 +295,5 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_bf16a_kernel(
     }
 }
 
-}  // namespace bf16a
+}  // namespace glds
 }  // namespace gem
