@@ -245,7 +245,8 @@ def main():
         eng.set_precision("f32")
 
     # ---- side measurement (not `value`): several sequences in flight on one GPU (BASELINE configs[2]'s regime): one engine
-    # and one HIP stream per sequence, the kernels of different sequences overlap on the device
+    # and one HIP stream per sequence, the kernels of different sequences overlap on the device.  Eager launches (the single
+    # host thread enqueues ~700 launches per sequence-step) and hipGraph replay (one launch per sequence-step, configs[4]).
     in_flight = None
     if a.precision == "f32" and not a.no_extra and world == 1 and a.workload == "seq2k":
         in_flight = {}
@@ -256,20 +257,31 @@ def main():
             e2.load_vae(GLOBAL_STAGE, sd_global)
             engines.append(e2)
         streams = [torch.cuda.Stream() for _ in engines]
-        for n in (2, 3):
-            def multi():
-                for e, st_ in zip(engines[:n], streams[:n]):
-                    with torch.cuda.stream(st_):
-                        e.optimize_windows(seqd["est_local"], seqd["cams"], seqd["heat"], f0, mb_w, eps_l, eps_g, w_local, w_global,
-                                           want_stats=False)
-            multi()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(a.steps):
-                multi()
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t1
-            in_flight[str(n)] = {"windows_per_s": round(B * n * a.steps / dt, 2), "ms_per_sequence": round(dt / (a.steps * n) * 1e3, 3)}
+        for mode in ("f32", "bf16"):
+            for graphs in (False, True):
+                for e in engines:
+                    e.set_precision(mode)
+                    e.enable_graphs(graphs)
+                for n in (1, 2, 3):
+                    def multi():
+                        for e, st_ in zip(engines[:n], streams[:n]):
+                            with torch.cuda.stream(st_):
+                                e.optimize_windows(seqd["est_local"], seqd["cams"], seqd["heat"], f0, mb_w, eps_l, eps_g, w_local, w_global,
+                                                   want_stats=False)
+                    multi(); multi()                    # (with graphs: eager warm-up, then capture)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(a.steps):
+                        multi()
+                    t_host = time.perf_counter() - t1
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - t1
+                    in_flight["%s_%s_%d" % (mode, "graph" if graphs else "eager", n)] = {
+                        "windows_per_s": round(B * n * a.steps / dt, 1), "ms_per_sequence": round(dt / (a.steps * n) * 1e3, 3),
+                        "host_enqueue_ms_per_sequence": round(t_host / (a.steps * n) * 1e3, 3)}
+        for e in engines:
+            e.set_precision("f32")
+            e.enable_graphs(False)
         del engines[1:]
 
     # ---- side record (not `value`): BASELINE configs[2] -- "all 5 test-sequence shapes concurrently on 1 MI355X, bf16 VAE

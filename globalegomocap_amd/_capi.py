@@ -59,6 +59,8 @@ SIGNATURES = {
                                      C.POINTER(GemLbfgsOpts), _P, _P, _P]),
     "gem_optimize_windows": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.POINTER(GemEnergyWeights),
                                        C.POINTER(GemEnergyWeights), C.POINTER(GemLbfgsOpts), _P, _P, _P, _P]),
+    "gem_graph_enable": (C.c_int, [_P, C.c_int]),
+    "gem_graph_stats": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "gem_read_trace": (C.c_int, [_P, C.c_int, C.c_int, _P, _P]),
     "gem_merge_windows": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "gem_calculate_errors": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.POINTER(C.c_double), _P, _P]),

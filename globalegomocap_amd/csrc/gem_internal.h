@@ -171,6 +171,24 @@ __device__ __forceinline__ double wave_max_dpp(double v) {
 
 }  // namespace gem
 
+namespace gem {
+// hipGraph cache of whole optimisation calls (gem_graph_enable): a call is identified by everything that is baked into its
+// kernel arguments -- entry point, batch size, precision, every caller pointer, the energy weights and optimiser options
+struct GraphKey {
+    int kind = 0, stage = 0, B = 0, precision = 0;
+    const void* ptr[12] = {};
+    gem_energy_weights w[2] = {};
+    gem_lbfgs_opts opt = {};
+    void* stream = nullptr;
+};
+struct GraphEntry {
+    GraphKey key;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;      // nullptr: seen once (ran eagerly), captured on the next identical call
+    uint64_t last_use = 0;
+};
+}  // namespace gem
+
 struct gem_handle {
     gem_config cfg;
     int T, J, C, Cp, D, Dp, top, topp;
@@ -181,6 +199,10 @@ struct gem_handle {
     int n_cu = 256;                // compute units of the device (hipDeviceAttributeMultiprocessorCount)
     double* post_work = nullptr;   // scratch of the post-processing calls (errors.hip), grown on demand
     size_t post_work_elems = 0;
+    bool graphs_on = false;        // gem_graph_enable
+    std::vector<gem::GraphEntry> graphs;
+    uint64_t graph_tick = 0;
+    int64_t graph_replays = 0, graph_captures = 0;
     int* d_parents = nullptr;
     int* d_children = nullptr;     // [J][J] child lists, -1 terminated
 };

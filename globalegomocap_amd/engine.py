@@ -57,6 +57,7 @@ class WindowEngine:
         _capi.check(self.lib.gem_create(C.byref(cfg), C.byref(self._h)), self.lib)
         self.T, self.D = self.shape.seq_len, self.shape.latent_dim
         self.precision = "f32"
+        self._graphs, self._gstream, self._bufs = False, None, {}
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -68,6 +69,44 @@ class WindowEngine:
             self.close()
         except Exception:
             pass
+
+    def enable_graphs(self, on=True):
+        """hipGraph replay of whole `optimize_windows` / `optimize_stage` calls (gem_graph_enable): the first call with a
+        given signature runs eagerly, the second is captured, later ones are ONE graph launch instead of ~700 kernel launches.
+        With graphs on, the calls run on a stream owned by the engine (the legacy default stream cannot be captured; the
+        caller's current stream waits for it) and their OUTPUT tensors are engine-owned buffers that the next call with the
+        same batch size overwrites -- which is what keeps the signature (all pointers) stable.  Inputs must be the same
+        tensors from call to call to get replays."""
+        _capi.check(self.lib.gem_graph_enable(self._h, 1 if on else 0), self.lib)
+        self._graphs = bool(on)
+        if on and self._gstream is None:
+            self._gstream = torch.cuda.Stream(device=self.device)
+
+    def graph_stats(self):
+        c, r = C.c_int64(), C.c_int64()
+        _capi.check(self.lib.gem_graph_stats(self._h, C.byref(c), C.byref(r)), self.lib)
+        return {"captures": c.value, "replays": r.value}
+
+    def _out(self, key, shape, dtype, zero=False):
+        """Output buffer: fresh per call, or (graphs on) one persistent buffer per (entry point, role, shape)."""
+        if not self._graphs:
+            return (torch.zeros if zero else torch.empty)(shape, device=self.device, dtype=dtype)
+        k = (key, tuple(shape), dtype)
+        if k not in self._bufs:
+            self._bufs[k] = torch.zeros(shape, device=self.device, dtype=dtype)
+        return self._bufs[k]
+
+    def _call(self, fn):
+        """Run fn(stream_ptr) on the caller's current stream, or (graphs on) on the engine's stream, ordered after
+        everything already enqueued on the current stream and before everything enqueued on it afterwards."""
+        if not self._graphs:
+            return fn(_stream())
+        cur = torch.cuda.current_stream()
+        self._gstream.wait_stream(cur)
+        with torch.cuda.stream(self._gstream):
+            r = fn(C.c_void_p(self._gstream.cuda_stream))
+        cur.wait_stream(self._gstream)
+        return r
 
     def set_precision(self, mode):
         """'f32' (default) | 'bf16x3' (split-bf16 MFMA, fp32-grade) | 'bf16' for the wide decoder/encoder products."""
@@ -146,10 +185,11 @@ class WindowEngine:
         heat_t = self._f32(heat) if heat is not None else None
         f0 = self._i32(frame0) if frame0 is not None else None
         opts = opts or _capi.default_lbfgs_opts()
-        out = torch.empty(B, self.T, N_JOINTS, 3, device=self.device)
-        stats = torch.zeros(B, 4, device=self.device, dtype=torch.int32) if want_stats else None
-        _capi.check(self.lib.gem_optimize_stage(self._h, stage, B, _ptr(p), _ptr(heat_t), _ptr(f0), _ptr(mb), _ptr(eps_t),
-                                                C.byref(weights), C.byref(opts), _ptr(out), _ptr(stats), _stream()), self.lib)
+        out = self._out("stage_out", (B, self.T, N_JOINTS, 3), torch.float32)
+        stats = self._out("stage_stats", (B, 4), torch.int32, zero=True) if want_stats else None
+        self._call(lambda st: _capi.check(self.lib.gem_optimize_stage(self._h, stage, B, _ptr(p), _ptr(heat_t), _ptr(f0), _ptr(mb),
+                                                                      _ptr(eps_t), C.byref(weights), C.byref(opts), _ptr(out),
+                                                                      _ptr(stats), st), self.lib))
         return out, stats
 
     def optimize_windows(self, local_pose, cams, heat, frame0, mean_bone, eps_local, eps_global, w_local, w_global,
@@ -165,13 +205,14 @@ class WindowEngine:
             if t is not None and (t.dtype != dt or not t.is_cuda or not t.is_contiguous()):
                 raise TypeError("optimize_windows wants contiguous device tensors of the documented dtypes")
         opts = opts or _capi.default_lbfgs_opts()
-        mid = torch.empty(B, self.T, N_JOINTS, 3, device=self.device)
-        glob = torch.empty(B, self.T, N_JOINTS, 3, device=self.device, dtype=torch.float64)
-        stats = torch.zeros(2 * B, 4, device=self.device, dtype=torch.int32) if want_stats else None
-        _capi.check(self.lib.gem_optimize_windows(self._h, B, _ptr(local_pose), _ptr(cams), _ptr(heat), _ptr(frame0),
-                                                  _ptr(mean_bone), _ptr(eps_local), _ptr(eps_global), C.byref(w_local),
-                                                  C.byref(w_global), C.byref(opts), _ptr(mid), _ptr(glob), _ptr(stats),
-                                                  _stream()), self.lib)
+        mid = self._out("win_mid", (B, self.T, N_JOINTS, 3), torch.float32)
+        glob = self._out("win_glob", (B, self.T, N_JOINTS, 3), torch.float64)
+        stats = self._out("win_stats", (2 * B, 4), torch.int32, zero=True) if want_stats else None
+        self._call(lambda st: _capi.check(self.lib.gem_optimize_windows(self._h, B, _ptr(local_pose), _ptr(cams), _ptr(heat),
+                                                                        _ptr(frame0), _ptr(mean_bone), _ptr(eps_local),
+                                                                        _ptr(eps_global), C.byref(w_local), C.byref(w_global),
+                                                                        C.byref(opts), _ptr(mid), _ptr(glob), _ptr(stats), st),
+                                          self.lib))
         return mid, glob, stats
 
     def read_trace(self, B, n_rounds=33):

@@ -153,6 +153,17 @@ int gem_optimize_windows(gem_handle* h, int B, const float* d_local_pose, const 
                          const gem_lbfgs_opts* opt, float* d_mid_local, double* d_global,
                          gem_window_stats* d_stats, void* stream);
 
+/* hipGraph replay of whole optimisation calls (BASELINE configs[4] "hipGraph-captured inner step"; the loop being captured
+ * replaces optimizer.py:261-270 for every window of the call).  With graphs on, gem_optimize_stage / gem_optimize_windows
+ * run eagerly the first time they see a given signature (batch size, precision, every pointer argument, weights, options,
+ * stream), capture the second call into a hipGraph and replay that graph from then on: one hipGraphLaunch instead of ~700
+ * kernel launches per call.  Results are bitwise those of the eager path.  Needs a non-default stream (the legacy default
+ * stream cannot be captured: such calls stay eager) and profiling off.  The caller must pass the SAME buffers to get
+ * replays; a call with other pointers is a new signature (at most 16 are cached per handle).
+ * gem_graph_stats: number of captures and replays so far. */
+int gem_graph_enable(gem_handle* h, int on);
+int gem_graph_stats(gem_handle* h, int64_t* n_captures, int64_t* n_replays);
+
 /* ---- sequence post-processing: the reporting side of the path, on the same stream ----
  * Both calls may grow an internal scratch buffer (hipMalloc, synchronous) the first time a larger sequence is seen. */
 
