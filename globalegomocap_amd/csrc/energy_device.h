@@ -97,8 +97,11 @@ __device__ __forceinline__ void energy_window(const EnergyArgs& a, int b, int la
             const float x = xs[p * 3 + 0], y = xs[p * 3 + 1], z = xs[p * 3 + 2];
             const float zz = -z;
             const float nn = sqrtf(x * x + y * y);
-            // nn == 0 is rejected by the reference ("norm is zero!"); here it yields inf/nan in f, which
-            // the host wrapper turns into the same exception.
+            // nn == 0 (joint on the optical axis) is rejected by the reference: Exception("norm is zero!"),
+            // FishEyeCalibrated.py:124-127.  Here it poisons the window's energy with NaN explicitly (the masked texels
+            // alone would leave f finite); lbfgs_advance latches a NaN closure value into the window's status, which the
+            // host wrapper turns into the same exception.
+            if (nn == 0.f) erep = __builtin_nan("");
             const float inv = 1.f / nn;
             const float theta = atanf(zz / nn);
             float rho = a.poly[0], drho = 0.f, ti = 1.f;

@@ -55,7 +55,7 @@ struct StageNet {
 // floats or 0-dim tensors; see lbfgs.hip)
 struct alignas(16) LbfgsState {
     int phase, n_iter, evals, ls_iter, ls_evals, max_ls, first_bracket, ls_done, insuf, low, high;
-    int hist_count, hist_start, pad0;
+    int hist_count, hist_start, nan_seen;      // nan_seen: a closure value was NaN (degenerate projection), latched
     double loss, prev_loss, t, gtd, d_norm, H_diag;
     double t_prev, f_prev, gtd_prev;
     double br_t[2], br_f[2], br_gtd[2];

@@ -128,6 +128,7 @@ __device__ __forceinline__ void lbfgs_advance_body(const AdvArgs& a) {
 
     const double f_new = a.f[b];
     if (a.trace && tid == 0) a.trace[b] = f_new;
+    if (f_new != f_new && tid == 0) sp->nan_seen = 1;
     const float* gsrc = a.gnew + (size_t)(a.slot_of ? a.slot_of[b] : b) * Dp;
     float gn[EPT], xv[EPT], dv[EPT], gcur[EPT], yv[EPT], sv[EPT];
     bool have_x = false, have_d = false;
@@ -548,6 +549,7 @@ __global__ void lbfgs_init_kernel(LbfgsState* st, const float* __restrict__ tria
         LbfgsState* s = st + i;
         s->phase = PH_INIT; s->n_iter = 0; s->evals = 0; s->ls_iter = 0; s->ls_evals = 0; s->max_ls = 0;
         s->first_bracket = 0; s->ls_done = 0; s->insuf = 0; s->low = 0; s->high = 1; s->hist_count = 0; s->hist_start = 0;
+        s->nan_seen = 0;
         s->loss = 0; s->prev_loss = 0; s->t = 0; s->gtd = 0; s->d_norm = 0; s->H_diag = 1;
         s->t_prev = 0; s->f_prev = 0; s->gtd_prev = 0;
         s->br_t[0] = s->br_t[1] = 0; s->br_f[0] = s->br_f[1] = 0; s->br_gtd[0] = s->br_gtd[1] = 0;
@@ -560,7 +562,7 @@ __global__ void lbfgs_stats_kernel(const LbfgsState* st, gem_window_stats* out, 
     out[i].n_iter = st[i].n_iter;
     out[i].func_evals = st[i].evals;
     out[i].final_loss = (float)st[i].loss;
-    out[i].status = st[i].phase == PH_DONE ? 1 : 0;
+    out[i].status = (st[i].phase == PH_DONE ? 1 : 0) | (st[i].nan_seen ? 2 : 0);
 }
 
 static AdvArgs make_args(gem_handle* h, const gem_lbfgs_opts& o) {

@@ -18,6 +18,19 @@ def shard_range(n_windows, rank, world):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def shard_indices(n_windows, rank, world, block=None):
+    """Window indices of rank `rank`.  block=None: the contiguous range of `shard_range`.  block=k: block-cyclic -- blocks
+    of k consecutive windows are dealt round-robin over the ranks, so that stretches of a long sequence whose windows finish
+    early (few L-BFGS evaluations) or late are spread over all ranks instead of landing on one; a
+    block keeps k overlapping windows = 8k + 2 contiguous frames together, so frames are still stored (almost) once."""
+    if block is None:
+        lo, hi = shard_range(n_windows, rank, world)
+        return np.arange(lo, hi)
+    blocks = np.arange(0, n_windows, block)
+    mine = blocks[rank::world]
+    return np.concatenate([np.arange(b, min(b + block, n_windows)) for b in mine]) if len(mine) else np.zeros(0, dtype=np.int64)
+
+
 def frame_span(starts, lo, hi, seq_len):
     """Frames [f0, f1) that the windows [lo, hi) touch: what a rank has to hold in HBM."""
     if hi <= lo:
@@ -55,6 +68,32 @@ def all_gather_windows(local, n_windows, group=None):
     if all(h - l == cap for l, h in sizes):
         return out
     return torch.cat([out[r * cap: r * cap + (h - l)] for r, (l, h) in enumerate(sizes)], dim=0)
+
+
+def all_gather_indexed(local, n_windows, block, group=None):
+    """all_gather for `shard_indices(..., block)` shards: every rank contributes its rows, every rank receives all
+    n_windows rows in window order.  One collective of equal-size (padded) shards, then one scatter by index."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    idx = [shard_indices(n_windows, r, world, block) for r in range(world)]
+    if local.shape[0] != len(idx[rank]):
+        raise ValueError("rank %d holds %d windows, its shard is %d" % (rank, local.shape[0], len(idx[rank])))
+    cap = max(len(i) for i in idx)
+    dev = local.device
+    gloo = dist.get_backend(group) == "gloo"
+    buf = torch.zeros((cap,) + tuple(local.shape[1:]), dtype=local.dtype, device="cpu" if gloo else dev)
+    buf[: local.shape[0]] = local
+    if gloo:
+        parts = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(parts, buf, group=group)
+    else:
+        flat = torch.empty((world * cap,) + tuple(local.shape[1:]), dtype=local.dtype, device=dev)
+        dist.all_gather_into_tensor(flat, buf, group=group)
+        parts = [flat[r * cap:(r + 1) * cap] for r in range(world)]
+    out = torch.empty((n_windows,) + tuple(local.shape[1:]), dtype=local.dtype, device=parts[0].device)
+    for r in range(world):
+        if len(idx[r]):
+            out[torch.as_tensor(idx[r], device=out.device)] = parts[r][: len(idx[r])]
+    return out.to(dev)
 
 
 def optimize_sharded(run_shard, starts, seq_len=10, group=None):

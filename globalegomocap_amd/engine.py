@@ -136,6 +136,23 @@ class WindowEngine:
         if B > self.max_windows:
             raise ValueError("B=%d exceeds max_windows=%d of this engine" % (B, self.max_windows))
 
+    def _check_heat(self, heat_t, frame0, B):
+        """Heat-map resolution and window starts against the frames actually held (the C ABI never learns n_frames: a wrong
+        start would be a silent out-of-bounds read on the device).  frame0 is checked when it is host data (no sync)."""
+        if heat_t is None:
+            return
+        if heat_t.dim() != 4 or tuple(heat_t.shape[1:]) != (self.heat_size[0], self.heat_size[1], N_JOINTS):
+            raise ValueError("heat-maps must be [F,%d,%d,%d] (the engine's heat_size), got %s"
+                             % (self.heat_size[0], self.heat_size[1], N_JOINTS, tuple(heat_t.shape)))
+        if frame0 is None:
+            raise ValueError("heat-maps need the first frame of every window (frame0)")
+        if not torch.is_tensor(frame0) or not frame0.is_cuda:
+            f = np.asarray(frame0.cpu() if torch.is_tensor(frame0) else frame0).reshape(-1)
+            if f.shape[0] != B:
+                raise ValueError("frame0 has %d entries for %d windows" % (f.shape[0], B))
+            if B and (f.min() < 0 or f.max() + self.T > heat_t.shape[0]):
+                raise ValueError("a window [frame0, frame0 + %d) leaves the %d frames of heat-maps" % (self.T, heat_t.shape[0]))
+
     def mean_bone_length(self, poses):
         p = self._f32(poses).reshape(-1, N_JOINTS, 3)
         out = torch.empty(N_JOINTS, device=self.device, dtype=torch.float32)
@@ -168,6 +185,7 @@ class WindowEngine:
         mb = self._f32(mean_bone).reshape(-1, N_JOINTS).expand(B, N_JOINTS).contiguous()
         heat_t = self._f32(heat) if heat is not None else None
         f0 = self._i32(frame0) if frame0 is not None else None
+        self._check_heat(heat_t, frame0, B)
         E = torch.empty(B, device=self.device, dtype=torch.float64)
         parts = torch.empty(B, 5, device=self.device, dtype=torch.float64)
         dz = torch.empty(B, self.D, device=self.device)
@@ -184,6 +202,7 @@ class WindowEngine:
         eps_t = self._f32(eps).reshape(B, self.D)
         heat_t = self._f32(heat) if heat is not None else None
         f0 = self._i32(frame0) if frame0 is not None else None
+        self._check_heat(heat_t, frame0, B)
         opts = opts or _capi.default_lbfgs_opts()
         out = self._out("stage_out", (B, self.T, N_JOINTS, 3), torch.float32)
         stats = self._out("stage_stats", (B, 4), torch.int32, zero=True) if want_stats else None
@@ -204,6 +223,19 @@ class WindowEngine:
                       (mean_bone, torch.float32), (eps_local, torch.float32), (eps_global, torch.float32)):
             if t is not None and (t.dtype != dt or not t.is_cuda or not t.is_contiguous()):
                 raise TypeError("optimize_windows wants contiguous device tensors of the documented dtypes")
+        F = local_pose.shape[0]
+        if cams.shape[0] != F or (heat is not None and heat.shape[0] != F):
+            raise ValueError("optimize_windows: local_pose, cams and heat must cover the same frames (%d / %d / %s)"
+                             % (F, cams.shape[0], None if heat is None else heat.shape[0]))
+        if tuple(local_pose.shape[1:]) != (N_JOINTS, 3) or tuple(cams.shape[1:]) != (4, 4):
+            raise ValueError("optimize_windows: local_pose must be [F,15,3] and cams [F,4,4]")
+        if heat is not None and tuple(heat.shape[1:]) != (self.heat_size[0], self.heat_size[1], N_JOINTS):
+            raise ValueError("optimize_windows: heat-maps must be [F,%d,%d,%d] (the engine's heat_size), got %s"
+                             % (self.heat_size[0], self.heat_size[1], N_JOINTS, tuple(heat.shape)))
+        if tuple(mean_bone.shape) != (B, N_JOINTS) or tuple(eps_local.shape) != (B, self.D) or tuple(eps_global.shape) != (B, self.D):
+            raise ValueError("optimize_windows: mean_bone must be [B,15] and eps_* [B,%d] with B = %d windows" % (self.D, B))
+        if F < self.T:
+            raise ValueError("optimize_windows: %d frames cannot hold a %d-frame window" % (F, self.T))
         opts = opts or _capi.default_lbfgs_opts()
         mid = self._out("win_mid", (B, self.T, N_JOINTS, 3), torch.float32)
         glob = self._out("win_glob", (B, self.T, N_JOINTS, 3), torch.float64)

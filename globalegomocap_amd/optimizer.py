@@ -37,8 +37,8 @@ def _as_state_dict(vae):
 
 def _raise_if_degenerate(stats):
     # a joint exactly on the optical axis makes the projection undefined; the reference raises
-    # Exception("norm is zero!") from FishEyeCalibrated.py:124-127, here it surfaces as a NaN loss
-    if stats is not None and not np.isfinite(stats["final_loss"]).all():
+    # Exception("norm is zero!") from FishEyeCalibrated.py:124-127; the device latches it in bit 1 of the window status
+    if stats is not None and ((stats["status"] & 2).any() or not np.isfinite(stats["final_loss"]).all()):
         raise Exception("norm is zero!")
 
 
@@ -116,6 +116,13 @@ class SequenceOptimizer:
         e = self.engine
         dev = e.device
         B = len(starts)
+        n_frames = len(est_local)
+        if len(cams) != n_frames or len(heat) != n_frames:
+            raise ValueError("est_local, cams and heat must cover the same frames (%d / %d / %d)" % (n_frames, len(cams), len(heat)))
+        if B and (int(np.min(starts)) < 0 or int(np.max(starts)) + self.seq_len > n_frames):
+            raise ValueError("a window [start, start + %d) leaves the %d frames of the sequence" % (self.seq_len, n_frames))
+        if len(chunk_of_window) != B or (B and int(np.max(chunk_of_window)) >= len(chunk_bounds)):
+            raise ValueError("chunk_of_window must name one of the %d chunks for each of the %d windows" % (len(chunk_bounds), B))
         pose_d = torch.as_tensor(np.asarray(est_local), dtype=torch.float32).to(dev).contiguous()
         cams_d = torch.as_tensor(np.asarray(cams), dtype=torch.float64).to(dev).contiguous()
         heat_d = (heat if torch.is_tensor(heat) else torch.as_tensor(np.asarray(heat))).to(dev, dtype=torch.float32).contiguous()

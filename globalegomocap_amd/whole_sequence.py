@@ -13,6 +13,7 @@ drawn (chunk by chunk, window by window, local then global) follow the reference
 import os
 import pickle
 import re
+import threading
 from collections import OrderedDict
 
 import numpy as np
@@ -38,9 +39,13 @@ SUMMARY_LINES = (          # (label printed by the reference, key) in print orde
 )
 
 
+_reader_local = threading.local()      # per reader thread: copy stream + pinned staging buffer, reused from chunk to chunk
+
+
 def natural_key(name):
-    """Sort key equivalent to natsort.natsorted for directory names like chunk_2 < chunk_10."""
-    return [int(t) if t.isdigit() else t.lower() for t in re.split(r"(\d+)", name)]
+    """Sort key equivalent to natsort.natsorted (default algorithm: case-sensitive text, unsigned integers) for directory
+    names like chunk_2 < chunk_10 (optimize_whole_sequence.py:48)."""
+    return [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", name)]
 
 
 def list_chunks(data_dir):
@@ -62,20 +67,27 @@ def load_chunk(path, device=None):
     if device is None:
         c["heat"] = np.asarray(heat, dtype=np.float32)
     else:
-        # frame by frame into one pinned staging buffer (no intermediate 25 MB numpy copy), then one async H2D copy on
-        # this thread's own stream; the consumer waits on the event
+        # into this reader thread's pinned staging buffer (one np.stack-free pass, no intermediate pageable copy), then one
+        # async H2D copy on the thread's own stream; the consumer waits on the event and marks the tensor as used on its stream
         n = len(heat)
         shape = (n,) + tuple(np.shape(heat[0])) if n else (0, 64, 64, 15)
-        stage = torch.empty(shape, dtype=torch.float32).pin_memory()
-        view = stage.numpy()
-        for i in range(n):
-            view[i] = heat[i]
-        stream = torch.cuda.Stream(device=device)
-        with torch.cuda.stream(stream):
-            c["heat"] = stage.to(device, non_blocking=True)
+        tl = _reader_local
+        if getattr(tl, "stream", None) is None or tl.device != device:
+            tl.stream, tl.device, tl.stage, tl.copied = torch.cuda.Stream(device=device), device, None, None
+        numel = int(np.prod(shape))
+        if tl.stage is None or tl.stage.numel() < numel:
+            tl.stage = torch.empty(max(numel, 1), dtype=torch.float32).pin_memory()
+        if tl.copied is not None:
+            tl.copied.synchronize()                        # the previous chunk's copy has left the staging buffer
+        view = tl.stage[:numel].view(shape).numpy()
+        if n:
+            np.stack(heat, out=view) if isinstance(heat, (list, tuple)) else np.copyto(view, np.asarray(heat, dtype=np.float32))
+        with torch.cuda.stream(tl.stream):
+            c["heat"] = tl.stage[:numel].view(shape).to(device, non_blocking=True)
             ev = torch.cuda.Event()
-            ev.record(stream)
-        c["heat_ready"], c["_stage"] = ev, stage          # keep the pinned buffer alive until the copy has run
+            ev.record(tl.stream)
+        tl.copied = ev
+        c["heat_ready"] = ev
     return c
 
 
@@ -163,6 +175,7 @@ def optimize_sequences(data_dirs, camera_model_path, vae_weight=0.0, gmm_weight=
         w_local, w_global = opt.stage_weights(vae_weight, smoothness_weight, bone_length_weight, weight_3d, reproj_weight)
         for c in batch:
             torch.cuda.current_stream().wait_event(c["heat_ready"])
+            c["heat"].record_stream(torch.cuda.current_stream())      # allocated on a reader's stream, consumed on this one
         heat_d = batch[0]["heat"] if len(batch) == 1 else torch.cat([c["heat"] for c in batch])
         mid_local, opt_global, _ = opt.run(np.concatenate([c["est_local"] for c in batch]), np.concatenate([c["cams"] for c in batch]),
                                            heat_d, np.concatenate(starts),

@@ -73,7 +73,8 @@ typedef struct gem_window_stats {
     int32_t n_iter;         /* state['n_iter'] */
     int32_t func_evals;     /* state['func_evals'] */
     float   final_loss;
-    int32_t status;         /* 0 = still running (bug), 1 = finished */
+    int32_t status;         /* bit 0: finished (0 = still running: a bug); bit 1: a closure value was NaN -- a joint exactly on
+                             * the optical axis, where the reference raises Exception("norm is zero!") (FishEyeCalibrated.py:124-127) */
 } gem_window_stats;
 
 enum { GEM_STAGE_LOCAL = 0, GEM_STAGE_GLOBAL = 1 };

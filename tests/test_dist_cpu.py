@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from globalegomocap_amd.dist import shard_range, frame_span, all_gather_windows, optimize_sharded
+from globalegomocap_amd.dist import shard_range, shard_indices, frame_span, all_gather_windows, all_gather_indexed, optimize_sharded
 from globalegomocap_amd.sequence import window_starts, merge_batches
 
 
@@ -28,6 +28,18 @@ def test_frame_span_is_contiguous_and_minimal():
     f0, f1 = frame_span(starts, lo, hi, 10)
     assert f0 == starts[lo] and f1 == starts[hi - 1] + 10
     assert frame_span(starts, 5, 5, 10) == (0, 0)
+
+
+def test_block_cyclic_shards_cover_everything_once():
+    for n in (0, 1, 15, 16, 17, 1563, 12499):
+        for world in (1, 2, 8):
+            for block in (None, 1, 16):
+                idx = [shard_indices(n, r, world, block) for r in range(world)]
+                allidx = np.sort(np.concatenate(idx)) if n else np.zeros(0)
+                assert np.array_equal(allidx, np.arange(n))
+                if block is not None and n >= world * block:
+                    sizes = [len(i) for i in idx]
+                    assert max(sizes) - min(sizes) <= block
 
 
 def _free_port():
@@ -56,6 +68,10 @@ def _worker(rank, world, port, n_windows, q):
         lo, hi = shard_range(n_windows, rank, world)
         g32 = all_gather_windows(full[lo:hi].float(), n_windows)
         ok = ok and torch.equal(g32, full.float())
+        # block-cyclic shards (load balancing over a long sequence): same rows, window order restored by the gather
+        mine = shard_indices(n_windows, rank, world, block=4)
+        gi = all_gather_indexed(full[torch.as_tensor(mine, dtype=torch.long)].clone(), n_windows, block=4)
+        ok = ok and torch.equal(gi, full)
         merged = merge_batches(out[:12].numpy())
         q.put((rank, bool(ok), merged.shape))
     finally:

@@ -139,7 +139,9 @@ def test_full_size_parameter_count_matches_the_reference():
 def test_chunk_listing_and_background_reader(tmp_path):
     import pickle
     from globalegomocap_amd import whole_sequence as ws
-    assert sorted(["c10", "c2", "c1", "C3x", "c2b"], key=ws.natural_key) == ["c1", "c2", "c2b", "C3x", "c10"]
+    # natsort.natsorted's default algorithm is case-SENSITIVE (upper case sorts first) with unsigned integers
+    assert sorted(["c10", "c2", "c1", "C3x", "c2b"], key=ws.natural_key) == ["C3x", "c1", "c2", "c2b", "c10"]
+    assert sorted(["Chunk_10", "chunk_9", "Chunk_2", "chunk_11"], key=ws.natural_key) == ["Chunk_2", "Chunk_10", "chunk_9", "chunk_11"]
     for i, n in ((2, 30), (10, 20), (1, 25)):
         d = tmp_path / ("chunk_%d" % i)
         d.mkdir()
