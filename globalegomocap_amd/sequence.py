@@ -34,6 +34,24 @@ def merge_batches(windows, overlap=OVERLAP):
     return np.concatenate(parts)
 
 
+def merge_chunks(windows, n_chunks, overlap=OVERLAP):
+    """merge_batches for n_chunks chunks of equally many windows at once: [n_chunks*wpc, T, ...] -> [n_chunks, fpc, ...]
+    (same arithmetic per element as merge_batches, vectorised over the chunks)."""
+    w = np.asarray(windows)
+    wpc, T = w.shape[0] // n_chunks, w.shape[1]
+    w = w.reshape((n_chunks, wpc, T) + w.shape[2:])
+    if overlap == 0:
+        return w.reshape((n_chunks, wpc * T) + w.shape[3:])
+    step = T - overlap
+    out = np.empty((n_chunks, wpc * step + overlap) + w.shape[3:], dtype=w.dtype)
+    out[:, :step] = w[:, 0, :step]
+    for i in range(1, wpc):
+        out[:, i * step:i * step + overlap] = (w[:, i - 1, -overlap:] + w[:, i, :overlap]) / 2
+        out[:, i * step + overlap:(i + 1) * step] = w[:, i, overlap:step]
+    out[:, wpc * step:] = w[:, -1, -overlap:]
+    return out
+
+
 def final_smooth(seq):
     """scipy gaussian_filter1d(sigma=1, axis=0) (optimizer.py:448-450)."""
     from scipy.ndimage import gaussian_filter1d
@@ -45,12 +63,12 @@ def relative_global_numpy(local, cams):
     returns (utils/utils.py:99-112): X_rel[t] = C0^-1 C_t X_loc[t], per window."""
     local = np.asarray(local, dtype=np.float64)
     cams = np.asarray(cams, dtype=np.float64)
-    M = np.einsum("bij,btjk->btik", np.linalg.inv(cams[:, 0]), cams)
-    return np.einsum("btij,btnj->btni", M[..., :3, :3], local) + M[..., None, :3, 3]
+    M = np.matmul(np.linalg.inv(cams[:, 0])[:, None], cams)
+    return np.matmul(local, np.swapaxes(M[..., :3, :3], -1, -2)) + M[..., None, :3, 3]
 
 
 def to_global_numpy(rel, cams):
     """X_glob = C0 X_rel (optimizer.py:302-308), per window, float64."""
     rel = np.asarray(rel, dtype=np.float64)
     c0 = np.asarray(cams, dtype=np.float64)[:, 0]
-    return np.einsum("bij,btnj->btni", c0[:, :3, :3], rel) + c0[:, None, None, :3, 3]
+    return np.matmul(rel, np.swapaxes(c0[:, None, :3, :3], -1, -2)) + c0[:, None, None, :3, 3]

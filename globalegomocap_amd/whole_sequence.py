@@ -20,7 +20,8 @@ import numpy as np
 import torch
 
 from .optimizer import SequenceOptimizer, GLOBAL_VAE_PATH, LOCAL_VAE_PATH
-from .sequence import SEQ_LEN, OVERLAP, window_starts, cut_windows, merge_batches, relative_global_numpy, to_global_numpy
+from .sequence import (SEQ_LEN, OVERLAP, window_starts, cut_windows, merge_batches, merge_chunks, relative_global_numpy,
+                       to_global_numpy)
 
 SUMMARY_LINES = (          # (label printed by the reference, key) in print order, None = separator
     ("Average original global pose mpjpe", "original_global_mpjpe"), ("Average mid global pose mpjpe", "mid_global_mpjpe"),
@@ -40,6 +41,7 @@ SUMMARY_LINES = (          # (label printed by the reference, key) in print orde
 
 
 _reader_local = threading.local()      # per reader thread: copy stream + pinned staging buffer, reused from chunk to chunk
+_heat_pool = {}                        # device -> frame buffers the readers fill in place (kept between calls)
 
 
 def natural_key(name):
@@ -54,9 +56,128 @@ def list_chunks(data_dir):
     return [os.path.join(data_dir, n) for n in names if os.path.isdir(os.path.join(data_dir, n))]
 
 
-def load_chunk(path, device=None):
+SIDE_CACHE = "test_data.cache"          # raw-array cache of test_data.pkl, written next to it (see _write_sidecar)
+_MAGIC = 0x47454D43414348         # "GEMCACH"
+_HDR = 8                          # int64 words: magic, n_frames, H, W, J, n_joint_coords (J*3), reserved x2
+
+
+def _sidecar_layout(n, H, W, J):
+    """byte offsets of (est_local f64 [n,J,3], gt f64 [n,J,3], cams f64 [n,4,4], heat f32 [n,H,W,J]) and the file size."""
+    o_est = _HDR * 8
+    o_gt = o_est + n * J * 3 * 8
+    o_cam = o_gt + n * J * 3 * 8
+    o_heat = (o_cam + n * 16 * 8 + 4095) // 4096 * 4096          # page-aligned: one aligned bulk read
+    return o_est, o_gt, o_cam, o_heat, o_heat + n * H * W * J * 4
+
+
+def _read_sidecar(path, small=True):
+    """(header (n,H,W,J), small arrays or None, cache file, heat offset) when a valid cache of `<chunk>/test_data.pkl` exists,
+    else None.  Valid = at least as new as the pickle, right magic, exactly as long as its header says."""
+    cache = os.path.join(path, SIDE_CACHE)
+    try:
+        if os.path.getmtime(cache) < os.path.getmtime(os.path.join(path, "test_data.pkl")):
+            return None
+        with open(cache, "rb", buffering=0) as f:
+            hdr = np.frombuffer(f.read(_HDR * 8), dtype=np.int64)
+            if hdr.shape[0] != _HDR or hdr[0] != _MAGIC:
+                return None
+            n, H, W, J = (int(v) for v in hdr[1:5])
+            o_est, o_gt, o_cam, o_heat, total = _sidecar_layout(n, H, W, J)
+            if os.fstat(f.fileno()).st_size != total:
+                return None
+            arrays = None
+            if small:
+                blob = np.frombuffer(f.read(o_cam + n * 16 * 8 - o_est), dtype=np.float64)
+                arrays = {"est_local": blob[:n * J * 3].reshape(n, J, 3).copy(), "gt": blob[n * J * 3:2 * n * J * 3].reshape(n, J, 3).copy(),
+                          "cams": blob[2 * n * J * 3:].reshape(n, 4, 4).copy()}
+        return (n, H, W, J), arrays, cache, o_heat
+    except (OSError, ValueError):
+        return None
+
+
+def _write_sidecar(path, c, heat):
+    """One-time cache next to the pickle: ONE raw file holding the small arrays (float64) and the heat-maps as float32
+    [N,H,W,J] -- what the device wants, read back with a single readinto of a pinned buffer instead of un-pickling N Python
+    objects under the GIL.  Written atomically; a read-only data directory is simply left without a cache."""
+    cache = os.path.join(path, SIDE_CACHE)
+    try:
+        h = np.ascontiguousarray(np.asarray(heat, dtype=np.float32))
+        if h.ndim != 4 or c["est_local"].shape != (h.shape[0], h.shape[3], 3) or c["cams"].shape != (h.shape[0], 4, 4):
+            return
+        n, H, W, J = h.shape
+        o_est, o_gt, o_cam, o_heat, total = _sidecar_layout(n, H, W, J)
+        tmp = cache + ".tmp%d" % os.getpid()
+        with open(tmp, "wb") as f:
+            f.write(np.array([_MAGIC, n, H, W, J, J * 3, 0, 0], dtype=np.int64).tobytes())
+            for k in ("est_local", "gt", "cams"):
+                f.write(np.ascontiguousarray(c[k], dtype=np.float64).tobytes())
+            f.write(b"\0" * (o_heat - f.tell()))
+            f.write(memoryview(h).cast("B"))
+        os.replace(tmp, cache)
+    except OSError:
+        try:
+            os.remove(cache)
+        except OSError:
+            pass
+
+
+def _stage_to_device(fill, shape, device, dest=None):
+    """fill(view) writes the float32 [shape] data into this reader thread's pinned staging buffer; one async H2D copy on the
+    thread's own stream follows, into `dest` (a slice of the consumer's frame buffer: no concatenation afterwards) or into a
+    fresh tensor.  Returns (device tensor, event)."""
+    tl = _reader_local
+    if getattr(tl, "stream", None) is None or tl.device != device:
+        tl.stream, tl.device, tl.stage, tl.copied = torch.cuda.Stream(device=device), device, None, None
+    numel = int(np.prod(shape))
+    if tl.stage is None or tl.stage.numel() < numel:
+        tl.stage = torch.empty(max(numel, 1), dtype=torch.float32).pin_memory()
+    if tl.copied is not None:
+        tl.copied.synchronize()                        # the previous chunk's copy has left the staging buffer
+    view = tl.stage[:numel].view(shape).numpy()
+    if numel:
+        fill(view)
+    with torch.cuda.stream(tl.stream):
+        if dest is not None and tuple(dest.shape) == tuple(shape):
+            t = dest.copy_(tl.stage[:numel].view(shape), non_blocking=True)
+        else:
+            t = tl.stage[:numel].view(shape).to(device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(tl.stream)
+    tl.copied = ev
+    return t, ev
+
+
+def peek_frames(path):
+    """Number of frames of a chunk without reading its arrays (from the cache's header), or None when unknown."""
+    side = _read_sidecar(path, small=False)
+    return None if side is None else side[0][0]
+
+
+def load_chunk(path, device=None, sidecar=True, dest=None):
     """`<chunk>/test_data.pkl` (optimizer.py:315-324) as dense arrays; KeyError on a missing key like the reference.
-    With `device`, the heat-maps (99 % of the bytes) go straight to that device from the calling thread."""
+    With `device`, the heat-maps (99 % of the bytes) go straight to that device from the calling thread.
+    sidecar=True: a raw-array cache of the pickle is used when present and written after the first un-pickling (the pickle
+    holds 100 separate [64,64,15] arrays per chunk: un-pickling them is GIL-bound Python object work, 3 ms per chunk and
+    thread; the cache is one 24.6 MB read straight into pinned memory, 70 GB/s over 8 reader threads)."""
+    side = _read_sidecar(path) if sidecar else None
+    if side is not None:
+        (n, H, W, J), arrays, cache, o_heat = side
+        shape = (n, H, W, J)
+        c = {"path": path, **arrays}
+
+        def fill(view):
+            with open(cache, "rb", buffering=0) as f:
+                f.seek(o_heat)
+                got = f.readinto(memoryview(view).cast("B"))
+            if got != view.nbytes:
+                raise IOError("short read of %s" % cache)
+        if device is None:
+            c["heat"] = np.empty(shape, dtype=np.float32)
+            if c["heat"].size:
+                fill(c["heat"])
+        else:
+            c["heat"], c["heat_ready"] = _stage_to_device(fill, shape, device, dest)
+        return c
     with open(os.path.join(path, "test_data.pkl"), "rb") as f:
         d = pickle.load(f)
     c = {"path": path,
@@ -64,43 +185,47 @@ def load_chunk(path, device=None):
          "gt": np.asarray(d["gt_global_skeleton"], dtype=np.float64),
          "cams": np.asarray(d["camera_pose_list"], dtype=np.float64)}
     heat = d["heatmap_list"]
+    n = len(heat)
+    shape = (n,) + tuple(np.shape(heat[0])) if n else (0, 64, 64, 15)
     if device is None:
-        c["heat"] = np.asarray(heat, dtype=np.float32)
+        c["heat"] = np.asarray(heat, dtype=np.float32).reshape(shape)
     else:
-        # into this reader thread's pinned staging buffer (one np.stack-free pass, no intermediate pageable copy), then one
-        # async H2D copy on the thread's own stream; the consumer waits on the event and marks the tensor as used on its stream
-        n = len(heat)
-        shape = (n,) + tuple(np.shape(heat[0])) if n else (0, 64, 64, 15)
-        tl = _reader_local
-        if getattr(tl, "stream", None) is None or tl.device != device:
-            tl.stream, tl.device, tl.stage, tl.copied = torch.cuda.Stream(device=device), device, None, None
-        numel = int(np.prod(shape))
-        if tl.stage is None or tl.stage.numel() < numel:
-            tl.stage = torch.empty(max(numel, 1), dtype=torch.float32).pin_memory()
-        if tl.copied is not None:
-            tl.copied.synchronize()                        # the previous chunk's copy has left the staging buffer
-        view = tl.stage[:numel].view(shape).numpy()
-        if n:
-            np.stack(heat, out=view) if isinstance(heat, (list, tuple)) else np.copyto(view, np.asarray(heat, dtype=np.float32))
-        with torch.cuda.stream(tl.stream):
-            c["heat"] = tl.stage[:numel].view(shape).to(device, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(tl.stream)
-        tl.copied = ev
-        c["heat_ready"] = ev
+        def fill(view):
+            if isinstance(heat, (list, tuple)):
+                np.stack(heat, out=view)
+            else:
+                np.copyto(view, np.asarray(heat, dtype=np.float32))
+        c["heat"], c["heat_ready"] = _stage_to_device(fill, shape, device, dest)
+    if sidecar and n:
+        _write_sidecar(path, c, heat)
     return c
 
 
-class ChunkStream:
-    """Reads chunk pickles on `workers` background threads, at most `depth` chunks ahead of the consumer, and yields
-    them in directory order."""
+_pool, _pool_workers = None, 0
 
-    def __init__(self, paths, depth=8, workers=4, device=None):
+
+def _reader_pool(workers):
+    """One pool of reader threads for the process (thread start-up costs milliseconds here; the threads also keep their
+    pinned staging buffers and copy streams between calls)."""
+    global _pool, _pool_workers
+    if _pool is None or _pool_workers < workers:
         from concurrent.futures import ThreadPoolExecutor
+        _pool, _pool_workers = ThreadPoolExecutor(max_workers=max(1, workers), thread_name_prefix="gem-reader"), workers
+    return _pool
+
+
+class ChunkStream:
+    """Reads chunk pickles (or their raw-array caches) on `workers` background threads, at most `depth` chunks ahead of the
+    consumer, and yields them in directory order.  The reads release the GIL (file -> pinned memory), so they overlap with
+    each other and with the consumer's device work."""
+
+    def __init__(self, paths, depth=8, workers=8, device=None, sidecar=True, dests=None):
         self._paths = list(paths)
         self._depth = max(1, depth)
         self._device = device
-        self._pool = ThreadPoolExecutor(max_workers=max(1, workers))
+        self._sidecar = sidecar
+        self._dests = dests or {}          # path -> device slice the chunk's heat-maps are copied into
+        self._pool = _reader_pool(workers)
 
     def __iter__(self):
         pending = []
@@ -111,14 +236,19 @@ class ChunkStream:
                     p = next(it, None)
                     if p is None:
                         break
-                    pending.append(self._pool.submit(load_chunk, p, self._device))
+                    pending.append(self._pool.submit(load_chunk, p, self._device, self._sidecar, self._dests.get(p)))
                 if not pending:
                     return
                 yield pending.pop(0).result()          # a reader's exception (e.g. KeyError) surfaces here
         finally:
             for f in pending:
                 f.cancel()
-            self._pool.shutdown(wait=True)
+            for f in pending:                           # (running reads finish before the caller reuses their destinations)
+                if not f.cancelled():
+                    try:
+                        f.result()
+                    except Exception:
+                        pass
 
 
 def _batches(stream, chunks_per_batch):
@@ -135,11 +265,12 @@ def _batches(stream, chunks_per_batch):
 def optimize_sequences(data_dirs, camera_model_path, vae_weight=0.0, gmm_weight=0.0, smoothness_weight=0.001,
                        bone_length_weight=0.01, weight_3d=0.01, reproj_weight=0.01, final_smooth=True, merge=True,
                        global_vae_path=GLOBAL_VAE_PATH, local_vae_path=LOCAL_VAE_PATH, chunks_per_batch=None, optimizer=None,
-                       device_metrics=True, verbose=True, seq_len=SEQ_LEN, overlap=OVERLAP):
+                       device_metrics=True, verbose=True, seq_len=SEQ_LEN, overlap=OVERLAP, sidecar=True, timings=None):
     """Several sequences in ONE batched device call (BASELINE configs[2]: all test sequences concurrently on one GPU):
     the chunks of every directory of `data_dirs` go through the optimiser together, the reports are per sequence.
     Returns a list of (summary, per-chunk error dicts, estimated_pose, optimized_pose, gt_pose), one per directory, each
-    exactly what `optimize_directory` returns; the noise is drawn sequence by sequence, chunk by chunk."""
+    exactly what `optimize_directory` returns; the noise is drawn sequence by sequence, chunk by chunk.
+    sidecar=True keeps a raw-array cache of every pickle next to it (`load_chunk`); False reads the pickles only."""
     del gmm_weight, merge                       # accepted and unused, as in the reference (SURVEY D4)
     paths, group_of = [], {}
     for gi, d in enumerate(data_dirs):
@@ -153,7 +284,41 @@ def optimize_sequences(data_dirs, camera_model_path, vae_weight=0.0, gmm_weight=
     opt = optimizer
     results, est_all, opt_all, gt_all = ([[] for _ in range(n_groups)] for _ in range(4))
     device = torch.device("cuda", torch.cuda.current_device())
-    for batch in _batches(ChunkStream(paths, device=device), chunks_per_batch):
+    # When every chunk's frame count is known up front (cache metadata), the readers copy their heat-maps straight into
+    # slices of ONE frame buffer per batch (two buffers alternate, so that the readers can fill the next batch while the
+    # device still works on the current one): no concatenation, no 0.5 GB allocation per call.
+    dests, batch_bufs = {}, []
+    frames = [peek_frames(q) if sidecar else None for q in paths]
+    if paths and all(f is not None for f in frames):
+        per_batch = chunks_per_batch or len(paths)
+        hs = optimizer.engine.heat_size if optimizer is not None else (64, 64)
+        need = max(sum(frames[i:i + per_batch]) for i in range(0, len(paths), per_batch))
+        pool = _heat_pool.setdefault(device, [])
+        while len(pool) < (2 if chunks_per_batch and len(paths) > per_batch else 1):
+            pool.append(None)
+        for k in range(len(pool)):
+            if pool[k] is None or pool[k].shape[0] < need or tuple(pool[k].shape[1:3]) != tuple(hs):
+                pool[k] = torch.empty((need, hs[0], hs[1], 15), dtype=torch.float32, device=device)
+        for bi, i in enumerate(range(0, len(paths), per_batch)):
+            buf, f0 = pool[bi % len(pool)], 0
+            batch_bufs.append((buf, sum(frames[i:i + per_batch])))
+            for q, n in zip(paths[i:i + per_batch], frames[i:i + per_batch]):
+                dests[q] = buf[f0:f0 + n]
+                f0 += n
+    # read-ahead: with the in-place frame buffers at most ONE batch ahead of the consumer (the buffer of batch k+2 is the
+    # buffer of batch k: its readers may only start once batch k has left the device, i.e. when the consumer asks for more)
+    depth = (chunks_per_batch or len(paths) or 1) if dests else max(16, (chunks_per_batch or 0) + 2)
+    import time
+    tick = [time.perf_counter()]
+
+    def lap(name):          # developer timing (tools/whole_sequence_timing.py): wall time of the host phases
+        if timings is not None:
+            now = time.perf_counter()
+            timings[name] = timings.get(name, 0.0) + (now - tick[0])
+            tick[0] = now
+    lap("plan")
+    for bi, batch in enumerate(_batches(ChunkStream(paths, depth=depth, device=device, sidecar=sidecar, dests=dests), chunks_per_batch)):
+        lap("wait_for_readers")
         starts, chunk_of, bounds, f_off, eps = [], [], [], 0, []
         for ci, c in enumerate(batch):
             if verbose:
@@ -172,15 +337,50 @@ def optimize_sequences(data_dirs, camera_model_path, vae_weight=0.0, gmm_weight=
                              (n_win, opt.engine.max_windows))
         for c in batch:                          # global torch RNG, in the reference's order (D5)
             eps.append(torch.randn(2 * len(c["starts"]), opt.engine.D))
+        lap("noise")
         w_local, w_global = opt.stage_weights(vae_weight, smoothness_weight, bone_length_weight, weight_3d, reproj_weight)
         for c in batch:
             torch.cuda.current_stream().wait_event(c["heat_ready"])
             c["heat"].record_stream(torch.cuda.current_stream())      # allocated on a reader's stream, consumed on this one
-        heat_d = batch[0]["heat"] if len(batch) == 1 else torch.cat([c["heat"] for c in batch])
+        if batch_bufs and all(c["heat"].data_ptr() == dests[c["path"]].data_ptr() for c in batch):
+            heat_d = batch_bufs[bi][0][:batch_bufs[bi][1]]          # the readers filled the batch's frame buffer in place
+        else:
+            heat_d = batch[0]["heat"] if len(batch) == 1 else torch.cat([c["heat"] for c in batch])
         mid_local, opt_global, _ = opt.run(np.concatenate([c["est_local"] for c in batch]), np.concatenate([c["cams"] for c in batch]),
                                            heat_d, np.concatenate(starts),
                                            np.concatenate(chunk_of), bounds, w_local, w_global, eps=torch.cat(eps), keep_device=True)
+        lap("optimise (enqueue + device + read-back of the stats)")
         mid_np = mid_local.cpu().numpy()
+        counts = [len(c["starts"]) for c in batch]
+        if device_metrics and counts and min(counts) == max(counts) and counts[0] > 0:
+            # equal chunks (the reference's 100-frame chunks): the sequences main() returns besides the optimised one are built
+            # for ALL windows of the batch at once, the overlap merges are vectorised over the chunks, the error reports of
+            # all chunks are enqueued back to back and read back with ONE synchronisation
+            e, nb, wpc = opt.engine, len(batch), counts[0]
+            est_cat = np.concatenate([c["est_local"] for c in batch])
+            cams_cat = np.concatenate([c["cams"] for c in batch])
+            gt_cat = np.concatenate([c["gt"] for c in batch])
+            idx = np.concatenate(starts)[:, None] + np.arange(seq_len)[None]
+            loc_w, cam_w = est_cat[idx], cams_cat[idx]
+            est_m = merge_chunks(to_global_numpy(relative_global_numpy(loc_w, cam_w), cam_w), nb, overlap)
+            mid_m = merge_chunks(to_global_numpy(relative_global_numpy(mid_np, cam_w), cam_w), nb, overlap)
+            gt_m = merge_chunks(gt_cat[idx], nb, overlap)
+            fpc = est_m.shape[1]
+            opt_d = e.merge_windows(opt_global, nb, overlap=overlap, smooth=bool(final_smooth))          # [nb*fpc,15,3] f64, device
+            est_d, mid_d, gt_d = (torch.as_tensor(x.reshape(nb * fpc, 15, 3), device=device) for x in (est_m, mid_m, gt_m))
+            reps = torch.stack([e.calculate_errors_device(est_d[k * fpc:(k + 1) * fpc], mid_d[k * fpc:(k + 1) * fpc],
+                                                          opt_d[k * fpc:(k + 1) * fpc], gt_d[k * fpc:(k + 1) * fpc]) for k in range(nb)])
+            reps, opt_m = reps.cpu().numpy(), opt_d.cpu().numpy().reshape(nb, fpc, 15, 3)
+            for k, c in enumerate(batch):
+                res = OrderedDict((key, float(reps[k, i])) for i, key in enumerate(e.ERROR_KEYS))
+                res["joints_error"] = reps[k, 17:].copy()
+                gi = group_of[c["path"]]
+                results[gi].append(res)
+                est_all[gi].extend(list(est_m[k])); opt_all[gi].extend(list(opt_m[k])); gt_all[gi].extend(list(gt_m[k]))
+                if verbose and res["bone_length_aligned_optimized_mpjpe"] > res["bone_length_aligned_mid_optimized_mpjpe"]:
+                    print(res)
+            lap("sequences + reports")
+            continue
         w0 = 0
         for c in batch:
             nw = len(c["starts"])

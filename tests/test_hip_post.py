@@ -1,6 +1,8 @@
 """GPU parity tests of the sequence post-processing calls: overlap merge + Gaussian
 smoothing and the 18-entry error report, against the host mirrors (which tests/test_host_cpu.py pins to
 the reference's golden run) and against the golden run itself."""
+import os
+
 import numpy as np
 import pytest
 
@@ -240,3 +242,41 @@ def test_several_sequences_in_one_batch_match_sequence_by_sequence_runs(golden, 
         for k in a[0]:
             tol = 1e-9 if k.startswith("original") or k in ("aligned_original_mpjpe", "bone_length_aligned_original_mpjpe") else 0.5e-3
             np.testing.assert_allclose(b[0][k], a[0][k], rtol=0, atol=tol, err_msg=k)
+
+
+def test_equal_chunks_take_the_vectorised_report_path_and_the_sidecar_cache(golden, tmp_path):
+    """Equal 100-frame chunks (the reference's data layout): all chunks' bookkeeping and error reports in one go, heat-maps
+    read from the raw-array cache on the second run; reports must be those of the per-chunk main() loop and of the
+    pickle-only run."""
+    import pickle
+    import torch
+    from globalegomocap_amd import optimizer as gopt, whole_sequence as ws
+    from helpers import sd_from_npz
+    lt = golden("lbfgs_tiny")
+    kw = dict(global_vae_path=sd_from_npz(lt, "global/"), local_vae_path=sd_from_npz(lt, "local/"))
+    for i in range(3):
+        d = tmp_path / ("chunk_%d" % i)
+        d.mkdir()
+        data = synth.make_sequence(n_frames=100, seed=70 + i, cam_jitter=(0.3, 0.002))
+        with open(d / "test_data.pkl", "wb") as f:
+            pickle.dump({k: data[k] for k in ("estimated_local_skeleton", "gt_global_skeleton", "camera_pose_list", "heatmap_list")}, f)
+    torch.manual_seed(9)
+    per_chunk = [gopt.main(p, DEFAULT_CALIBRATION, 0.0, 0.0, 0.001, 0.01, 0.01, 0.01, final_smooth=True, **kw)
+                 for p in ws.list_chunks(str(tmp_path))]
+    runs = []
+    for sidecar in (False, True, True):             # pickles only; pickles + cache written; cache read
+        torch.manual_seed(9)
+        runs.append(ws.optimize_directory(str(tmp_path), DEFAULT_CALIBRATION, verbose=False, sidecar=sidecar, **kw))
+    assert os.path.exists(tmp_path / "chunk_0" / ws.SIDE_CACHE)
+    ref_opt = np.concatenate([np.asarray(r[3]) for r in per_chunk])
+    for summary, results, est, opt, gt in runs:
+        assert len(results) == 3 and len(opt) == 3 * 98 == len(est) == len(gt)
+        assert np.linalg.norm(np.asarray(opt) - ref_opt, axis=-1).mean() < 0.5e-3
+        np.testing.assert_allclose(np.asarray(est), np.concatenate([np.asarray(r[1]) for r in per_chunk]), rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(np.asarray(gt), np.concatenate([np.asarray(r[4]) for r in per_chunk]), rtol=1e-9, atol=1e-12)
+        for k in summary:
+            ref = np.mean([r[0][k] for r in per_chunk], axis=0)
+            tol = 1e-9 if k.startswith("original") or k in ("aligned_original_mpjpe", "bone_length_aligned_original_mpjpe") else 0.5e-3
+            np.testing.assert_allclose(summary[k], ref, rtol=0, atol=tol, err_msg=k)
+    # cache vs pickle: the same device inputs, so the same results bit for bit
+    assert np.array_equal(np.asarray(runs[0][3]), np.asarray(runs[2][3]))

@@ -155,6 +155,22 @@ def test_chunk_listing_and_background_reader(tmp_path):
     assert [len(c["est_local"]) for c in got] == [25, 30, 20]
     assert got[0]["heat"].dtype == np.float32 and got[0]["heat"].shape == (25, 64, 64, 15) and got[0]["cams"].shape == (25, 4, 4)
     assert [len(b) for b in ws._batches(iter(got), 2)] == [2, 1] and [len(b) for b in ws._batches(iter(got), None)] == [3]
+    # the first read left a raw-array cache next to every pickle; the second read comes from it, bit for bit
+    for p_ in paths:
+        assert os.path.exists(os.path.join(p_, ws.SIDE_CACHE))
+    again = list(ws.ChunkStream(paths, depth=2))
+    plain = list(ws.ChunkStream(paths, depth=2, sidecar=False))
+    for a_, b_, c_ in zip(got, again, plain):
+        for k in ("est_local", "gt", "cams", "heat"):
+            assert np.array_equal(a_[k], b_[k]) and np.array_equal(a_[k], c_[k]) and a_[k].dtype == b_[k].dtype == c_[k].dtype, k
+    # a cache older than its pickle, or of the wrong length, is ignored and rewritten
+    os.utime(os.path.join(paths[0], ws.SIDE_CACHE), (1, 1))
+    assert ws._read_sidecar(paths[0]) is None
+    ws.load_chunk(paths[0])
+    assert ws._read_sidecar(paths[0]) is not None
+    with open(os.path.join(paths[1], ws.SIDE_CACHE), "ab") as f:
+        f.write(b"xx")
+    assert ws._read_sidecar(paths[1]) is None
     (tmp_path / "chunk_3").mkdir()
     with open(tmp_path / "chunk_3" / "test_data.pkl", "wb") as f:
         pickle.dump({"estimated_local_skeleton": []}, f)
@@ -175,6 +191,13 @@ def test_slam_trajectory_conversion_against_reference_golden(golden):
         assert mats.shape == g["mats_" + tag].shape
         np.testing.assert_allclose(mats, g["mats_" + tag], rtol=0, atol=1e-12)
         np.testing.assert_allclose(mats[0], np.eye(4), atol=1e-12)
+    # read_trajectory_new itself, on the reference's own output (slam_reader.py:50-121; the generator replaces open3d's
+    # PointCloud.transform by R p + t, nothing else): scaled matrices and the inverse similarity (R_1, t_1)
+    a, b = (int(v) for v in g["new_range"])
+    mats, R1, t1 = slam.camera_pose_list(lines, g["new_local"], g["new_gt"], a, b)
+    np.testing.assert_allclose(np.asarray(mats), g["new_mats"], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(R1, g["new_R1"], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(t1, g["new_t1"], rtol=0, atol=1e-11)
     # known scale: ground-truth head = 1.8 x (SLAM head), rotated and shifted
     t, q = slam.parse_trajectory(lines, 0, 40)
     rt, rq = slam.relative_poses(t, q)
