@@ -198,7 +198,7 @@ int gem_create(const gem_config* cfg, gem_handle** out) {
     static_assert(MAX_HIST >= 32, "ring capacity");
     if (dev_alloc(w.allocs, &w.S, (size_t)B * w.hist_cap * h->Dp)) return 1;
     if (dev_alloc(w.allocs, &w.Y, (size_t)B * w.hist_cap * h->Dp)) return 1;
-    if (dev_alloc(w.allocs, &w.state, (size_t)B)) return 1;
+    if (dev_alloc(w.allocs, &w.state, (size_t)B) || dev_alloc(w.allocs, &w.phase, (size_t)B)) return 1;
     if (dev_alloc(w.allocs, &w.f, (size_t)B)) return 1;
     if (dev_alloc(w.allocs, &w.parts, (size_t)B * 5)) return 1;
     if (dev_alloc(w.allocs, &w.trace, (size_t)TRACE_ROUNDS * B)) return 1;

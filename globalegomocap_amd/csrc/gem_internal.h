@@ -97,6 +97,7 @@ struct Workspace {
     float *S = nullptr, *Y = nullptr;   // [B, hist_cap, Dp]
     int hist_cap = 0;
     LbfgsState* state = nullptr;        // [B]
+    int* phase = nullptr;               // [B] copy of state[b].phase for the compaction scan
     double* f = nullptr;                // [B] energy of the trial point
     double* parts = nullptr;            // [B,5]
     double* trace = nullptr;            // [TRACE_ROUNDS][Bmax] closure value each window consumed in round r of the last stage (NaN: none)

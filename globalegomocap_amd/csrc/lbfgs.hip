@@ -32,6 +32,7 @@ struct AdvArgs {
     const float* gnew;
     float *x, *d, *g, *gp, *bg0, *bg1, *trial, *S, *Y;
     uint16_t* trial_b;        // bf16 copy of the trial point for the bf16 decoder mode (nullptr: none)
+    int* phase_arr;           // [B] copy of state.phase: what compact_kernel scans (4 bytes per window instead of the 1.2 KB record)
     const int* slot_of;       // window -> slot of its gradient row (nullptr: identity)
     SlabSrc gslab;            // base != nullptr: the gradient rows still lie in split-K slabs (summed here, in slab order)
     int Dp, hist_cap;
@@ -100,7 +101,9 @@ struct BlockRed {
 };
 
 // FULL: Dp == EPT * NT exactly (D = 2048 with 8 x 256): no bounds predicate around the strip loads / stores
-template <int EPT, int NT, bool FULL>
+// HB: the (s, y) ring is stored as bf16 (bf16 decoder mode: the ring is the kernel's HBM traffic at large batch, 4 k reads of
+// D values per iteration with k pairs; the curvature pairs tolerate 8 bits, the iterate, gradients and all scalars stay fp32)
+template <int EPT, int NT, bool FULL, bool HB>
 __device__ __forceinline__ void lbfgs_advance_body(const AdvArgs& a) {
     __shared__ double red[24];
     __shared__ double ro_s[MAX_HIST];
@@ -160,6 +163,47 @@ __device__ __forceinline__ void lbfgs_advance_body(const AdvArgs& a) {
         } else {
 #pragma unroll
             for (int i = 0; i < EPT; ++i) { const int e = tid + NT * i; if (FULL || e < Dp) p[off + e] = v[i]; }
+        }
+    };
+    // ring accessors: vector `slot` of this window in the ring `base` (a.S or a.Y); with HB the ring holds 2-byte values
+    auto hload = [&](const float* base, int slot, float (&v)[EPT]) {
+        const size_t eo = ((size_t)b * a.hist_cap + slot) * Dp;
+        if constexpr (!HB) { load(base + eo - off, v); }
+        else {
+            const uint16_t* q = reinterpret_cast<const uint16_t*>(base) + eo;
+            if constexpr (EPT % 4 == 0) {
+#pragma unroll
+                for (int i = 0; i < EPT / 4; ++i) {
+                    const int e = (tid + NT * i) * 4;
+                    typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+                    u2 w = {0u, 0u};
+                    if (FULL || e < Dp) w = *reinterpret_cast<const u2*>(q + e);
+                    v[4 * i] = __builtin_bit_cast(float, w[0] << 16); v[4 * i + 1] = __builtin_bit_cast(float, w[0] & 0xFFFF0000u);
+                    v[4 * i + 2] = __builtin_bit_cast(float, w[1] << 16); v[4 * i + 3] = __builtin_bit_cast(float, w[1] & 0xFFFF0000u);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < EPT; ++i) { const int e = tid + NT * i; v[i] = (FULL || e < Dp) ? __builtin_bit_cast(float, (unsigned)q[e] << 16) : 0.f; }
+            }
+        }
+    };
+    auto hstore = [&](float* base, int slot, const float (&v)[EPT]) {
+        const size_t eo = ((size_t)b * a.hist_cap + slot) * Dp;
+        if constexpr (!HB) { store(base + eo - off, v); }
+        else {
+            uint16_t* q = reinterpret_cast<uint16_t*>(base) + eo;
+            if constexpr (EPT % 4 == 0) {
+#pragma unroll
+                for (int i = 0; i < EPT / 4; ++i) {
+                    const int e = (tid + NT * i) * 4;
+                    typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+                    const bf4 w = __builtin_convertvector(f32x4{v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]}, bf4);
+                    if (FULL || e < Dp) *reinterpret_cast<bf4*>(q + e) = w;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < EPT; ++i) { const int e = tid + NT * i; if (FULL || e < Dp) q[e] = (uint16_t)(__builtin_bit_cast(unsigned int, (float)(__bf16)v[i]) >> 16); }
+            }
         }
     };
     auto store_trial = [&](const float (&v)[EPT]) {       // the next point to evaluate, fp32 and (bf16 decoder mode) bf16
@@ -369,14 +413,11 @@ __device__ __forceinline__ void lbfgs_advance_body(const AdvArgs& a) {
             H_diag = 1.0;
         } else {
             (void)have_ys;
-            auto pair_ptr = [&](const float* base, int k) {
-                const int slot = (hist_start + k) & hmask;
-                return base + ((size_t)b * a.hist_cap + slot) * Dp - off;
-            };
+            auto ring_slot = [&](int k) { return (hist_start + k) & hmask; };      // k-th oldest stored pair -> ring slot
             // y.s, y.y and (for the pairwise two-loop below) s_prev.y of the newest stored pair, in ONE reduction
             float sprev[EPT];
             const bool has_prev = hist_count >= 1;
-            if (has_prev) load(pair_ptr(a.S, hist_count - 1), sprev);
+            if (has_prev) hload(a.S, ring_slot(hist_count - 1), sprev);
             double r3[3] = {0.0, 0.0, 0.0};
             {
                 float p0 = 0.f, p1 = 0.f, p2 = 0.f;
@@ -398,10 +439,8 @@ __device__ __forceinline__ void lbfgs_advance_body(const AdvArgs& a) {
                     hist_count--;
                 }
                 const int slot = (hist_start + hist_count) & hmask;
-                float* Ys = a.Y + ((size_t)b * a.hist_cap + slot) * Dp - off;
-                float* Ss = a.S + ((size_t)b * a.hist_cap + slot) * Dp - off;
-                store(Ys, yv);
-                store(Ss, sv);
+                hstore(a.Y, slot, yv);
+                hstore(a.S, slot, sv);
                 const bool link = has_prev && hist_count >= 1;                     // a previous pair survives: record s_prev . y_new
                 hist_count++;
                 H_diag = ys / r3[1];
@@ -423,8 +462,8 @@ __device__ __forceinline__ void lbfgs_advance_body(const AdvArgs& a) {
             float sXa[EPT], yXa[EPT], sXb[EPT], yXb[EPT], sZa[EPT], yZa[EPT], sZb[EPT], yZb[EPT];
             auto clampk = [&](int k) { return k < 0 ? 0 : (k >= hc ? hc - 1 : k); };
             auto ld2 = [&](int kA, int kB, float (&sA)[EPT], float (&yA)[EPT], float (&sB)[EPT], float (&yB)[EPT]) {
-                load(pair_ptr(a.S, clampk(kA)), sA); load(pair_ptr(a.Y, clampk(kA)), yA);
-                load(pair_ptr(a.S, clampk(kB)), sB); load(pair_ptr(a.Y, clampk(kB)), yB);
+                hload(a.S, ring_slot(clampk(kA)), sA); hload(a.Y, ring_slot(clampk(kA)), yA);
+                hload(a.S, ring_slot(clampk(kB)), sB); hload(a.Y, ring_slot(clampk(kB)), yB);
             };
             auto dstep1 = [&](int kA, float (&sA)[EPT], float (&yA)[EPT], float (&sB)[EPT], float (&yB)[EPT]) {
                 const int kB = kA - 1;
@@ -529,6 +568,7 @@ __device__ __forceinline__ void lbfgs_advance_body(const AdvArgs& a) {
         ls_evals++;
     }
     if (tid == 0) {
+        if (a.phase_arr) a.phase_arr[b] = phase;
         sp->phase = phase; sp->n_iter = n_iter; sp->evals = evals; sp->ls_iter = ls_iter; sp->ls_evals = ls_evals;
         sp->max_ls = max_ls; sp->first_bracket = first_bracket; sp->ls_done = ls_done; sp->insuf = insuf;
         sp->low = low; sp->high = high; sp->hist_count = hist_count; sp->hist_start = hist_start;
@@ -539,13 +579,15 @@ __device__ __forceinline__ void lbfgs_advance_body(const AdvArgs& a) {
     }
 }
 
-template <int EPT, bool FULL>
-__global__ __launch_bounds__(256) void lbfgs_advance_kernel(AdvArgs a) { lbfgs_advance_body<EPT, 256, FULL>(a); }
+template <int EPT, bool FULL, bool HB = false>
+__global__ __launch_bounds__(256) void lbfgs_advance_kernel(AdvArgs a) { lbfgs_advance_body<EPT, 256, FULL, HB>(a); }
 
-__global__ void lbfgs_init_kernel(LbfgsState* st, const float* __restrict__ trial, float* __restrict__ x, int B, int Dp) {
+__global__ void lbfgs_init_kernel(LbfgsState* st, int* __restrict__ phase_arr, const float* __restrict__ trial, float* __restrict__ x, int B,
+                                  int Dp) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < (size_t)B * Dp) x[i] = trial[i];
     if (i < (size_t)B) {
+        phase_arr[i] = PH_INIT;
         LbfgsState* s = st + i;
         s->phase = PH_INIT; s->n_iter = 0; s->evals = 0; s->ls_iter = 0; s->ls_evals = 0; s->max_ls = 0;
         s->first_bracket = 0; s->ls_done = 0; s->insuf = 0; s->low = 0; s->high = 1; s->hist_count = 0; s->hist_start = 0;
@@ -572,6 +614,7 @@ static AdvArgs make_args(gem_handle* h, const gem_lbfgs_opts& o) {
     a.trace = (w.round >= 0 && w.round < TRACE_ROUNDS) ? w.trace + (size_t)w.round * w.Bmax : nullptr;
     a.x = w.x; a.d = w.d; a.g = w.g; a.gp = w.gp; a.bg0 = w.bg0; a.bg1 = w.bg1; a.trial = w.trial; a.S = w.S; a.Y = w.Y;
     a.trial_b = h->precision == GEM_PRECISION_BF16 ? w.trial_b : nullptr;
+    a.phase_arr = w.phase;
     a.slot_of = w.dyn ? w.slot_of : nullptr;
     a.gslab = w.dyn ? w.grad_slab : SlabSrc{};
     a.Dp = h->Dp; a.hist_cap = w.hist_cap; a.o = o;        // hist_cap: power of two (gem_create)
@@ -581,8 +624,8 @@ static AdvArgs make_args(gem_handle* h, const gem_lbfgs_opts& o) {
 int launch_lbfgs_init(gem_handle* h, int B, const gem_lbfgs_opts& o, hipStream_t s) {
     (void)o;
     const size_t n = (size_t)B * h->Dp;
-    hipLaunchKernelGGL(lbfgs_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h->ws.state, h->ws.trial, h->ws.x, B,
-                       h->Dp);
+    hipLaunchKernelGGL(lbfgs_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h->ws.state, h->ws.phase, h->ws.trial, h->ws.x,
+                       B, h->Dp);
     GEM_HIP(hipGetLastError());
     return 0;
 }
@@ -600,6 +643,7 @@ int launch_lbfgs_advance(gem_handle* h, int B, const gem_lbfgs_opts& o, hipStrea
     if (ept <= 1) hipLaunchKernelGGL((lbfgs_advance_kernel<1, false>), dim3(B), dim3(256), 0, s, a);
     else if (ept <= 2) hipLaunchKernelGGL((lbfgs_advance_kernel<2, false>), dim3(B), dim3(256), 0, s, a);
     else if (ept <= 4) hipLaunchKernelGGL((lbfgs_advance_kernel<4, false>), dim3(B), dim3(256), 0, s, a);
+    else if (h->Dp == 2048 && h->precision == GEM_PRECISION_BF16) hipLaunchKernelGGL((lbfgs_advance_kernel<8, true, true>), dim3(B), dim3(256), 0, s, a);
     else if (h->Dp == 2048) hipLaunchKernelGGL((lbfgs_advance_kernel<8, true>), dim3(B), dim3(256), 0, s, a);       // the reference's latent size
     else if (ept <= 8) hipLaunchKernelGGL((lbfgs_advance_kernel<8, false>), dim3(B), dim3(256), 0, s, a);
     else if (ept <= 16) hipLaunchKernelGGL((lbfgs_advance_kernel<16, false>), dim3(B), dim3(256), 0, s, a);
@@ -611,7 +655,7 @@ int launch_lbfgs_advance(gem_handle* h, int B, const gem_lbfgs_opts& o, hipStrea
 
 // Stable partition of the windows: those still iterating first (slots [0, n)), finished ones behind.
 // One 1024-thread block; B is at most a few thousand.
-__global__ __launch_bounds__(1024) void compact_kernel(const LbfgsState* __restrict__ st, int B, int T, int* __restrict__ perm,
+__global__ __launch_bounds__(1024) void compact_kernel(const int* __restrict__ phase_arr, int B, int T, int* __restrict__ perm,
                                                        int* __restrict__ slot_of, int* __restrict__ n_active, int force_all,
                                                        int* __restrict__ log_slot) {
     __shared__ int wsum[16];
@@ -622,7 +666,7 @@ __global__ __launch_bounds__(1024) void compact_kernel(const LbfgsState* __restr
     for (int pass = 0; pass < 2; ++pass) {
         for (int start = 0; start < B; start += 1024) {
             const int b = start + tid;
-            const bool active = b < B && (force_all || st[b].phase != PH_DONE);
+            const bool active = b < B && (force_all || phase_arr[b] != PH_DONE);
             const bool flag = b < B && (active == (pass == 0));
             const unsigned long long m = __ballot(flag);
             const int prefix = __popcll(m & ((1ull << lane) - 1ull));
@@ -642,7 +686,7 @@ __global__ __launch_bounds__(1024) void compact_kernel(const LbfgsState* __restr
 
 int launch_compact(gem_handle* h, int B, int force_all, hipStream_t s) {
     Workspace& w = h->ws;
-    hipLaunchKernelGGL(compact_kernel, dim3(1), dim3(1024), 0, s, w.state, B, h->T, w.perm, w.slot_of, w.n_active, force_all,
+    hipLaunchKernelGGL(compact_kernel, dim3(1), dim3(1024), 0, s, w.phase, B, h->T, w.perm, w.slot_of, w.n_active, force_all,
                        w.n_log + (w.log_pos % N_LOG));
     GEM_HIP(hipGetLastError());
     w.cur_log = w.log_pos++;
