@@ -350,7 +350,7 @@ static int launch_one(gem_handle* h, const Layer& L, const float* A, int lda, co
 // Large batches: the LDS-DMA kernel of gemm_glds.h with fp32 operands (128x128x32 tiles, one wave per 64x64 with 16
 // independent 16x16x4 accumulators, operands global -> LDS by DMA).  Measured on the decoder_input shapes at 8192
 // windows: 133 TFLOP/s = 0.85 of the fp32 matrix peak (tools/gemm_glds_bench), against 113-127 for the register-staged
-// 128x128 kernel above.  No split-K: only used when the launch has >= 2 tiles per CU.
+// 128x128 kernel above.  No split-K: only used when the launch has >= 1.5 tiles per CU (480 tiles at 1536 windows).
 template <int TAPS, int EPI>
 static int launch_glds_f32(gem_handle* h, const Layer& L, const float* A, int lda, const float* aux, float* C, int ldc, int M, int T,
                            hipStream_t s, const int* row_map) {
@@ -376,7 +376,7 @@ template <int TAPS, int EPI, int TAG>
 static int launch_tile(gem_handle* h, const Layer& L, const float* A, int lda, const float* aux, float* C, int ldc, int M, int T,
                        hipStream_t s, const int* row_map) {
     static const bool no_glds = getenv("GEM_NO_GLDS_F32") != nullptr;          // developer override (A/B runs)
-    if (!no_glds && L.N % 128 == 0 && L.K % 32 == 0 && (long)((M + 127) / 128) * (L.N / 128) >= 2L * h->n_cu && h->ws.zero16 &&
+    if (!no_glds && L.N % 128 == 0 && L.K % 32 == 0 && (long)((M + 127) / 128) * (L.N / 128) >= 3L * h->n_cu / 2 && h->ws.zero16 &&
         !h->ws.defer_reduce)
         return launch_glds_f32<TAPS, EPI>(h, L, A, lda, aux, C, ldc, M, T, s, row_map);
     // 128x128 tiles only when they still fill the chip (>= 2 workgroups per CU) and divide N

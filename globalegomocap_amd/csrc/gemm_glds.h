@@ -92,7 +92,6 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_glds_kernel(c
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF = A_BYTES + B_BYTES;
     constexpr int A_INSTR = A_BYTES / 1024 / NW, B_INSTR = B_BYTES / 1024 / NW;      // 1 KB DMA pieces per wave
     static_assert(A_BYTES % (1024 * NW) == 0 && B_BYTES % (1024 * NW) == 0, "tile must split into whole DMA pieces per wave");
-    static_assert(2 * BUF >= BM * BN * 4 || true, "epilogue staging");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -224,26 +223,15 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_glds_kernel(c
     }
 
     // ---- epilogue: fp32 tile -> LDS (row m, 16-byte chunk q of its BN columns at position q ^ (m & (CH-1))) -> whole rows out
-    // D[n][m]: the lane's column is its row m of C, its registers are runs of 4 consecutive n
+    // D[n][m]: the lane's column is its row m of C, its registers are runs of 4 consecutive n.  Tiles taller than 128 rows
+    // are staged in passes of 128 rows (the staged fp32 rows have to fit the two operand buffers).
     constexpr int ROWB = BN * 4;                 // bytes per staged row
     constexpr int CH = BN / 4;                   // 16-byte chunks per row (32 for BN = 128, 16 for BN = 64)
-    static_assert(BM * ROWB <= 2 * BUF, "the staged fp32 tile must fit the two operand buffers");
-#pragma unroll
-    for (int i = 0; i < NB; ++i)
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int m = wm * 64 + j * MF + fr;
-#pragma unroll
-            for (int g = 0; g < (MF == 32 ? 4 : 1); ++g) {
-                const int q = (wn * 64 + i * MF + (MF == 32 ? 8 * g + 4 * fh : 4 * fh)) >> 2;
-                const f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                *reinterpret_cast<f32x4*>(smem + m * ROWB + ((q ^ (m & (CH - 1))) << 4)) = v;
-            }
-        }
-    __syncthreads();
+    constexpr int PR = BM < 128 ? BM : 128;      // rows per pass
+    static_assert(PR * ROWB <= 2 * BUF, "a pass of the staged fp32 tile must fit the two operand buffers");
     const bool split = a.n_split > 1;
     constexpr int TPR = BN / 8;                  // threads per row (8 columns each)
-    constexpr int RPP = NT / TPR;                // rows per pass
+    constexpr int RPP = NT / TPR;                // rows per store sweep
     const int c8 = (tid % TPR) * 8, r0 = tid / TPR;
     f32x4 bv0 = {0.f, 0.f, 0.f, 0.f}, bv1 = {0.f, 0.f, 0.f, 0.f};
     if ((EPI == EPI_BIAS || EPI == EPI_BIAS_LRELU) && !split && a.bias) {
@@ -252,45 +240,64 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_glds_kernel(c
     }
     unsigned char* Cb = reinterpret_cast<unsigned char*>(a.C);
     if (split) Cb += (size_t)ks * a.slab_stride * 4;
-#pragma unroll 4
-    for (int p = 0; p < BM / RPP; ++p) {
-        const int r = p * RPP + r0, row = m0 + r;
-        if (row >= M) continue;
-        const int q0 = c8 >> 2;
-        f32x4 v0 = *reinterpret_cast<const f32x4*>(smem + r * ROWB + ((q0 ^ (r & (CH - 1))) << 4));
-        f32x4 v1 = *reinterpret_cast<const f32x4*>(smem + r * ROWB + (((q0 + 1) ^ (r & (CH - 1))) << 4));
-        float v[8] = {v0[0] + bv0[0], v0[1] + bv0[1], v0[2] + bv0[2], v0[3] + bv0[3], v1[0] + bv1[0], v1[1] + bv1[1], v1[2] + bv1[2], v1[3] + bv1[3]};
-        const size_t off = (size_t)row * a.ldc + n0 + c8;
-        if (!split) {
-            if (EPI == EPI_BIAS_LRELU) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * SLOPE;
-            }
-            if (EPI == EPI_MASK) {
-                if constexpr (IN_F32) {
-                    const f32x4 ma = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.aux) + off);
-                    const f32x4 mb = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.aux) + off + 4);
+    for (int pass = 0; pass < BM / PR; ++pass) {
+        if (pass) __syncthreads();               // the previous pass has been read out
+        if (wm * 64 / PR == pass) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] *= ma[e] > 0.f ? 1.f : SLOPE;
-                        v[4 + e] *= mb[e] > 0.f ? 1.f : SLOPE;
+            for (int i = 0; i < NB; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const int m = (wm * 64) % PR + j * MF + fr;
+#pragma unroll
+                    for (int g = 0; g < (MF == 32 ? 4 : 1); ++g) {
+                        const int q = (wn * 64 + i * MF + (MF == 32 ? 8 * g + 4 * fh : 4 * fh)) >> 2;
+                        const f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                        *reinterpret_cast<f32x4*>(smem + m * ROWB + ((q ^ (m & (CH - 1))) << 4)) = v;
                     }
-                } else {
-                    const u32x4 m4 = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint16_t*>(a.aux) + off);
+                }
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int p = 0; p < PR / RPP; ++p) {
+            const int r = p * RPP + r0, row = m0 + pass * PR + r;
+            if (row >= M) continue;
+            const int q0 = c8 >> 2;
+            f32x4 v0 = *reinterpret_cast<const f32x4*>(smem + r * ROWB + ((q0 ^ (r & (CH - 1))) << 4));
+            f32x4 v1 = *reinterpret_cast<const f32x4*>(smem + r * ROWB + (((q0 + 1) ^ (r & (CH - 1))) << 4));
+            float v[8] = {v0[0] + bv0[0], v0[1] + bv0[1], v0[2] + bv0[2], v0[3] + bv0[3], v1[0] + bv1[0], v1[1] + bv1[1], v1[2] + bv1[2], v1[3] + bv1[3]};
+            const size_t off = (size_t)row * a.ldc + n0 + c8;
+            if (!split) {
+                if (EPI == EPI_BIAS_LRELU) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[2 * e] *= bf_lo(m4[e]) > 0.f ? 1.f : SLOPE;
-                        v[2 * e + 1] *= bf_hi(m4[e]) > 0.f ? 1.f : SLOPE;
+                    for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * SLOPE;
+                }
+                if (EPI == EPI_MASK) {
+                    if constexpr (IN_F32) {
+                        const f32x4 ma = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.aux) + off);
+                        const f32x4 mb = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.aux) + off + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] *= ma[e] > 0.f ? 1.f : SLOPE;
+                            v[4 + e] *= mb[e] > 0.f ? 1.f : SLOPE;
+                        }
+                    } else {
+                        const u32x4 m4 = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint16_t*>(a.aux) + off);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[2 * e] *= bf_lo(m4[e]) > 0.f ? 1.f : SLOPE;
+                            v[2 * e + 1] *= bf_hi(m4[e]) > 0.f ? 1.f : SLOPE;
+                        }
                     }
                 }
             }
-        }
-        if (OUT_BF16 && !split) {
-            const u32x4 o = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
-            *reinterpret_cast<u32x4*>(Cb + off * 2) = o;
-        } else {
-            *reinterpret_cast<f32x4*>(Cb + off * 4) = f32x4{v[0], v[1], v[2], v[3]};
-            *reinterpret_cast<f32x4*>(Cb + off * 4 + 16) = f32x4{v[4], v[5], v[6], v[7]};
+            if (OUT_BF16 && !split) {
+                const u32x4 o = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+                *reinterpret_cast<u32x4*>(Cb + off * 2) = o;
+            } else {
+                *reinterpret_cast<f32x4*>(Cb + off * 4) = f32x4{v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<f32x4*>(Cb + off * 4 + 16) = f32x4{v[4], v[5], v[6], v[7]};
+            }
         }
     }
 }

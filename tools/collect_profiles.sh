@@ -1,0 +1,46 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (through gpurun): rocprofv3 evidence for profiles/ -- kernel stats + HBM traffic (separate --pmc passes)
+# of the default bench command (BASELINE configs[1], fp32) and of the bf16 decoder mode at configs[2] / configs[3] sizes.
+#   gpurun --timeout 1200 -- 'bash tools/collect_profiles.sh r02'
+set -o pipefail
+TAG=${1:-r02}
+OUT=gpurun_out/${TAG}p
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p $OUT
+python bench.py --steps 3 --warmup 1 --cpu-windows 0 --no-extra --weights-cache /tmp/vae_cache.pt > $OUT/cache.log 2>&1 || exit 1
+COMMON="--cpu-windows 0 --no-extra --weights-cache /tmp/vae_cache.pt"
+run() {   # name, rocprof args, bench args
+  mkdir -p $(dirname $OUT/$1); rocprofv3 $2 --output-format csv -d $OUT/$1 -- python bench.py $3 $COMMON > $OUT/$1.log 2>&1 || { echo "FAILED $1"; tail -5 $OUT/$1.log; exit 1; }
+  grep '^{' $OUT/$1.log | cut -c1-160
+}
+# headline: configs[1] fp32
+run f32/trace      "--kernel-trace --stats" "--steps 5 --warmup 1"
+run f32/pmc_fetch  "--pmc FETCH_SIZE"       "--steps 2 --warmup 1 --no-profile"
+run f32/pmc_write  "--pmc WRITE_SIZE"       "--steps 2 --warmup 1 --no-profile"
+# bf16 decoder mode: configs[2] (1536 windows in one call) and configs[3] per-GPU shard (8196 windows)
+run bf16_1536/trace     "--kernel-trace --stats" "--steps 5 --warmup 1 --workload 128 --precision bf16"
+run bf16_8192/trace     "--kernel-trace --stats" "--steps 3 --warmup 1 --workload w8192 --precision bf16"
+run bf16_8192/pmc_fetch "--pmc FETCH_SIZE"       "--steps 1 --warmup 1 --workload w8192 --precision bf16 --no-profile"
+run bf16_8192/pmc_write "--pmc WRITE_SIZE"       "--steps 1 --warmup 1 --workload w8192 --precision bf16 --no-profile"
+# fp32 at configs[2] size (the LDS-DMA fp32 kernel takes over the decoder_input products)
+run f32_1536/trace      "--kernel-trace --stats" "--steps 3 --warmup 1 --workload 128"
+# keep the summaries small: per-dispatch traces are dropped, the stats / counter tables stay
+find $OUT -name '*_kernel_trace.csv' -delete
+for d in f32 bf16_8192; do
+  for k in pmc_fetch pmc_write; do
+    f=$(find $OUT/$d/$k -name '*counter_collection.csv' | head -1)
+    [ -n "$f" ] && python - "$f" <<'PY'
+import csv, sys, collections
+f = sys.argv[1]
+acc = collections.defaultdict(list)
+for r in csv.DictReader(open(f)):
+    acc[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
+with open(f.replace("counter_collection.csv", "counter_summary.csv"), "w") as o:
+    w = csv.writer(o); w.writerow(["kernel", "counter", "dispatches", "mean_value"])
+    for (k, c), v in sorted(acc.items()):
+        w.writerow([k, c, len(v), sum(v) / len(v)])
+PY
+    find $OUT/$d/$k -name '*counter_collection.csv' -delete
+  done
+done
+du -sh $OUT

@@ -69,7 +69,8 @@ static double run(const char* name, int M, int N, int K, int T, int n_split, int
     a.n_split = n_split; a.tiles_per_split = (nTiles + n_split - 1) / n_split; a.slab_stride = (size_t)M * N;
     auto k = gemm_glds_kernel<F32, TAPS, EPI, BM, BN, OUT_BF16, MF>;
     constexpr int BUF = (BM + BN) * 128;
-    const size_t smem = (size_t)(2 * BUF > BM * BN * 4 ? 2 * BUF : BM * BN * 4);
+    constexpr int PRB = (BM < 128 ? BM : 128) * BN * 4;
+    const size_t smem = (size_t)(2 * BUF > PRB ? 2 * BUF : PRB);
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const int grid = ((M + BM - 1) / BM) * (N / BN) * n_split;
     const int threads = (BM / 64) * (BN / 64) * 64;
@@ -129,6 +130,18 @@ int main(int argc, char** argv) {
         run<true, 3, EPI_BIAS_LRELU, 128, 128, false, 16>("conv 512->256 240w split 8", 2400, 256, 512, 10, 8, reps);
         run<true, 3, EPI_NONE, 128, 128, false, 16>("conv 256->512 240w split 4", 2400, 512, 256, 10, 4, reps);
         run<true, 3, EPI_BIAS_LRELU, 128, 128, false, 16>("conv 512->256 8192w", 81920, 256, 512, 10, 1, reps);
+    }
+    if (!strcmp(which, "tall")) {
+        run<false, 1, EPI_BIAS, 256, 128, true, 16>("dec_in fwd 8192w", 8192, 5120, 2048, 10, 1, reps);
+        run<false, 1, EPI_BIAS, 128, 128, true, 16>("dec_in fwd 8192w", 8192, 5120, 2048, 10, 1, reps);
+        run<false, 1, EPI_NONE, 256, 128, false, 16>("dec_in bwd 8192w", 8192, 2048, 5120, 10, 1, reps);
+        run<false, 1, EPI_NONE, 128, 128, false, 16>("dec_in bwd 8192w", 8192, 2048, 5120, 10, 1, reps);
+        run<false, 1, EPI_BIAS, 256, 128, true, 16>("dec_in fwd 1536w", 1536, 5120, 2048, 10, 1, reps);
+        run<false, 1, EPI_BIAS, 128, 128, true, 16>("dec_in fwd 1536w", 1536, 5120, 2048, 10, 1, reps);
+        run<false, 3, EPI_BIAS_LRELU, 256, 128, true, 16>("conv 512->256 8192w", 81920, 256, 512, 10, 1, reps);
+        run<false, 3, EPI_BIAS_LRELU, 128, 128, true, 16>("conv 512->256 8192w", 81920, 256, 512, 10, 1, reps);
+        run<true, 1, EPI_BIAS, 256, 128, false, 16>("dec_in fwd 8192w", 8192, 5120, 2048, 10, 1, reps);
+        run<true, 1, EPI_BIAS, 128, 128, false, 16>("dec_in fwd 8192w", 8192, 5120, 2048, 10, 1, reps);
     }
     if (all || !strcmp(which, "bf16")) {
         run<false, 1, EPI_BIAS, 128, 128, true, 16>("dec_in fwd 8192w", 8192, 5120, 2048, 10, 1, reps);

@@ -1,9 +1,8 @@
 #!/usr/bin/env python3
-"""Turn a gpurun_out/<round>/ rocprofv3 dump of `bench.py` into the small summaries kept under profiles/.
+"""Turn a gpurun_out/<tag>p/ dump of tools/collect_profiles.sh into the small summaries kept under profiles/.
 
-    python tools/summarize_profile.py gpurun_out/r01 profiles r01
+    python tools/summarize_profile.py gpurun_out/r02p profiles r02
 """
-import collections
 import csv
 import glob
 import json
@@ -15,50 +14,64 @@ os.makedirs(dst, exist_ok=True)
 
 
 def short(name):
-    return name.replace("void gem::", "gem::").split("(")[0]
+    return name.replace("void gem::", "gem::").replace("void ", "").split("(")[0].strip()
 
 
-stats = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))[0]
-rows = list(csv.DictReader(open(stats)))
-with open(os.path.join(dst, "kernel_stats_%s.csv" % tag), "w") as f:
-    w = csv.writer(f)
-    w.writerow(["kernel", "calls", "total_ms", "avg_us", "pct", "min_us", "max_us"])
-    for r in rows:
-        w.writerow([short(r["Name"]), r["Calls"], "%.3f" % (float(r["TotalDurationNs"]) / 1e6), "%.2f" % (float(r["AverageNs"]) / 1e3),
-                    r["Percentage"], "%.2f" % (float(r["MinNs"]) / 1e3), "%.2f" % (float(r["MaxNs"]) / 1e3)])
-
-traffic = {}
-for key, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-    f = glob.glob(os.path.join(src, "pmc_" + key, "*", "*counter_collection.csv"))
+def kernel_stats(sub, out_name):
+    f = glob.glob(os.path.join(src, sub, "trace", "*", "*kernel_stats.csv"))
     if not f:
-        continue
-    acc = collections.defaultdict(list)
-    for r in csv.DictReader(open(f[0])):
-        if r["Counter_Name"] == counter:
-            acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
-    traffic[key] = {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
+        return
+    rows = list(csv.DictReader(open(f[0])))
+    line = [l for l in open(os.path.join(src, sub, "trace.log")) if l.startswith("{")]
+    with open(os.path.join(dst, out_name), "w") as o:
+        if line:
+            d = json.loads(line[-1])
+            o.write("# rocprofv3 --kernel-trace --stats of: python bench.py (see profiles/README.md); this run printed value = %s %s, %s ms per step, "
+                    "workload: %s\n" % (d["value"], d["unit"], d["ms_per_step"], d["config"]["workload"]))
+        w = csv.writer(o)
+        w.writerow(["kernel", "calls", "total_ms", "avg_us", "pct", "min_us", "max_us"])
+        for r in rows:
+            w.writerow([short(r["Name"]), r["Calls"], "%.3f" % (float(r["TotalDurationNs"]) / 1e6), "%.2f" % (float(r["AverageNs"]) / 1e3),
+                        r["Percentage"], "%.2f" % (float(r["MinNs"]) / 1e3), "%.2f" % (float(r["MaxNs"]) / 1e3)])
 
-dom = [k for k in traffic.get("fetch", {}) if "gemm_f32_kernel<1, 0, 1, 1, 1" in k]
-out = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python bench.py --steps 2 --warmup 1 "
-               "--cpu-windows 0 --no-profile`; counters are in KiB; on gfx950 FETCH_SIZE reports half of a wide coalesced "
-               "stream, so read bytes = 2 * FETCH_SIZE * 1024 (MI355X_MICROARCH.md section HBM); per launch = mean over dispatches",
-       "kernels": {}}
-for k in sorted(set(traffic.get("fetch", {})) | set(traffic.get("write", {}))):
-    if not k.startswith("gem::"):
-        continue
-    fe = traffic.get("fetch", {}).get(k, (0.0, 0))
-    wr = traffic.get("write", {}).get(k, (0.0, 0))
-    out["kernels"][k] = {"dispatches": fe[1], "fetch_kib_raw": round(fe[0], 1), "read_bytes_corrected": round(2 * fe[0] * 1024),
-                         "write_bytes": round(wr[0] * 1024)}
-if dom:
-    d = out["kernels"][dom[0]]
-    red = [k for k in out["kernels"] if "splitk_reduce_kernel<0>" in k]
-    extra = out["kernels"][red[0]] if red else {"read_bytes_corrected": 0, "write_bytes": 0}
-    out["dominant_kernel"] = dom[0]
-    out["hbm_bytes_per_launch"] = d["read_bytes_corrected"] + d["write_bytes"]
-    out["hbm_bytes_per_launch_with_reduce"] = out["hbm_bytes_per_launch"] + extra["read_bytes_corrected"] + extra["write_bytes"]
-json.dump(out, open(os.path.join(dst, "traffic_%s.json" % tag), "w"), indent=1)
-json.dump({k: out.get(k) for k in ("note", "dominant_kernel", "hbm_bytes_per_launch", "hbm_bytes_per_launch_with_reduce")},
-          open(os.path.join(dst, "traffic_dominant_kernel.json"), "w"), indent=1)
-print(open(os.path.join(dst, "kernel_stats_%s.csv" % tag)).read()[:3000])
-print(json.dumps(out, indent=1)[:3000])
+
+def traffic(sub, dominant_substr, out_name, note_cmd):
+    t = {}
+    for key, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+        f = glob.glob(os.path.join(src, sub, "pmc_" + key, "*", "*counter_summary.csv"))
+        if not f:
+            return None
+        t[key] = {short(r["kernel"]): (float(r["mean_value"]), int(r["dispatches"])) for r in csv.DictReader(open(f[0])) if r["counter"] == counter}
+    out = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `%s`; counters are in KiB; on gfx950 FETCH_SIZE "
+                   "reports half of a wide coalesced stream, so read bytes = 2 * FETCH_SIZE * 1024 (MI355X_MICROARCH.md section HBM); "
+                   "per launch = mean over dispatches" % note_cmd, "kernels": {}}
+    for k in sorted(set(t["fetch"]) | set(t["write"])):
+        if not k.startswith("gem::"):
+            continue
+        fe, wr = t["fetch"].get(k, (0.0, 0)), t["write"].get(k, (0.0, 0))
+        out["kernels"][k] = {"dispatches": fe[1], "fetch_kib_raw": round(fe[0], 1), "read_bytes_corrected": round(2 * fe[0] * 1024),
+                             "write_bytes": round(wr[0] * 1024)}
+    dom = [k for k in out["kernels"] if dominant_substr in k]
+    if dom:
+        d = out["kernels"][dom[0]]
+        out["dominant_kernel"] = dom[0]
+        out["hbm_bytes_per_launch"] = d["read_bytes_corrected"] + d["write_bytes"]
+    json.dump(out, open(os.path.join(dst, out_name), "w"), indent=1)
+    return out
+
+
+kernel_stats("f32", "kernel_stats_%s.csv" % tag)
+kernel_stats("f32_1536", "kernel_stats_%s_f32_1536_windows.csv" % tag)
+kernel_stats("bf16_1536", "kernel_stats_%s_bf16_1536_windows.csv" % tag)
+kernel_stats("bf16_8192", "kernel_stats_%s_bf16_8196_windows.csv" % tag)
+o = traffic("f32", "gemm_f32_kernel<1, 0, 1, 1, 1", "traffic_%s.json" % tag,
+            "python bench.py --steps 2 --warmup 1 --cpu-windows 0 --no-extra --no-profile")
+if o and "dominant_kernel" in o:
+    json.dump({k: o.get(k) for k in ("note", "dominant_kernel", "hbm_bytes_per_launch")}, open(os.path.join(dst, "traffic_dominant_kernel.json"), "w"), indent=1)
+    print("headline dominant kernel:", o["dominant_kernel"], o["hbm_bytes_per_launch"], "bytes per launch")
+b = traffic("bf16_8192", "gemm_glds_kernel<false, 1, 0", "traffic_%s_bf16_8196_windows.json" % tag,
+            "python bench.py --steps 1 --warmup 1 --workload w8192 --precision bf16 --cpu-windows 0 --no-extra --no-profile")
+if b:
+    for k, v in b["kernels"].items():
+        if "glds" in k or "lbfgs" in k or "energy" in k:
+            print(k, v)
