@@ -59,6 +59,7 @@ SIGNATURES = {
                                      C.POINTER(GemLbfgsOpts), _P, _P, _P]),
     "gem_optimize_windows": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.POINTER(GemEnergyWeights),
                                        C.POINTER(GemEnergyWeights), C.POINTER(GemLbfgsOpts), _P, _P, _P, _P]),
+    "gem_set_texel_cache": (C.c_int, [_P, C.c_int]),
     "gem_graph_enable": (C.c_int, [_P, C.c_int]),
     "gem_graph_stats": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "gem_read_trace": (C.c_int, [_P, C.c_int, C.c_int, _P, _P]),

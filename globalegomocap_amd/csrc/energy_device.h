@@ -7,6 +7,7 @@
 namespace gem {
 
 __device__ __forceinline__ double wave_sum(double v) { return wave_sum_dpp(v); }
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr int MAXT = 16;               // frames per window supported by the LDS carve
 constexpr int MAXJ = GEM_MAX_JOINTS;
@@ -125,11 +126,33 @@ __device__ __forceinline__ void energy_window(const EnergyArgs& a, int b, int la
             const bool xl = in && x0i >= 0, xr = in && x0i + 1 < a.W, yt = y0i >= 0, yb = y0i + 1 < a.H;
             const int xa = x0i < 0 ? 0 : x0i, xb = x0i + 1 < a.W ? x0i + 1 : a.W - 1;
             const int ya = y0i < 0 ? 0 : y0i, yc = y0i + 1 < a.H ? y0i + 1 : a.H - 1;
+            // The 2x2 texel block under a joint rarely changes from one evaluation to the next (the joint moves by a fraction
+            // of a texel): the four raw texels of the last evaluation are kept per (window, frame, joint) and re-read as ONE
+            // coalesced 20-byte record instead of up to four scattered cache lines of the [frame][y][x][joint] heat-maps
+            // (57 KB of lines per window and evaluation otherwise: the stand-alone energy kernel is bound by them at large
+            // batch).  Same values, bit for bit; the cache is emptied at the start of every stage.
             const float* hm = a.heat + ((size_t)(a.frame0[b] + t) * a.H * a.W) * J + j;
-            float nw = hm[((size_t)ya * a.W + xa) * J];
-            float ne = hm[((size_t)ya * a.W + xb) * J];
-            float sw = hm[((size_t)yc * a.W + xa) * J];
-            float se = hm[((size_t)yc * a.W + xb) * J];
+            float nw, ne, sw, se;
+            const int key = in ? (ya * a.W + xa) | ((yc * a.W + xb) << 16) : -1;      // the block's clamped corner texels (H*W <= 65536/2)
+            const size_t ci = (size_t)b * (T * J) + p;
+            bool hit = false;
+            if (a.tex_key && in) {
+                hit = a.tex_key[ci] == key;
+                if (hit) {
+                    const f32x4_t c = *reinterpret_cast<const f32x4_t*>(a.tex_val + ci * 4);
+                    nw = c[0]; ne = c[1]; sw = c[2]; se = c[3];
+                }
+            }
+            if (!hit) {
+                nw = hm[((size_t)ya * a.W + xa) * J];
+                ne = hm[((size_t)ya * a.W + xb) * J];
+                sw = hm[((size_t)yc * a.W + xa) * J];
+                se = hm[((size_t)yc * a.W + xb) * J];
+                if (a.tex_key && in) {
+                    a.tex_key[ci] = key;
+                    *reinterpret_cast<f32x4_t*>(a.tex_val + ci * 4) = f32x4_t{nw, ne, sw, se};
+                }
+            }
             nw = (yt && xl) ? nw : 0.f;
             ne = (yt && xr) ? ne : 0.f;
             sw = (yb && xl) ? sw : 0.f;

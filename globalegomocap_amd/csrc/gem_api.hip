@@ -202,6 +202,9 @@ int gem_create(const gem_config* cfg, gem_handle** out) {
     if (dev_alloc(w.allocs, &w.f, (size_t)B)) return 1;
     if (dev_alloc(w.allocs, &w.parts, (size_t)B * 5)) return 1;
     if (dev_alloc(w.allocs, &w.trace, (size_t)TRACE_ROUNDS * B)) return 1;
+    if ((size_t)cfg->heat_h * cfg->heat_w <= 32768) {        // (the texel-block key packs two texel indices into 32 bits)
+        if (dev_alloc(w.allocs, &w.tex_key, rows * h->J) || dev_alloc(w.allocs, &w.tex_val, rows * h->J * 4)) return 1;
+    }
     if (dev_alloc(w.allocs, &w.pose_a, rows * h->C)) return 1;
     if (dev_alloc(w.allocs, &w.pose_b, rows * h->C)) return 1;
     if (dev_alloc(w.allocs, &w.n_log, (size_t)N_LOG)) return 1;
@@ -404,6 +407,7 @@ static EnergyArgs energy_args(gem_handle* h, const float* X0, const float* heat,
     EnergyArgs a;
     a.Xp = w.dec_act.back(); a.X0 = X0; a.heat = heat; a.frame0 = frame0; a.mean_bone = mean_bone;
     a.dXp = w.dXp; a.dXp_b = nullptr; a.f = w.f; a.parts = w.parts;
+    a.tex_key = w.tex_on ? w.tex_key : nullptr; a.tex_val = w.tex_on ? w.tex_val : nullptr;
     a.w3d = (float)wt.w3d; a.ws = (float)wt.smooth; a.wb = (float)wt.bone; a.wv = (float)wt.vae; a.wr = (float)wt.reproj;
     a.dw3d = wt.w3d; a.dws = wt.smooth; a.dwb = wt.bone; a.dwv = wt.vae; a.dwr = wt.reproj;
     a.T = h->T; a.J = h->J; a.H = h->cfg.heat_h; a.W = h->cfg.heat_w; a.n_poly = h->cfg.n_poly;
@@ -486,7 +490,12 @@ static int optimize_stage_impl(gem_handle* h, int stage, int B, const float* d_p
         if (launch_compact(h, B, 1, s)) return 1;
         w.dyn = true;
     }
+    // texel-block cache of the reprojection term: valid for this stage's heat-maps / windows only
+    static const bool no_tex = getenv("GEM_NO_TEXCACHE") != nullptr;
+    w.tex_on = !no_tex && h->tex_cache && w.tex_key && wt.reproj != 0.0;
+    if (w.tex_on) GEM_HIP(hipMemsetAsync(w.tex_key, 0xFF, (size_t)B * h->T * h->J * sizeof(int), s));
     const EnergyArgs ea = energy_args(h, d_pose_in, d_heat, d_frame0, d_mean_bone, wt);
+    w.tex_on = false;
     const int rounds = opt.max_eval + 1;          // upper bound on evaluations per window (see lbfgs.hip)
     // closure values of this stage, one row per round (0xFF bytes = NaN: "window took no evaluation in this round")
     GEM_HIP(hipMemsetAsync(w.trace, 0xFF, (size_t)TRACE_ROUNDS * w.Bmax * sizeof(double), s));
@@ -665,6 +674,12 @@ int gem_read_trace(gem_handle* h, int B, int n_rounds, double* d_out, void* stre
     if (B == 0 || n_rounds == 0) return 0;
     GEM_HIP(hipMemcpy2DAsync(d_out, (size_t)B * sizeof(double), h->ws.trace, (size_t)h->ws.Bmax * sizeof(double),
                              (size_t)B * sizeof(double), (size_t)n_rounds, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+
+int gem_set_texel_cache(gem_handle* h, int on) {
+    if (!h) { set_error("gem_set_texel_cache: null handle"); return 1; }
+    h->tex_cache = on != 0;
     return 0;
 }
 

@@ -100,6 +100,9 @@ struct Workspace {
     int* phase = nullptr;               // [B] copy of state[b].phase for the compaction scan
     double* f = nullptr;                // [B] energy of the trial point
     double* parts = nullptr;            // [B,5]
+    int* tex_key = nullptr;             // [B, T*J] / float [B, T*J, 4]: heat-map texels of the last evaluation (energy_device.h)
+    float* tex_val = nullptr;
+    bool tex_on = false;                // energy_args() hands the cache to the kernels (inside a stage only)
     double* trace = nullptr;            // [TRACE_ROUNDS][Bmax] closure value each window consumed in round r of the last stage (NaN: none)
     int round = -1;                     // evaluation round being enqueued (-1: outside the rounds)
     // pipeline scratch
@@ -200,6 +203,7 @@ struct gem_handle {
     int n_cu = 256;                // compute units of the device (hipDeviceAttributeMultiprocessorCount)
     double* post_work = nullptr;   // scratch of the post-processing calls (errors.hip), grown on demand
     size_t post_work_elems = 0;
+    bool tex_cache = true;         // gem_set_texel_cache
     bool graphs_on = false;        // gem_graph_enable
     std::vector<gem::GraphEntry> graphs;
     uint64_t graph_tick = 0;
@@ -279,6 +283,8 @@ struct EnergyArgs {
     float cx, cy;
     const int* parents;
     const int* children;
+    int* tex_key;             // [B, T*J] texel-block cache of the reprojection term: key of the cached 2x2 block (-1: empty) ...
+    float* tex_val;           // [B, T*J, 4] ... and its four texels (nw, ne, sw, se); nullptr: no cache
     const int* n_dev;         // device count of active slots (nullptr: all B)
     const int* perm;          // slot -> window (nullptr: identity); X / dX rows are slot-ordered, the rest window-ordered
 };

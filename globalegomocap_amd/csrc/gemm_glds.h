@@ -83,8 +83,9 @@ __device__ __forceinline__ bool tile_of_block(int id, int n_mt, int n_nt, int n_
     return true;
 }
 
-template <bool IN_F32, int TAPS, int EPI, int BM, int BN, bool OUT_BF16, int MF = 16>
+template <bool IN_F32, int TAPS, int EPI, int BM, int BN, bool OUT_BF16, int MF = 16, int STAGES = 2>
 __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_glds_kernel(const Args a) {
+    static_assert(STAGES == 2 || STAGES == 3, "double or triple buffering");
     static_assert(!(IN_F32 && OUT_BF16), "fp32 operands write fp32");
     constexpr int ES = IN_F32 ? 4 : 2;           // operand element size
     constexpr int BK = 128 / ES;                 // one K-step = 128 bytes of every row
@@ -178,12 +179,8 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_glds_kernel(c
         b_off[q] = A_BYTES + rb * 128; b_x[q] = (rb >> 1) & 7;
     }
 
-    stage(0, kt_begin);
-    __syncthreads();
-    int cur = 0;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        if (kt + 1 < kt_end) stage(cur ^ 1, kt + 1);
-        const unsigned char* base = smem + cur * BUF;
+    auto compute = [&](int buf) {
+        const unsigned char* base = smem + buf * BUF;
 #pragma unroll
         for (int s = 0; s < NSUB; ++s) {
             if constexpr (IN_F32) {
@@ -218,8 +215,38 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_glds_kernel(c
                     }
             }
         }
-        __syncthreads();          // (waits for this wave's DMA as well: the next tile is complete for everybody)
-        cur ^= 1;
+    };
+
+    if constexpr (STAGES == 2) {
+        // two buffers: the DMA of tile t+1 is issued before the MFMAs of tile t; the barrier that ends a K-step (with the
+        // vmcnt(0) the compiler puts in front of it) completes tile t+1 for everybody
+        stage(0, kt_begin);
+        __syncthreads();
+        int cur = 0;
+        for (int kt = kt_begin; kt < kt_end; ++kt) {
+            if (kt + 1 < kt_end) stage(cur ^ 1, kt + 1);
+            compute(cur);
+            __syncthreads();
+            cur ^= 1;
+        }
+    } else {
+        // three buffers, tiles two K-steps ahead: a COUNTED s_waitcnt leaves the DMA of tile t+1 in flight across the barrier
+        // (one raw s_barrier per K-step, no fence: __syncthreads would drain the DMA queue).  A wave's DMA pieces retire in issue
+        // order, so vmcnt(pieces of one tile) = "my part of tile t has landed"; the barrier extends that to every wave's part
+        // and also says that everybody has finished reading tile t-1, whose buffer the DMA of tile t+2 overwrites next.
+        constexpr int PIECES = A_INSTR + B_INSTR;
+        stage(0, kt_begin);
+        if (kt_begin + 1 < kt_end) stage(1, kt_begin + 1);
+        int cur = 0;
+        for (int kt = kt_begin; kt < kt_end; ++kt) {
+            if (kt + 1 < kt_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + 2 < kt_end) stage(cur >= 1 ? cur - 1 : 2, kt + 2);          // buffer (cur + 2) % 3
+            compute(cur);
+            cur = cur == 2 ? 0 : cur + 1;
+        }
+        __syncthreads();          // every wave has left the main loop: the operand buffers become the epilogue's staging area
     }
 
     // ---- epilogue: fp32 tile -> LDS (row m, 16-byte chunk q of its BN columns at position q ^ (m & (CH-1))) -> whole rows out
@@ -228,7 +255,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_glds_kernel(c
     constexpr int ROWB = BN * 4;                 // bytes per staged row
     constexpr int CH = BN / 4;                   // 16-byte chunks per row (32 for BN = 128, 16 for BN = 64)
     constexpr int PR = BM < 128 ? BM : 128;      // rows per pass
-    static_assert(PR * ROWB <= 2 * BUF, "a pass of the staged fp32 tile must fit the two operand buffers");
+    static_assert(PR * ROWB <= STAGES * BUF, "a pass of the staged fp32 tile must fit the operand buffers");
     const bool split = a.n_split > 1;
     constexpr int TPR = BN / 8;                  // threads per row (8 columns each)
     constexpr int RPP = NT / TPR;                // rows per store sweep

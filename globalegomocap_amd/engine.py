@@ -70,6 +70,10 @@ class WindowEngine:
         except Exception:
             pass
 
+    def set_texel_cache(self, on=True):
+        """Diagnostic switch of the reprojection term's texel-block cache (gem_set_texel_cache); results do not depend on it."""
+        _capi.check(self.lib.gem_set_texel_cache(self._h, 1 if on else 0), self.lib)
+
     def enable_graphs(self, on=True):
         """hipGraph replay of whole `optimize_windows` / `optimize_stage` calls (gem_graph_enable): the first call with a
         given signature runs eagerly, the second is captured, later ones are ONE graph launch instead of ~700 kernel launches.

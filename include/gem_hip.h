@@ -154,6 +154,11 @@ int gem_optimize_windows(gem_handle* h, int B, const float* d_local_pose, const 
                          const gem_lbfgs_opts* opt, float* d_mid_local, double* d_global,
                          gem_window_stats* d_stats, void* stream);
 
+/* The reprojection term (optimizer.py:139-149) keeps the four heat-map texels under every joint from one evaluation of a
+ * stage to the next and re-reads them as one record while the joint stays inside the same texel block (same values, bit for
+ * bit; fewer scattered cache lines).  On by default; this switch exists so that a test can prove "bit for bit". */
+int gem_set_texel_cache(gem_handle* h, int on);
+
 /* hipGraph replay of whole optimisation calls (BASELINE configs[4] "hipGraph-captured inner step"; the loop being captured
  * replaces optimizer.py:261-270 for every window of the call).  With graphs on, gem_optimize_stage / gem_optimize_windows
  * run eagerly the first time they see a given signature (batch size, precision, every pointer argument, weights, options,

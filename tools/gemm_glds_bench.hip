@@ -41,7 +41,7 @@ __global__ void ref_kernel(const void* Av, const void* Wv, const float* bias, fl
     C[i] = acc;
 }
 
-template <bool F32, int TAPS, int EPI, int BM, int BN, bool OUT_BF16, int MF = 16>
+template <bool F32, int TAPS, int EPI, int BM, int BN, bool OUT_BF16, int MF = 16, int STAGES = 2>
 static double run(const char* name, int M, int N, int K, int T, int n_split, int reps) {
     constexpr int ES = F32 ? 4 : 2;
     std::vector<unsigned char> hA((size_t)M * K * ES), hW((size_t)TAPS * N * K * ES);
@@ -67,10 +67,10 @@ static double run(const char* name, int M, int N, int K, int T, int n_split, int
     a.lda = K; a.ldc = N; a.M = M; a.N = N; a.K = K; a.T = T;
     const int nTiles = TAPS * (K / (128 / ES));
     a.n_split = n_split; a.tiles_per_split = (nTiles + n_split - 1) / n_split; a.slab_stride = (size_t)M * N;
-    auto k = gemm_glds_kernel<F32, TAPS, EPI, BM, BN, OUT_BF16, MF>;
+    auto k = gemm_glds_kernel<F32, TAPS, EPI, BM, BN, OUT_BF16, MF, STAGES>;
     constexpr int BUF = (BM + BN) * 128;
     constexpr int PRB = (BM < 128 ? BM : 128) * BN * 4;
-    const size_t smem = (size_t)(2 * BUF > PRB ? 2 * BUF : PRB);
+    const size_t smem = (size_t)(STAGES * BUF > PRB ? STAGES * BUF : PRB);
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const int grid = ((M + BM - 1) / BM) * (N / BN) * n_split;
     const int threads = (BM / 64) * (BN / 64) * 64;
@@ -105,8 +105,8 @@ static double run(const char* name, int M, int N, int K, int T, int n_split, int
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1e3 / reps, tf = 2.0 * M * N * K * TAPS / (us * 1e-6) / 1e12;
     const double peak = F32 ? 157.3 : 2500.0;
-    printf("%-30s %s M %6d N %5d K %5d taps %d split %d  %dx%d mf%d out %s: %8.2f us  %7.1f TFLOP/s (%.3f of %.0f)  max err %.3e (ref max %.2f)\n", name,
-           F32 ? "f32 " : "bf16", M, N, K, TAPS, n_split, BM, BN, MF, OUT_BF16 ? "bf16" : "f32 ", us, tf, tf / peak, peak, maxerr, maxref);
+    printf("%-30s %s M %6d N %5d K %5d taps %d split %d  %dx%d mf%d st%d out %s: %8.2f us  %7.1f TFLOP/s (%.3f of %.0f)  max err %.3e (ref max %.2f)\n", name,
+           F32 ? "f32 " : "bf16", M, N, K, TAPS, n_split, BM, BN, MF, STAGES, OUT_BF16 ? "bf16" : "f32 ", us, tf, tf / peak, peak, maxerr, maxref);
     CK(hipFree(dA)); CK(hipFree(dW)); CK(hipFree(db)); CK(hipFree(dZ)); CK(hipFree(dC)); CK(hipFree(dRef));
     return tf;
 }
@@ -131,17 +131,19 @@ int main(int argc, char** argv) {
         run<true, 3, EPI_NONE, 128, 128, false, 16>("conv 256->512 240w split 4", 2400, 512, 256, 10, 4, reps);
         run<true, 3, EPI_BIAS_LRELU, 128, 128, false, 16>("conv 512->256 8192w", 81920, 256, 512, 10, 1, reps);
     }
-    if (!strcmp(which, "tall")) {
-        run<false, 1, EPI_BIAS, 256, 128, true, 16>("dec_in fwd 8192w", 8192, 5120, 2048, 10, 1, reps);
-        run<false, 1, EPI_BIAS, 128, 128, true, 16>("dec_in fwd 8192w", 8192, 5120, 2048, 10, 1, reps);
-        run<false, 1, EPI_NONE, 256, 128, false, 16>("dec_in bwd 8192w", 8192, 2048, 5120, 10, 1, reps);
-        run<false, 1, EPI_NONE, 128, 128, false, 16>("dec_in bwd 8192w", 8192, 2048, 5120, 10, 1, reps);
-        run<false, 1, EPI_BIAS, 256, 128, true, 16>("dec_in fwd 1536w", 1536, 5120, 2048, 10, 1, reps);
-        run<false, 1, EPI_BIAS, 128, 128, true, 16>("dec_in fwd 1536w", 1536, 5120, 2048, 10, 1, reps);
-        run<false, 3, EPI_BIAS_LRELU, 256, 128, true, 16>("conv 512->256 8192w", 81920, 256, 512, 10, 1, reps);
-        run<false, 3, EPI_BIAS_LRELU, 128, 128, true, 16>("conv 512->256 8192w", 81920, 256, 512, 10, 1, reps);
-        run<true, 1, EPI_BIAS, 256, 128, false, 16>("dec_in fwd 8192w", 8192, 5120, 2048, 10, 1, reps);
-        run<true, 1, EPI_BIAS, 128, 128, false, 16>("dec_in fwd 8192w", 8192, 5120, 2048, 10, 1, reps);
+    if (!strcmp(which, "pipe")) {
+        run<false, 1, EPI_BIAS, 128, 128, true, 16, 2>("dec_in fwd 8192w", 8192, 5120, 2048, 10, 1, reps);
+        run<false, 1, EPI_BIAS, 128, 128, true, 16, 3>("dec_in fwd 8192w", 8192, 5120, 2048, 10, 1, reps);
+        run<false, 1, EPI_BIAS, 256, 128, true, 16, 3>("dec_in fwd 8192w", 8192, 5120, 2048, 10, 1, reps);
+        run<false, 1, EPI_NONE, 128, 128, false, 16, 3>("dec_in bwd 8192w", 8192, 2048, 5120, 10, 1, reps);
+        run<false, 1, EPI_NONE, 256, 128, false, 16, 3>("dec_in bwd 8192w", 8192, 2048, 5120, 10, 1, reps);
+        run<false, 1, EPI_BIAS, 128, 128, true, 16, 3>("dec_in fwd 1536w", 1536, 5120, 2048, 10, 1, reps);
+        run<false, 1, EPI_BIAS, 256, 128, true, 16, 3>("dec_in fwd 1536w", 1536, 5120, 2048, 10, 1, reps);
+        run<false, 1, EPI_NONE, 128, 128, false, 16, 3>("dec_in bwd 1536w split 3", 1536, 2048, 5120, 10, 3, reps);
+        run<false, 3, EPI_BIAS_LRELU, 128, 128, true, 16, 3>("conv 512->256 8192w", 81920, 256, 512, 10, 1, reps);
+        run<false, 3, EPI_BIAS_LRELU, 256, 128, true, 16, 3>("conv 512->256 8192w", 81920, 256, 512, 10, 1, reps);
+        run<false, 3, EPI_BIAS_LRELU, 128, 64, true, 16, 3>("conv 64->64 8192w", 81920, 64, 64, 10, 1, reps);
+        run<true, 1, EPI_BIAS, 128, 128, false, 16, 3>("dec_in fwd 8192w", 8192, 5120, 2048, 10, 1, reps);
     }
     if (all || !strcmp(which, "bf16")) {
         run<false, 1, EPI_BIAS, 128, 128, true, 16>("dec_in fwd 8192w", 8192, 5120, 2048, 10, 1, reps);
