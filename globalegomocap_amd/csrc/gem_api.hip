@@ -3,6 +3,7 @@
 // sequencing; all arithmetic of the path runs in the HIP kernels of gemm_f32.hip, energy.hip, lbfgs.hip.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -773,6 +774,13 @@ int gem_profile_read(gem_handle* h, int family, double* total_ms, int64_t* n_lau
                 GEM_HIP(hipMemcpy(nlog.data(), h->ws.n_log, (size_t)N_LOG * sizeof(int), hipMemcpyDeviceToHost));
             }
             if (h->ws.log_pos - r.log_idx <= N_LOG) r.flops = r.flops_per_window * nlog[r.log_idx % N_LOG];
+        }
+        static const char* dump = getenv("GEM_PROFILE_DUMP");          // developer aid: one line per timed launch
+        if (dump) {
+            if (FILE* f = fopen(dump, "a")) {
+                fprintf(f, "%d %d %.3f\n", r.family, r.log_idx >= 0 && !nlog.empty() ? nlog[r.log_idx % N_LOG] : -1, ms * 1e3);
+                fclose(f);
+            }
         }
         p.total_ms[r.family] += ms;
         p.n[r.family] += 1;

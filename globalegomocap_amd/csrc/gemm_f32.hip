@@ -18,6 +18,7 @@
 
 #include "gem_internal.h"
 #include "gemm_glds.h"
+#include "gemm_rows.h"
 
 namespace gem {
 
@@ -372,9 +373,64 @@ static int launch_glds_f32(gem_handle* h, const Layer& L, const float* A, int ld
     return 0;
 }
 
+// Few rows (one sequence: <= ~256 windows), linear layers: the weight-streaming kernel of gemm_rows.h -- one workgroup per CU,
+// all active rows against one 64-column weight tile.  Forward (direct output, bias fused): no split-K, no slabs, no reduce
+// pass.  Backward (the consumer sums slabs anyway): as few K slices as fill the chip.  Used when the cut fills >= 3/4 of the
+// CUs' matrix time; otherwise (tiny batches, large batches) the tiled kernels below take over.
+template <int S, int RT>
+static int launch_rows_as(gem_handle* h, const Layer& L, const float* A, int lda, float* C, int ldc, int M, hipStream_t s,
+                          const int* row_map, const rows::Plan& p, bool direct) {
+    auto k = rows::gemm_rows_kernel<S, RT>;
+    static PerDeviceOnce once;
+    if (once.need(h->cfg.device))
+        GEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_PER_CU));
+    rows::Args a{};
+    a.A = A; a.W = L.w; a.bias = direct ? L.bias : nullptr; a.C = direct ? C : h->ws.splitk;
+    a.m_dev = h->ws.dyn ? h->ws.n_active : nullptr;
+    a.row_map = row_map;
+    a.lda = lda; a.ldc = ldc; a.M = M; a.N = L.N; a.K = L.K;
+    a.n_rb = p.n_rb; a.n_split = p.n_split; a.tiles_per_split = p.per; a.slab_stride = (size_t)M * ldc;
+    const int grid = p.n_rb * (L.N / rows::BN) * p.n_split;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), (size_t)S * rows::Geometry<RT>::STAGE_BYTES, s, a);
+    GEM_HIP(hipGetLastError());
+    return 0;
+}
+
+// returns -1 when the shape is not one for this kernel (the caller falls through to the tiled kernels)
+template <int EPI>
+static int launch_rows(gem_handle* h, const Layer& L, const float* A, int lda, const float* aux, float* C, int ldc, int M,
+                       hipStream_t s, const int* row_map) {
+    static const bool off = getenv("GEM_NO_ROWS") != nullptr;                 // developer override (A/B runs)
+    static const char* only = getenv("GEM_ROWS_ONLY");                        // "fwd": direct-output launches only
+    if (off || M < 48 || L.N % rows::BN != 0 || L.K % rows::BK != 0 || (size_t)h->ws.Bmax * lda * 4 >= ((size_t)1 << 32) ||
+        (size_t)L.N * L.K * 4 >= ((size_t)1 << 32))
+        return -1;
+    // direct output unless the consumer takes slabs (decoder_input backward: lbfgs_advance_kernel sums them)
+    const bool slabs = h->ws.defer_reduce && h->ws.splitk;
+    if (slabs && only && only[0] == 'f') return -1;
+    rows::Plan p5 = rows::plan(M, L.N, L.K, 5, h->n_cu, slabs, h->ws.splitk_elems, ldc);
+    rows::Plan p8 = rows::plan(M, L.N, L.K, 8, h->n_cu, slabs, h->ws.splitk_elems, ldc);
+    const bool use8 = p8.n_rb > 0 && (p5.n_rb == 0 || p8.fill > p5.fill + 1e-9);
+    const rows::Plan& p = use8 ? p8 : p5;
+    if (p.n_rb == 0 || p.fill < 0.75) return -1;
+    const bool direct = p.n_split == 1;
+    if (!direct) {
+        SlabSrc& d = h->ws.deferred;
+        d.base = h->ws.splitk; d.nslab = p.n_split; d.stride = (size_t)M * ldc;
+        d.dyn_W = 0; d.n_tiles = 0; d.ldc = ldc; d.CT = L.N / 64; d.m_dev = h->ws.dyn ? h->ws.n_active : nullptr;
+    }
+    (void)aux;
+    return use8 ? launch_rows_as<3, 8>(h, L, A, lda, C, ldc, M, s, row_map, p, direct)
+                : launch_rows_as<4, 5>(h, L, A, lda, C, ldc, M, s, row_map, p, direct);
+}
+
 template <int TAPS, int EPI, int TAG>
 static int launch_tile(gem_handle* h, const Layer& L, const float* A, int lda, const float* aux, float* C, int ldc, int M, int T,
                        hipStream_t s, const int* row_map) {
+    if (TAPS == 1 && (EPI == EPI_BIAS || EPI == EPI_NONE)) {
+        const int rc = launch_rows<EPI>(h, L, A, lda, aux, C, ldc, M, s, row_map);
+        if (rc >= 0) return rc;
+    }
     static const bool no_glds = getenv("GEM_NO_GLDS_F32") != nullptr;          // developer override (A/B runs)
     if (!no_glds && L.N % 128 == 0 && L.K % 32 == 0 && (long)((M + 127) / 128) * (L.N / 128) >= 3L * h->n_cu / 2 && h->ws.zero16 &&
         !h->ws.defer_reduce)

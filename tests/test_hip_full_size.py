@@ -122,6 +122,55 @@ def test_full_size_stages_against_reference_golden(torch_cuda, golden, full_vaes
     eng.close()
 
 
+@pytest.mark.parametrize("copies", [20, 19])
+def test_full_size_stages_in_a_one_sequence_batch_against_reference_golden(torch_cuda, golden, full_vaes, copies):
+    """The same 24 reference stage calls, but batched the way BASELINE configs[1] batches them: 12 windows x 20 (or 19: a
+    ragged last row tile) copies = 240 (228) windows per stage call, the size at which the decoder_input products run in
+    the few-rows kernel (csrc/gemm_rows.h) and the rows in use shrink on the device while the stage runs.  Every copy must
+    reproduce the reference like the 12-window call does -- evaluation counts, closure prefix, final energy, poses -- and
+    all copies of a window must agree bitwise (they sit in different row tiles / row blocks)."""
+    import torch
+    from globalegomocap_amd.engine import stats_to_numpy
+    g = golden("pipeline_full")
+    data, sd_l, sd_g, w_l, w_g = full_vaes
+    B = 12 * copies
+    eng = _engine(B, sd_l, sd_g)
+    mb = eng.mean_bone_length(data["estimated_local_skeleton"].astype(np.float32))
+    starts = np.tile(window_starts(100), copies).astype(np.int32)
+    heat = data["heatmap_list"]
+    local_diff = []
+    for st, w in ((0, w_l), (1, w_g)):
+        rows = np.arange(st, 24, 2)
+        out, stats = eng.optimize_stage(st, np.tile(g["stage_in"][rows], (copies, 1, 1, 1)), mb, np.tile(g["eps"][rows], (copies, 1)),
+                                        _ew(w), heat, starts)
+        tr = eng.read_trace(B)
+        sn = stats_to_numpy(stats)
+        assert (sn["status"] == 1).all()
+        o = out.reshape(copies, 12, 10, 15, 3)
+        s_ = stats.reshape(copies, 12, -1)
+        for c in range(1, copies):
+            assert torch.equal(o[0], o[c]) and torch.equal(s_[0], s_[c]), (st, c)
+        out = out.cpu().numpy()
+        for k, row in enumerate(rows):
+            ref_tr = g["trace"][row]
+            n_ref = int(g["func_evals"][row])
+            d = np.linalg.norm(out[k] - g["stage_out"][row], axis=-1)
+            info = (int(row), int(sn["func_evals"][k]), n_ref, float(sn["final_loss"][k]), float(np.nanmin(ref_tr)), float(d.mean() * 1e3))
+            np.testing.assert_allclose(tr[k, :4], ref_tr[:4], rtol=5e-4 if st else 2e-4, atol=1e-9, err_msg="row %d" % row)
+            assert abs(int(sn["func_evals"][k]) - n_ref) <= 1 and abs(int(sn["n_iter"][k]) - int(g["n_iter"][row])) <= 1, info
+            if st:
+                assert int(sn["func_evals"][k]) == n_ref and int(sn["n_iter"][k]) == int(g["n_iter"][row]), info
+                assert abs(sn["final_loss"][k] - np.nanmin(ref_tr)) <= 1e-4 * abs(np.nanmin(ref_tr)), info
+                assert d.mean() < 0.05e-3 and d.max() < 0.2e-3, info
+            else:
+                assert abs(sn["final_loss"][k] - np.nanmin(ref_tr)) <= 2e-3 * abs(np.nanmin(ref_tr)), info
+                assert d.mean() < 2e-3, info
+                local_diff.append(d.mean())
+    print("B = %d: local-stage pose deviation from the reference (mm): %s" % (B, np.round(np.sort(local_diff) * 1e3, 4)))
+    assert np.median(local_diff) < 0.05e-3, np.sort(local_diff)
+    eng.close()
+
+
 def test_full_size_bench_call_against_reference_golden(torch_cuda, golden, full_vaes, tmp_path):
     """The call bench.py times -- WindowEngine.optimize_windows: local stage, fp64 relative-global transform, global stage,
     back to global, all 12 windows of a jittered-camera chunk at once -- and the main() mirror around it, against the

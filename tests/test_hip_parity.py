@@ -681,6 +681,55 @@ def test_zero_weights_stop_at_the_first_evaluation_and_return_the_decoded_start(
     np.testing.assert_allclose(one.cpu().numpy(), out[:1].cpu().numpy(), rtol=0, atol=2e-6)
 
 
+@pytest.mark.parametrize("B", [240, 229, 175, 100])
+def test_one_sequence_batches_take_the_row_streaming_gemm(torch_cuda, B):
+    """BASELINE configs[1] regime (one sequence: 100..256 windows in a batch): the decoder_input products run in the
+    weight-streaming few-rows kernel (csrc/gemm_rows.h: all rows against one 64-column weight tile per workgroup, row tiles of
+    16 dealt over 2..4 row blocks, K quarters per wave summed through LDS).  One evaluation spot-checked against the oracle on
+    windows at row-tile / row-block edges, bitwise agreement of identical windows that sit in different row blocks -- for one
+    evaluation and for a whole stage (row count shrinking on the device as windows finish).  The reference-pinned check of
+    this kernel is tests/test_hip_full_size.py::test_full_size_stages_in_a_one_sequence_batch_against_reference_golden."""
+    import torch
+    from globalegomocap_amd.engine import stats_to_numpy
+    sd = vae_schema.synthetic_state_dict(FULL, 5)
+    eng = _engine(FULL, max_windows=B)
+    eng.load_vae(0, sd)
+    vae = O.fold_vae(sd)
+    cam = oracle_camera()
+    seq = synth.make_sequence(n_frames=200, seed=35)
+    est = np.asarray(seq["estimated_local_skeleton"], dtype=np.float32)
+    heat = np.asarray(seq["heatmap_list"], dtype=np.float32)
+    rng = np.random.default_rng(8)
+    starts = rng.integers(0, 190, B).astype(np.int32)
+    starts[B - 1] = starts[0]; starts[B // 2] = starts[0]                  # the same window in three row blocks
+    pose = np.stack([est[s:s + 10] for s in starts])
+    mb = O.mean_bone_length(est)
+    eps = rng.normal(size=(B, 2048)).astype(np.float32)
+    eps[B - 1] = eps[0]; eps[B // 2] = eps[0]
+    mu_d, lv_d, z_d = eng.encode(0, pose.reshape(B, 10, 45), eps)
+    E, parts, dz, X = eng.energy_grad(0, z_d, pose, mb, _ew(W_ALL), heat, starts)
+    for b in (B // 2, B - 1):
+        assert torch.equal(X[0], X[b]) and torch.equal(dz[0], dz[b]) and torch.equal(z_d[0], z_d[b]), b
+    z = z_d.cpu().numpy()
+    mu_o, lv_o = O.encode(vae, pose[:1].reshape(1, 10, 45))
+    assert np.abs(mu_d[0].cpu().numpy() - mu_o[0]).max() <= 1e-4 * max(1.0, np.abs(mu_o).max())
+    for b in sorted({0, 15, 16, 79, 80, B // 2, B - 17, B - 1}):
+        Xo, acts = O.decode(vae, z[b:b + 1], keep=True)
+        f, p_, dX = O.energy_and_grad(Xo[0], pose[b], mb, O.Weights(*W_ALL), cam, heat[starts[b]:starts[b] + 10])
+        dzo = O.decode_backward(vae, dX[None], acts)[0]
+        assert np.abs(X[b].cpu().numpy() - Xo[0]).max() <= 5e-5 * max(1.0, np.abs(Xo[0]).max()), b
+        assert abs(float(E[b]) - f) <= 2e-4 * abs(f) + 1e-7, b
+        assert np.abs(dz[b].cpu().numpy() - dzo).max() <= 2e-3 * np.abs(dzo).max() + 1e-8, b
+    # a whole stage: the rows in use shrink on the device while it runs
+    w = _ew((1e-1, 1e-1, 1.0, 1e-3, 1e-2))
+    out, stats = eng.optimize_stage(0, pose, mb, eps, w, heat, starts)
+    st = stats_to_numpy(stats)
+    assert (st["status"] == 1).all() and st["func_evals"].mean() > 20
+    for b in (B // 2, B - 1):
+        assert torch.equal(out[0], out[b]) and torch.equal(stats[0], stats[b]), b
+    assert np.isfinite(out.cpu().numpy()).all()
+
+
 def test_mid_size_batch_runs_the_fused_tail_in_several_waves(torch_cuda):
     """300..1280 windows: more tail workgroups than CUs.  One evaluation against the same windows in a small batch, and a
     whole stage whose duplicated windows (first 40 = last 40, i.e. different workgroup waves) must agree bitwise."""
