@@ -332,7 +332,7 @@ def main():
             if n_k:
                 ach = fl_k / (ms_k * 1e-3) / 1e12
                 rec["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak2, "unit": "TFLOP/s", "frac": round(ach / peak2, 4),
-                                   "kernel": "decoder_input forward + backward-data (%s)" % ("gemm_f32_kernel" if mode == "f32" else "gemm_bf16a_kernel"),
+                                   "kernel": "decoder_input forward + backward-data (%s)" % ("glds::gemm_glds_kernel<true,1,...>" if mode == "f32" else "glds::gemm_glds_kernel<false,1,...>"),
                                    "launches": int(n_k), "avg_us": round(ms_k * 1e3 / n_k, 2), "flop_per_launch": fl_k / n_k,
                                    "traffic": None}
             configs2[mode] = rec
@@ -379,8 +379,9 @@ def main():
                         "frac": round(achieved / peak, 4), "traffic": traffic if a.precision == "f32" else None,
                         "traffic_source": "profiles/traffic_dominant_kernel.json (separate rocprofv3 --pmc passes of this "
                                           "command, committed; NOT measured in this run)" if traffic and a.precision == "f32" else None,
-                        "kernel": ("gemm_f32_kernel<1,EPI_BIAS,*,*,1>" if a.precision == "f32" else
-                                   "gemm_bf16a_kernel<1,*,128,128>" if a.precision == "bf16" else "gemm_bf16_kernel<1,*,3>")
+                        "kernel": (("rows::gemm_rows_kernel<4,5> / <3,8>" if 48 <= B <= 256 else "gemm_f32_kernel<1,EPI_BIAS,*,*,1> / glds::gemm_glds_kernel<true,1,...>")
+                                   if a.precision == "f32" else
+                                   "glds::gemm_glds_kernel<false,1,*,128,128>" if a.precision == "bf16" else "gemm_bf16_kernel<1,*,3>")
                                   + " (decoder_input forward + backward-data)",
                         "launches": int(n), "avg_us": round(ms * 1e3 / n, 2),
                         "flop_per_launch": fl / n}

@@ -304,7 +304,9 @@ inline Plan plan(int M, int N, int K, int rt_max, int n_cu, bool allow_split, si
             if (sk > 1 && (nk / sk < 4 || (size_t)sk * M * ldc > slab_capacity_elems)) break;
             const int per = (nk + sk - 1) / sk;
             const double slab_units = sk > 1 ? sk * ((double)M * N * 8.0 / 3.0e12) / 0.214e-6 : 0.0;
-            const double cost = (double)rpb * per + slab_units;
+            // a K-step costs its MFMAs (rpb units) plus ~0.7 units of per-step overhead (measured: 40 steps of 4 row tiles
+            // take 95.8 k cycles, 20 steps of 8 take 88.8 k: tools/gemm_rows_bench)
+            const double cost = ((double)rpb + 0.7) * per + slab_units;
             if (cost < best_cost) { best_cost = cost; best = Plan{n_rb, sk, per, (double)R * n_ct * nk / ((double)n_cu * rpb * per)}; }
         }
     }
