@@ -410,7 +410,7 @@ static int launch_rows(gem_handle* h, const Layer& L, const float* A, int lda, c
     if (slabs && only && only[0] == 'f') return -1;
     rows::Plan p5 = rows::plan(M, L.N, L.K, 5, h->n_cu, slabs, h->ws.splitk_elems, ldc);
     rows::Plan p8 = rows::plan(M, L.N, L.K, 8, h->n_cu, slabs, h->ws.splitk_elems, ldc);
-    const bool use8 = p8.n_rb > 0 && (p5.n_rb == 0 || p8.fill > p5.fill + 1e-9);
+    const bool use8 = p8.n_rb > 0 && (p5.n_rb == 0 || p8.cost < p5.cost - 1e-9);          // ties: the smaller ring
     const rows::Plan& p = use8 ? p8 : p5;
     if (p.n_rb == 0 || p.fill < 0.75) return -1;
     const bool direct = p.n_split == 1;

@@ -290,9 +290,9 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const Args a) {
 
 // How a launch is cut: row blocks (fixed for the launch) and K slices.  Cost in units of one K-step of one row tile;
 // a slab costs its write plus the consumer's read.
-struct Plan { int n_rb, n_split, per; double fill; };
+struct Plan { int n_rb, n_split, per; double fill, cost; };
 inline Plan plan(int M, int N, int K, int rt_max, int n_cu, bool allow_split, size_t slab_capacity_elems, int ldc) {
-    Plan best{0, 0, 0, 0.0};
+    Plan best{0, 0, 0, 0.0, 1e30};
     if (N % BN != 0 || K % BK != 0 || M <= 0) return best;
     const int R = (M + 15) / 16, n_ct = N / BN, nk = K / BK;
     double best_cost = 1e30;
@@ -307,7 +307,7 @@ inline Plan plan(int M, int N, int K, int rt_max, int n_cu, bool allow_split, si
             // a K-step costs its MFMAs (rpb units) plus ~0.7 units of per-step overhead (measured: 40 steps of 4 row tiles
             // take 95.8 k cycles, 20 steps of 8 take 88.8 k: tools/gemm_rows_bench)
             const double cost = ((double)rpb + 0.7) * per + slab_units;
-            if (cost < best_cost) { best_cost = cost; best = Plan{n_rb, sk, per, (double)R * n_ct * nk / ((double)n_cu * rpb * per)}; }
+            if (cost < best_cost) { best_cost = cost; best = Plan{n_rb, sk, per, (double)R * n_ct * nk / ((double)n_cu * rpb * per), cost}; }
         }
     }
     return best;

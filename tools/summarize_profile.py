@@ -52,10 +52,11 @@ def traffic(sub, dominant_substr, out_name, note_cmd):
         out["kernels"][k] = {"dispatches": fe[1], "fetch_kib_raw": round(fe[0], 1), "read_bytes_corrected": round(2 * fe[0] * 1024),
                              "write_bytes": round(wr[0] * 1024)}
     dom = [k for k in out["kernels"] if dominant_substr in k]
-    if dom:
-        d = out["kernels"][dom[0]]
-        out["dominant_kernel"] = dom[0]
-        out["hbm_bytes_per_launch"] = d["read_bytes_corrected"] + d["write_bytes"]
+    if dom:       # (forward and backward-data may be two instantiations: dispatch-weighted mean per launch)
+        n = sum(out["kernels"][k]["dispatches"] for k in dom)
+        out["dominant_kernel"] = " + ".join(dom)
+        out["hbm_bytes_per_launch"] = round(sum((out["kernels"][k]["read_bytes_corrected"] + out["kernels"][k]["write_bytes"]) *
+                                                out["kernels"][k]["dispatches"] for k in dom) / max(n, 1))
     json.dump(out, open(os.path.join(dst, out_name), "w"), indent=1)
     return out
 
@@ -64,7 +65,7 @@ kernel_stats("f32", "kernel_stats_%s.csv" % tag)
 kernel_stats("f32_1536", "kernel_stats_%s_f32_1536_windows.csv" % tag)
 kernel_stats("bf16_1536", "kernel_stats_%s_bf16_1536_windows.csv" % tag)
 kernel_stats("bf16_8192", "kernel_stats_%s_bf16_8196_windows.csv" % tag)
-o = traffic("f32", "gemm_f32_kernel<1, 0, 1, 1, 1", "traffic_%s.json" % tag,
+o = traffic("f32", "rows::gemm_rows_kernel", "traffic_%s.json" % tag,
             "python bench.py --steps 2 --warmup 1 --cpu-windows 0 --no-extra --no-profile")
 if o and "dominant_kernel" in o:
     json.dump({k: o.get(k) for k in ("note", "dominant_kernel", "hbm_bytes_per_launch")}, open(os.path.join(dst, "traffic_dominant_kernel.json"), "w"), indent=1)
