@@ -108,15 +108,24 @@ class SequenceOptimizer:
         w_local = energy_weights(weight_3d / 10000, smoothness_weight / 100, bone_length_weight, vae_weight, reproj_weight)
         return w_local, w_global
 
-    def run(self, est_local, cams, heat, starts, chunk_of_window, chunk_bounds, w_local, w_global, eps=None, keep_device=False):
+    def run(self, est_local, cams, heat, starts, chunk_of_window, chunk_bounds, w_local, w_global, eps=None, keep_device=False, timings=None, while_device_runs=None):
         """est_local [F,15,3], cams [F,4,4], heat [F,H,W,15]; starts [B] first frame of each window;
         chunk_bounds [(f0, f1)] per chunk for the per-chunk mean bone length (optimizer.py:42-43).
         Returns (mid_local f32 [B,T,15,3], global f64 [B,T,15,3], stats); the two pose arrays stay torch device
-        tensors with keep_device=True (for the device post-processing)."""
+        tensors with keep_device=True (for the device post-processing).  `while_device_runs()` is called between the enqueue
+        and the blocking read-back of the statistics."""
         e = self.engine
         dev = e.device
         B = len(starts)
         n_frames = len(est_local)
+        import time
+        tick = [time.perf_counter()]
+
+        def lap(name):          # developer timing (tools/whole_sequence_timing.py)
+            if timings is not None:
+                now = time.perf_counter()
+                timings[name] = timings.get(name, 0.0) + (now - tick[0])
+                tick[0] = now
         if len(cams) != n_frames or len(heat) != n_frames:
             raise ValueError("est_local, cams and heat must cover the same frames (%d / %d / %d)" % (n_frames, len(cams), len(heat)))
         if B and (int(np.min(starts)) < 0 or int(np.max(starts)) + self.seq_len > n_frames):
@@ -126,15 +135,24 @@ class SequenceOptimizer:
         pose_d = torch.as_tensor(np.asarray(est_local), dtype=torch.float32).to(dev).contiguous()
         cams_d = torch.as_tensor(np.asarray(cams), dtype=torch.float64).to(dev).contiguous()
         heat_d = (heat if torch.is_tensor(heat) else torch.as_tensor(np.asarray(heat))).to(dev, dtype=torch.float32).contiguous()
+        lap("run: checks + upload of poses / cameras")
         mb = torch.stack([e.mean_bone_length(pose_d[a:b]) for a, b in chunk_bounds])
         mb_w = mb[torch.as_tensor(np.asarray(chunk_of_window), dtype=torch.long, device=dev)].contiguous()
+        lap("run: mean bone lengths")
         if eps is None:
             eps = torch.randn(2 * B, e.D)
         eps = torch.as_tensor(np.asarray(eps) if not torch.is_tensor(eps) else eps, dtype=torch.float32).reshape(B, 2, e.D)
-        eps_l, eps_g = eps[:, 0].contiguous().to(dev), eps[:, 1].contiguous().to(dev)
+        eps_d = eps.to(dev, non_blocking=True)                 # one copy (asynchronous from a pinned block), split on the device
+        eps_l, eps_g = eps_d[:, 0].contiguous(), eps_d[:, 1].contiguous()
         f0 = torch.as_tensor(np.asarray(starts), dtype=torch.int32).to(dev)
+        lap("run: noise upload")
         mid, glob, stats = e.optimize_windows(pose_d, cams_d, heat_d, f0, mb_w, eps_l, eps_g, w_local, w_global, self.opts)
+        lap("run: enqueue")
+        if while_device_runs is not None:          # host work that does not need the result (the caller's report preparation)
+            while_device_runs()
+            lap("run: caller's host work behind the device")
         st = stats_to_numpy(stats)
+        lap("run: wait for the device + stats")
         _raise_if_degenerate(st)
         if keep_device:
             return mid, glob, st

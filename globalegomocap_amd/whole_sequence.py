@@ -127,23 +127,28 @@ def _stage_to_device(fill, shape, device, dest=None):
     fresh tensor.  Returns (device tensor, event)."""
     tl = _reader_local
     if getattr(tl, "stream", None) is None or tl.device != device:
-        tl.stream, tl.device, tl.stage, tl.copied = torch.cuda.Stream(device=device), device, None, None
+        tl.stream, tl.device, tl.stage, tl.copied, tl.turn = torch.cuda.Stream(device=device), device, [None, None], [None, None], 0
     numel = int(np.prod(shape))
-    if tl.stage is None or tl.stage.numel() < numel:
-        tl.stage = torch.empty(max(numel, 1), dtype=torch.float32).pin_memory()
-    if tl.copied is not None:
-        tl.copied.synchronize()                        # the previous chunk's copy has left the staging buffer
-    view = tl.stage[:numel].view(shape).numpy()
+    # two staging buffers per reader: the next chunk is read from the page cache while the previous one is still on its way
+    # over PCIe (with one buffer the copy engine idles for a whole read, 2.4 ms per chunk and reader)
+    k = tl.turn
+    tl.turn ^= 1
+    if tl.stage[k] is None or tl.stage[k].numel() < numel:
+        tl.stage[k] = torch.empty(max(numel, 1), dtype=torch.float32).pin_memory()
+    if tl.copied[k] is not None:
+        tl.copied[k].synchronize()                     # the copy that last used this staging buffer has left it
+    stage = tl.stage[k]
+    view = stage[:numel].view(shape).numpy()
     if numel:
         fill(view)
     with torch.cuda.stream(tl.stream):
         if dest is not None and tuple(dest.shape) == tuple(shape):
-            t = dest.copy_(tl.stage[:numel].view(shape), non_blocking=True)
+            t = dest.copy_(stage[:numel].view(shape), non_blocking=True)
         else:
-            t = tl.stage[:numel].view(shape).to(device, non_blocking=True)
+            t = stage[:numel].view(shape).to(device, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(tl.stream)
-    tl.copied = ev
+    tl.copied[k] = ev
     return t, ev
 
 
@@ -227,16 +232,22 @@ class ChunkStream:
         self._dests = dests or {}          # path -> device slice the chunk's heat-maps are copied into
         self._pool = _reader_pool(workers)
 
+        self._pending, self._it = [], iter(self._paths)
+
+    def prime(self):
+        """Hand the first `depth` chunks to the readers now (otherwise that happens when the first chunk is asked for)."""
+        while len(self._pending) < self._depth:
+            p = next(self._it, None)
+            if p is None:
+                break
+            self._pending.append(self._pool.submit(load_chunk, p, self._device, self._sidecar, self._dests.get(p)))
+        return self
+
     def __iter__(self):
-        pending = []
-        it = iter(self._paths)
+        pending = self._pending
         try:
             while True:
-                while len(pending) < self._depth:
-                    p = next(it, None)
-                    if p is None:
-                        break
-                    pending.append(self._pool.submit(load_chunk, p, self._device, self._sidecar, self._dests.get(p)))
+                self.prime()
                 if not pending:
                     return
                 yield pending.pop(0).result()          # a reader's exception (e.g. KeyError) surfaces here
@@ -249,6 +260,43 @@ class ChunkStream:
                         f.result()
                     except Exception:
                         pass
+            del pending[:]
+
+
+_noise_pool = {}
+
+
+def _draw_noise(rows, D):
+    """One `torch.randn(rows[k], D)` per chunk from the global generator, in order (optimizer.py:261: `torch.randn_like` per
+    stage call; D5) -- drawn straight into consecutive slices of ONE pinned buffer that is kept between calls: a fresh 0.4 MB
+    tensor per chunk plus their concatenation cost more in first-touch page faults (5 ms per 240 windows) than in arithmetic,
+    and the pinned block goes to the device in one asynchronous copy.  Returns the per-chunk views."""
+    total = int(sum(rows))
+    key = (D, torch.get_default_dtype())
+    buf = _noise_pool.get(key)
+    if buf is None or buf.shape[0] < total:
+        buf = torch.empty(max(total, 1), D)
+        if torch.cuda.is_available():
+            buf = buf.pin_memory()
+        _noise_pool[key] = buf
+    out, r0 = [], 0
+    for r in rows:
+        v = buf[r0:r0 + r]
+        if r:
+            torch.randn(r, D, out=v)
+        out.append(v)
+        r0 += r
+    return out
+
+
+def _noise_block(views):
+    """The concatenation of `_draw_noise`'s views without copying (they are consecutive slices of one buffer)."""
+    if not views:
+        return torch.empty(0, 0)
+    total = sum(v.shape[0] for v in views)
+    base = views[0]
+    whole = base.as_strided((total, base.shape[1]), (base.shape[1], 1), base.storage_offset())
+    return whole
 
 
 def _batches(stream, chunks_per_batch):
@@ -317,9 +365,23 @@ def optimize_sequences(data_dirs, camera_model_path, vae_weight=0.0, gmm_weight=
             timings[name] = timings.get(name, 0.0) + (now - tick[0])
             tick[0] = now
     lap("plan")
-    for bi, batch in enumerate(_batches(ChunkStream(paths, depth=depth, device=device, sidecar=sidecar, dests=dests), chunks_per_batch)):
+    batch_iter = _batches(ChunkStream(paths, depth=depth, device=device, sidecar=sidecar, dests=dests).prime(), chunks_per_batch)
+    known = paths and all(f is not None for f in frames) and opt is not None
+    bi = -1
+    while True:
+        bi += 1
+        eps = []
+        if known:          # frame counts known up front: the noise is drawn while the readers work (same order, same generator: D5)
+            per_batch = chunks_per_batch or len(paths)
+            for n in frames[bi * per_batch:(bi + 1) * per_batch]:
+                eps.append(2 * len(window_starts(n, seq_len, overlap)))
+            eps = _draw_noise(eps, opt.engine.D)
+            lap("noise")
+        batch = next(batch_iter, None)
+        if batch is None:
+            break
         lap("wait_for_readers")
-        starts, chunk_of, bounds, f_off, eps = [], [], [], 0, []
+        starts, chunk_of, bounds, f_off = [], [], [], 0
         for ci, c in enumerate(batch):
             if verbose:
                 print("running data: {}".format(c["path"]))
@@ -335,36 +397,49 @@ def optimize_sequences(data_dirs, camera_model_path, vae_weight=0.0, gmm_weight=
         if n_win > opt.engine.max_windows:
             raise ValueError("%d windows in one batch exceed the engine's max_windows=%d: pass chunks_per_batch" %
                              (n_win, opt.engine.max_windows))
-        for c in batch:                          # global torch RNG, in the reference's order (D5)
-            eps.append(torch.randn(2 * len(c["starts"]), opt.engine.D))
-        lap("noise")
+        if not eps:
+            eps = _draw_noise([2 * len(c["starts"]) for c in batch], opt.engine.D)
+            lap("noise")
+        if [e_.shape[0] for e_ in eps] != [2 * len(c["starts"]) for c in batch]:
+            raise RuntimeError("chunk sizes changed between the cache headers and the data")
         w_local, w_global = opt.stage_weights(vae_weight, smoothness_weight, bone_length_weight, weight_3d, reproj_weight)
         for c in batch:
             torch.cuda.current_stream().wait_event(c["heat_ready"])
             c["heat"].record_stream(torch.cuda.current_stream())      # allocated on a reader's stream, consumed on this one
+        if timings is not None:                  # developer timing only: separates the PCIe tail from the optimiser's own time
+            torch.cuda.current_stream().synchronize()
+            lap("h2d tail (timing runs only: synchronised)")
         if batch_bufs and all(c["heat"].data_ptr() == dests[c["path"]].data_ptr() for c in batch):
             heat_d = batch_bufs[bi][0][:batch_bufs[bi][1]]          # the readers filled the batch's frame buffer in place
         else:
             heat_d = batch[0]["heat"] if len(batch) == 1 else torch.cat([c["heat"] for c in batch])
-        mid_local, opt_global, _ = opt.run(np.concatenate([c["est_local"] for c in batch]), np.concatenate([c["cams"] for c in batch]),
-                                           heat_d, np.concatenate(starts),
-                                           np.concatenate(chunk_of), bounds, w_local, w_global, eps=torch.cat(eps), keep_device=True)
-        lap("optimise (enqueue + device + read-back of the stats)")
-        mid_np = mid_local.cpu().numpy()
+        est_cat = np.concatenate([c["est_local"] for c in batch])
+        cams_cat = np.concatenate([c["cams"] for c in batch])
         counts = [len(c["starts"]) for c in batch]
-        if device_metrics and counts and min(counts) == max(counts) and counts[0] > 0:
+        equal = bool(device_metrics and counts and min(counts) == max(counts) and counts[0] > 0)
+        prep = {}
+
+        def prepare_reports():
             # equal chunks (the reference's 100-frame chunks): the sequences main() returns besides the optimised one are built
-            # for ALL windows of the batch at once, the overlap merges are vectorised over the chunks, the error reports of
-            # all chunks are enqueued back to back and read back with ONE synchronisation
-            e, nb, wpc = opt.engine, len(batch), counts[0]
-            est_cat = np.concatenate([c["est_local"] for c in batch])
-            cams_cat = np.concatenate([c["cams"] for c in batch])
+            # for ALL windows of the batch at once, the overlap merges vectorised over the chunks.  What does not depend on the
+            # optimiser's result is computed while the device works.
+            if not equal:
+                return
             gt_cat = np.concatenate([c["gt"] for c in batch])
             idx = np.concatenate(starts)[:, None] + np.arange(seq_len)[None]
-            loc_w, cam_w = est_cat[idx], cams_cat[idx]
-            est_m = merge_chunks(to_global_numpy(relative_global_numpy(loc_w, cam_w), cam_w), nb, overlap)
+            prep["cam_w"] = cams_cat[idx]
+            prep["est_m"] = merge_chunks(to_global_numpy(relative_global_numpy(est_cat[idx], prep["cam_w"]), prep["cam_w"]), len(batch), overlap)
+            prep["gt_m"] = merge_chunks(gt_cat[idx], len(batch), overlap)
+        mid_local, opt_global, _ = opt.run(est_cat, cams_cat, heat_d, np.concatenate(starts), np.concatenate(chunk_of), bounds, w_local,
+                                           w_global, eps=_noise_block(eps), keep_device=True, timings=timings,
+                                           while_device_runs=prepare_reports)
+        lap("optimise (enqueue + device + read-back of the stats)")
+        mid_np = mid_local.cpu().numpy()
+        if equal:
+            # ... the error reports of all chunks are enqueued back to back and read back with ONE synchronisation
+            e, nb, wpc = opt.engine, len(batch), counts[0]
+            cam_w, est_m, gt_m = prep["cam_w"], prep["est_m"], prep["gt_m"]
             mid_m = merge_chunks(to_global_numpy(relative_global_numpy(mid_np, cam_w), cam_w), nb, overlap)
-            gt_m = merge_chunks(gt_cat[idx], nb, overlap)
             fpc = est_m.shape[1]
             opt_d = e.merge_windows(opt_global, nb, overlap=overlap, smooth=bool(final_smooth))          # [nb*fpc,15,3] f64, device
             est_d, mid_d, gt_d = (torch.as_tensor(x.reshape(nb * fpc, 15, 3), device=device) for x in (est_m, mid_m, gt_m))
