@@ -501,10 +501,23 @@ static int optimize_stage_impl(gem_handle* h, int stage, int B, const float* d_p
     // closure values of this stage, one row per round (0xFF bytes = NaN: "window took no evaluation in this round")
     GEM_HIP(hipMemsetAsync(w.trace, 0xFF, (size_t)TRACE_ROUNDS * w.Bmax * sizeof(double), s));
     int rc = 0;
+    // The active windows are re-packed between the rounds: by compact_kernel, or -- one sequence in fp32 -- inside the
+    // decoder_input forward launch of the next round (gemm_rows.h; one launch and its boundary less per round).
+    StageNet& net_ = h->net[stage];
+    const bool fuse = w.dyn && net_.tail_start >= 0 && rows_can_fuse_compaction(h, net_.dec_in, h->Dp, net_.dec_in.N, B);
     for (int r = 0; r < rounds && !rc; ++r) {
         w.round = r;
-        rc = evaluate(h, stage, B, w.trial, ea, s) || launch_lbfgs_advance(h, B, opt, s);
-        if (!rc && w.dyn) rc = launch_compact(h, B, 0, s);
+        if (r > 0 && w.dyn) {
+            if (fuse) {
+                w.fuse_compact = true;
+                w.fuse_log = w.n_log + (w.log_pos % N_LOG);
+                w.cur_log = w.log_pos++;
+            } else {
+                rc = launch_compact(h, B, 0, s);
+            }
+        }
+        rc = rc || evaluate(h, stage, B, w.trial, ea, s) || launch_lbfgs_advance(h, B, opt, s);
+        if (w.fuse_compact) { set_error("optimize: the fused compaction was not picked up"); rc = 1; w.fuse_compact = false; }
     }
     w.round = -1;
     w.dyn = false;

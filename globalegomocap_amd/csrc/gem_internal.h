@@ -120,6 +120,9 @@ struct Workspace {
     bool dyn = false;                   // rounds in flight: GEMM / energy launches read their row count from n_active
     int* n_log = nullptr;               // [N_LOG] n_active after every compaction (profiling: true row counts)
     long log_pos = 0, cur_log = -1;
+    bool fuse_compact = false;          // next decoder_input forward launch re-packs the active windows itself (gemm_rows.h)
+    int* fuse_log = nullptr;            // ... and logs n_active here
+    int done_phase = 3;                 // lbfgs.hip PH_DONE
     std::vector<void*> allocs;
 };
 
@@ -248,6 +251,7 @@ __device__ inline void slab_layout(const SlabSrc& s, int& nslab, size_t& stride)
         stride = d.slab;
     }
 }
+bool rows_can_fuse_compaction(const gem_handle* h, const Layer& L, int lda, int ldc, int B);
 int launch_splitk_reduce(gem_handle* h, int epi, int nslab, size_t slab, const float* bias, const float* aux, float* C, int M, int N,
                          int ldc, const int* m_dev, hipStream_t s, int dyn_W = 0, int n_tiles = 0);
 // bf16-input MFMA variant of launch_gemm (gemm_bf16.hip): nprod = 1 (plain bf16) or 3 (hi/lo split, fp32-grade)

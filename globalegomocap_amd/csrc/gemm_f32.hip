@@ -377,42 +377,65 @@ static int launch_glds_f32(gem_handle* h, const Layer& L, const float* A, int ld
 // all active rows against one 64-column weight tile.  Forward (direct output, bias fused): no split-K, no slabs, no reduce
 // pass.  Backward (the consumer sums slabs anyway): as few K slices as fill the chip.  Used when the cut fills >= 3/4 of the
 // CUs' matrix time; otherwise (tiny batches, large batches) the tiled kernels below take over.
-template <int S, int RT>
+template <int S, int RT, bool FUSE>
 static int launch_rows_as(gem_handle* h, const Layer& L, const float* A, int lda, float* C, int ldc, int M, hipStream_t s,
                           const int* row_map, const rows::Plan& p, bool direct) {
-    auto k = rows::gemm_rows_kernel<S, RT>;
+    auto k = rows::gemm_rows_kernel<S, RT, FUSE>;
     static PerDeviceOnce once;
-    if (once.need(h->cfg.device))
-        GEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_PER_CU));
+    if (once.need(h->cfg.device))          // (the fused-compaction variant also has 2 KB of static LDS: ask for the ring only)
+        GEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    S * rows::Geometry<RT>::STAGE_BYTES));
+    Workspace& w = h->ws;
     rows::Args a{};
-    a.A = A; a.W = L.w; a.bias = direct ? L.bias : nullptr; a.C = direct ? C : h->ws.splitk;
-    a.m_dev = h->ws.dyn ? h->ws.n_active : nullptr;
+    a.A = A; a.W = L.w; a.bias = direct ? L.bias : nullptr; a.C = direct ? C : w.splitk;
+    a.m_dev = w.dyn ? w.n_active : nullptr;
     a.row_map = row_map;
     a.lda = lda; a.ldc = ldc; a.M = M; a.N = L.N; a.K = L.K;
     a.n_rb = p.n_rb; a.n_split = p.n_split; a.tiles_per_split = p.per; a.slab_stride = (size_t)M * ldc;
+    if (FUSE) {          // this launch also re-packs the windows that are still iterating (see rows::Args)
+        a.phase_arr = w.phase; a.n_windows = M; a.done_phase = w.done_phase; a.T = h->T;
+        a.perm_out = w.perm; a.slot_of_out = w.slot_of; a.n_active_out = w.n_active; a.log_slot = w.fuse_log;
+    }
     const int grid = p.n_rb * (L.N / rows::BN) * p.n_split;
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), (size_t)S * rows::Geometry<RT>::STAGE_BYTES, s, a);
     GEM_HIP(hipGetLastError());
     return 0;
 }
 
+// the cut for a linear layer with M rows, or false when this kernel is not the one for the shape
+static bool rows_plan(const gem_handle* h, const Layer& L, int lda, int ldc, int M, bool slabs, rows::Plan* out, bool* use8) {
+    static const bool off = getenv("GEM_NO_ROWS") != nullptr;                 // developer overrides (A/B runs)
+    static const char* only = getenv("GEM_ROWS_ONLY");                        // "fwd": direct-output launches only
+    if (off || M < 48 || L.N % rows::BN != 0 || L.K % rows::BK != 0 || (size_t)h->ws.Bmax * lda * 4 >= ((size_t)1 << 32) ||
+        (size_t)L.N * L.K * 4 >= ((size_t)1 << 32))
+        return false;
+    if (slabs && only && only[0] == 'f') return false;
+    const rows::Plan p5 = rows::plan(M, L.N, L.K, 5, h->n_cu, slabs, h->ws.splitk_elems, ldc);
+    const rows::Plan p8 = rows::plan(M, L.N, L.K, 8, h->n_cu, slabs, h->ws.splitk_elems, ldc);
+    *use8 = p8.n_rb > 0 && (p5.n_rb == 0 || p8.cost < p5.cost - 1e-9);          // ties: the smaller ring
+    *out = *use8 ? p8 : p5;
+    return out->n_rb != 0 && out->fill >= 0.75;
+}
+
+// Will the decoder_input forward product of a B-window round run in the few-rows kernel, so that it can re-pack the active
+// windows itself (no compact_kernel launch between the rounds)?
+bool rows_can_fuse_compaction(const gem_handle* h, const Layer& L, int lda, int ldc, int B) {
+    static const bool off = getenv("GEM_NO_FUSED_COMPACT") != nullptr;        // developer override (A/B runs)
+    rows::Plan p;
+    bool use8;
+    return !off && h->precision == GEM_PRECISION_F32 && B <= rows::FUSE_MAX_WINDOWS && rows_plan(h, L, lda, ldc, B, false, &p, &use8) &&
+           p.n_split == 1;
+}
+
 // returns -1 when the shape is not one for this kernel (the caller falls through to the tiled kernels)
 template <int EPI>
 static int launch_rows(gem_handle* h, const Layer& L, const float* A, int lda, const float* aux, float* C, int ldc, int M,
                        hipStream_t s, const int* row_map) {
-    static const bool off = getenv("GEM_NO_ROWS") != nullptr;                 // developer override (A/B runs)
-    static const char* only = getenv("GEM_ROWS_ONLY");                        // "fwd": direct-output launches only
-    if (off || M < 48 || L.N % rows::BN != 0 || L.K % rows::BK != 0 || (size_t)h->ws.Bmax * lda * 4 >= ((size_t)1 << 32) ||
-        (size_t)L.N * L.K * 4 >= ((size_t)1 << 32))
-        return -1;
     // direct output unless the consumer takes slabs (decoder_input backward: lbfgs_advance_kernel sums them)
     const bool slabs = h->ws.defer_reduce && h->ws.splitk;
-    if (slabs && only && only[0] == 'f') return -1;
-    rows::Plan p5 = rows::plan(M, L.N, L.K, 5, h->n_cu, slabs, h->ws.splitk_elems, ldc);
-    rows::Plan p8 = rows::plan(M, L.N, L.K, 8, h->n_cu, slabs, h->ws.splitk_elems, ldc);
-    const bool use8 = p8.n_rb > 0 && (p5.n_rb == 0 || p8.cost < p5.cost - 1e-9);          // ties: the smaller ring
-    const rows::Plan& p = use8 ? p8 : p5;
-    if (p.n_rb == 0 || p.fill < 0.75) return -1;
+    rows::Plan p;
+    bool use8;
+    if (!rows_plan(h, L, lda, ldc, M, slabs, &p, &use8)) return -1;
     const bool direct = p.n_split == 1;
     if (!direct) {
         SlabSrc& d = h->ws.deferred;
@@ -420,8 +443,14 @@ static int launch_rows(gem_handle* h, const Layer& L, const float* A, int lda, c
         d.dyn_W = 0; d.n_tiles = 0; d.ldc = ldc; d.CT = L.N / 64; d.m_dev = h->ws.dyn ? h->ws.n_active : nullptr;
     }
     (void)aux;
-    return use8 ? launch_rows_as<3, 8>(h, L, A, lda, C, ldc, M, s, row_map, p, direct)
-                : launch_rows_as<4, 5>(h, L, A, lda, C, ldc, M, s, row_map, p, direct);
+    if (h->ws.fuse_compact) {          // set by the round loop for the decoder_input forward launch only
+        h->ws.fuse_compact = false;
+        if (!direct || !row_map || M > rows::FUSE_MAX_WINDOWS) { set_error("launch_rows: fused compaction on a launch that cannot carry it"); return 1; }
+        return use8 ? launch_rows_as<3, 8, true>(h, L, A, lda, C, ldc, M, s, row_map, p, direct)
+                    : launch_rows_as<4, 5, true>(h, L, A, lda, C, ldc, M, s, row_map, p, direct);
+    }
+    return use8 ? launch_rows_as<3, 8, false>(h, L, A, lda, C, ldc, M, s, row_map, p, direct)
+                : launch_rows_as<4, 5, false>(h, L, A, lda, C, ldc, M, s, row_map, p, direct);
 }
 
 template <int TAPS, int EPI, int TAG>

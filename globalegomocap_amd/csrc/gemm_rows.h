@@ -51,6 +51,15 @@ struct Args {
     const int* m_dev;         // device row count (evaluation rounds) or nullptr
     const int* row_map;       // gathered A rows or nullptr
     int lda, ldc, M, N, K;
+    // fused compaction (FUSE): the stable partition of the windows -- still iterating first -- that compact_kernel
+    // (lbfgs.hip) otherwise computes in a launch of its own.  Every workgroup derives the row count and the row map from the
+    // per-window phase array; workgroup 0 also publishes them for the later kernels of the round.
+    const int* phase_arr;     // [n_windows] L-BFGS phase of every window
+    int n_windows, done_phase, T;
+    int* perm_out;            // [n_windows] slot -> window
+    int* slot_of_out;         // [n_windows] window -> slot
+    int* n_active_out;        // {n_active, n_active * T}
+    int* log_slot;            // profiling: n_active of this round
     int n_rb;                 // row blocks of the launch (fixed); the row tiles in use are re-dealt over them
     int n_split, tiles_per_split;
     size_t slab_stride;
@@ -72,7 +81,9 @@ struct Geometry {
 __device__ long long g_rows_clock[6];
 #endif
 
-template <int S, int RT>
+constexpr int FUSE_MAX_WINDOWS = 512;
+
+template <int S, int RT, bool FUSE = false>
 __global__ __launch_bounds__(256) void gemm_rows_kernel(const Args a) {
     typedef Geometry<RT> G;
     static_assert(S >= 3 && S * G::STAGE_BYTES <= 160 * 1024, "ring must fit the LDS");
@@ -124,7 +135,54 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const Args a) {
                                              (__attribute__((address_space(3))) void*)(lb + j * 1024), 16, 0, 0);
     }
 
-    const int M = a.m_dev ? *a.m_dev : a.M;
+    int M;
+    __shared__ int s_perm[FUSE ? FUSE_MAX_WINDOWS : 1];
+    __shared__ int s_wsum[4];
+    if (FUSE) {
+        // windows that are still iterating, in order, to the front (stable: a window's slot does not depend on the launch)
+        int base = 0;
+        for (int start = 0; start < a.n_windows; start += 256) {
+            const int b = start + tid;
+            const bool active = b < a.n_windows && a.phase_arr[b] != a.done_phase;
+            const unsigned long long m = __ballot(active);
+            const int prefix = __popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) s_wsum[wave] = __popcll(m);
+            __syncthreads();
+            int woff = 0, total = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { if (i < wave) woff += s_wsum[i]; total += s_wsum[i]; }
+            const int before = base + woff + prefix;           // active windows in front of b
+            if (active) s_perm[before] = b;
+            if (blockIdx.x == 0 && b < a.n_windows) {
+                // finished windows go behind the active ones, in order: slot = n_active + (finished windows in front of b);
+                // n_active is only known after the last chunk, so their slots are written in the second sweep below
+                if (active) { a.perm_out[before] = b; a.slot_of_out[b] = before; }
+            }
+            __syncthreads();
+            base += total;
+        }
+        M = base;
+        if (blockIdx.x == 0) {
+            int fin = 0;                                        // finished windows in front of the chunk
+            for (int start = 0; start < a.n_windows; start += 256) {
+                const int b = start + tid;
+                const bool done = b < a.n_windows && a.phase_arr[b] == a.done_phase;
+                const unsigned long long m = __ballot(done);
+                const int prefix = __popcll(m & ((1ull << lane) - 1ull));
+                __syncthreads();
+                if (lane == 0) s_wsum[wave] = __popcll(m);
+                __syncthreads();
+                int woff = 0, total = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { if (i < wave) woff += s_wsum[i]; total += s_wsum[i]; }
+                if (done) { const int sl = M + fin + woff + prefix; a.perm_out[sl] = b; a.slot_of_out[b] = sl; }
+                fin += total;
+            }
+            if (tid == 0) { a.n_active_out[0] = M; a.n_active_out[1] = M * a.T; *a.log_slot = M; }
+        }
+    } else {
+        M = a.m_dev ? *a.m_dev : a.M;
+    }
     const int R = (max(M, 0) + 15) >> 4;                       // row tiles in use this round
     const int rpb = (R + a.n_rb - 1) / a.n_rb;                 // ... per row block (<= RT by the launch's choice of n_rb)
     const int t0 = rb * rpb;
@@ -141,7 +199,8 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const Args a) {
     for (int j = 0; j < G::A_INSTR; ++j) {
         const int r = (wave * G::A_INSTR + j) * 4 + lrow;
         int src = min(m0 + r, M - 1);
-        if (a.row_map) src = a.row_map[src];
+        if (FUSE) src = s_perm[src];
+        else if (a.row_map) src = a.row_map[src];
         a_off[j] = (unsigned)src * (unsigned)a.lda * 4u + (unsigned)((lchunk ^ (r & 15)) * 16);
     }
     const unsigned char* a_base = reinterpret_cast<const unsigned char*>(a.A) + (size_t)kt_begin * ROW_BYTES;

@@ -24,6 +24,7 @@ namespace gem {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 enum { PH_INIT = 0, PH_BRACKET = 1, PH_ZOOM = 2, PH_DONE = 3 };
+static_assert(PH_DONE == 3, "Workspace::done_phase (gem_internal.h) names this value for the fused compaction of gemm_rows.h");
 
 struct AdvArgs {
     LbfgsState* state;
