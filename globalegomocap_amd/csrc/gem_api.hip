@@ -127,6 +127,61 @@ static int make_conv_layers(StageNet& net, const FoldedConv& f, Layer* fwd, Laye
     return 0;
 }
 
+// ---- decoder_input o conv 0 as ONE linear layer -----------------------------------------------------------------------------
+// h0 = Wd z + bd (decoder_input, rows (t', ci)) feeds ConvTranspose1d 0 + BatchNorm with NO activation in between
+// (SeqConvVAE.py:62, 67-75, 131-135), so
+//     pre0[(t, co)] = sum_tap sum_ci taps[tap][ci][co] h0[(t + tap - 1, ci)] + bc[co]      (frames outside the window: zero)
+//                   = (Wf z + bf)[(t, co)],   Wf[(t, co)][k] = sum_tap sum_ci taps[tap][ci][co] Wd[(t + tap - 1, ci)][k].
+// Wf is [T*C1p, Dp]: 2 x 2048 x 2560 FLOP per window instead of 2 x 2048 x 5120 + 2 x 3 x 512 x 256 x 10 (a third of the
+// matrix work of the two layers, half their weight bytes), one launch instead of two (three in the backward direction, where
+// its transpose replaces the conv adjoint, the split-K reduce behind it and the decoder_input backward product).  Built once
+// per gem_load_vae in fp64 from the fp64 folded conv taps and the fp32 decoder_input weights, rounded to fp32 once.
+__global__ __launch_bounds__(256) void compose_front_kernel(const double* __restrict__ taps /* [3][ci][co] */, const float* __restrict__ Wd /* [T*Cip][Dp] */,
+                                                            int T, int Ci, int Cip, int Co, int Cop, int Dp, float* __restrict__ Wf /* [T*Cop][Dp] */,
+                                                            float* __restrict__ WfT /* [Dp][T*Cop] */) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int n = blockIdx.y, t = n / Cop, co = n - t * Cop;
+    if (k >= Dp) return;
+    double acc = 0.0;
+    if (co < Co) {
+        for (int tap = 0; tap < 3; ++tap) {
+            const int ts = t + tap - 1;
+            if (ts < 0 || ts >= T) continue;
+            const double* tp = taps + (size_t)tap * Ci * Co + co;
+            const float* wd = Wd + (size_t)ts * Cip * Dp + k;
+            for (int ci = 0; ci < Ci; ++ci) acc += tp[(size_t)ci * Co] * (double)wd[(size_t)ci * Dp];
+        }
+    }
+    Wf[(size_t)n * Dp + k] = (float)acc;
+    WfT[(size_t)k * ((size_t)T * Cop) + n] = (float)acc;
+}
+
+static int compose_front(gem_handle* h, StageNet& net, const FoldedConv& f, const float* dec_in_bias_host /* time-major, padded */) {
+    const int T = h->T, Dp = h->Dp, Cip = h->topp, Cop = pad64(f.co), Nf = T * Cop;
+    double* d_taps = nullptr;
+    std::vector<void*> tmp;
+    if (upload(tmp, &d_taps, f.taps)) { free_all(tmp); return 1; }
+    float *Wf = nullptr, *WfT = nullptr;
+    if (dev_alloc(net.allocs, &Wf, (size_t)Nf * Dp) || dev_alloc(net.allocs, &WfT, (size_t)Dp * Nf)) { free_all(tmp); return 1; }
+    hipLaunchKernelGGL(compose_front_kernel, dim3((Dp + 255) / 256, Nf), dim3(256), 0, 0, d_taps, net.dec_in.w, T, f.ci, Cip, f.co, Cop, Dp, Wf, WfT);
+    if (!hip_ok(hipGetLastError(), "compose_front_kernel") || !hip_ok(hipDeviceSynchronize(), "compose_front_kernel")) { free_all(tmp); return 1; }
+    free_all(tmp);
+    std::vector<float> bf((size_t)Nf, 0.f), zb((size_t)Dp, 0.f);
+    for (int t = 0; t < T; ++t)
+        for (int co = 0; co < f.co; ++co) {
+            double acc = f.bias[co];
+            for (int tap = 0; tap < 3; ++tap) {
+                const int ts = t + tap - 1;
+                if (ts < 0 || ts >= T) continue;
+                for (int ci = 0; ci < f.ci; ++ci) acc += f.taps[((size_t)tap * f.ci + ci) * f.co + co] * (double)dec_in_bias_host[(size_t)ts * Cip + ci];
+            }
+            bf[(size_t)t * Cop + co] = (float)acc;
+        }
+    net.front.taps = 1; net.front.K = Dp; net.front.N = Nf; net.front.w = Wf;
+    net.front_bwd.taps = 1; net.front_bwd.K = Nf; net.front_bwd.N = Dp; net.front_bwd.w = WfT;
+    return upload(net.allocs, &net.front.bias, bf) || upload(net.allocs, &net.front_bwd.bias, zb);
+}
+
 }  // namespace gem
 
 using namespace gem;
@@ -293,6 +348,7 @@ int gem_load_vae(gem_handle* h, int stage, int n_blobs, const float* const* blob
       net.fc.taps = 1; net.fc.K = Kp; net.fc.N = 2 * Dp;
       if (upload(net.allocs, &net.fc.w, wv) || upload(net.allocs, &net.fc.bias, bv) || upload_bf16(net.allocs, &net.fc, wv)) return 1; }
     // ---- decoder_input: forward N = T*topp (n = t*topp + c), K = Dp; backward-data is the transpose
+    std::vector<float> dec_in_bias_tm;      // time-major, padded (for compose_front)
     { const int Np = T * h->topp;
       const float* W = blobs[bi]; const float* b = blobs[bi + 1];
       bi += 2;
@@ -312,11 +368,14 @@ int gem_load_vae(gem_handle* h, int stage, int n_blobs, const float* const* blob
       if (upload(net.allocs, &net.dec_in.w, wf) || upload(net.allocs, &net.dec_in.bias, bf) || upload_bf16(net.allocs, &net.dec_in, wf))
           return 1;
       if (upload(net.allocs, &net.dec_in_bwd.w, wb) || upload(net.allocs, &net.dec_in_bwd.bias, zb) ||
-          upload_bf16(net.allocs, &net.dec_in_bwd, wb)) return 1; }
+          upload_bf16(net.allocs, &net.dec_in_bwd, wb)) return 1;
+      dec_in_bias_tm = bf; }
     // ---- decoder convs
+    FoldedConv first_conv;
     auto add_dec = [&](int ci, int co, bool transposed, bool bn) -> int {
         FoldedConv f = fold_conv(blobs[bi], blobs[bi + 1], nullptr, bn ? blobs + bi + 2 : nullptr, ci, co, transposed);
         bi += bn ? 6 : 2;
+        if (net.dec.empty()) first_conv = f;
         Layer Lf, Lb;
         if (make_conv_layers(net, f, &Lf, &Lb)) return 1;
         net.dec.push_back(Lf);
@@ -337,6 +396,8 @@ int gem_load_vae(gem_handle* h, int stage, int n_blobs, const float* const* blob
             const size_t bytes = plan_tail(net.dec, st, T, h->J, nullptr);
             if (bytes && bytes <= 160 * 1024) { net.tail_start = st; net.tail_lds = bytes; break; }
         }
+    // decoder_input o conv 0 as one layer, when the tail takes over right behind conv 0 (GEM_NO_FRONT=1 keeps the two layers)
+    if (net.tail_start == 1 && !getenv("GEM_NO_FRONT") && compose_front(h, net, first_conv, dec_in_bias_tm.data())) return 1;
     net.loaded = true;
     return 0;
 }
@@ -441,22 +502,35 @@ static int evaluate(gem_handle* h, int stage, int B, const float* zp, const Ener
     }
     // wide layers as batched GEMMs, the narrow tail + energy + its adjoints in one kernel
     const int st = net.tail_start, rows = B * h->T;
-    if (launch_gemm(h, net.dec_in, EPI_BIAS, zp, h->Dp, nullptr, w.h0, net.dec_in.N, B, h->T, s, 0, w.dyn ? w.perm : nullptr)) return 1;
+    const bool front = net.front.w && st == 1 && h->precision == GEM_PRECISION_F32;
     const float* in = w.h0;
     SlabSrc in_slab;
-    for (int i = 0; i < st; ++i) {
-        // in the rounds the last wide conv leaves its split-K slabs to the tail kernel (sum + bias + LeakyReLU while staging)
-        w.defer_reduce = w.dyn && i == st - 1;
-        const int rc = launch_gemm(h, net.dec[i], EPI_BIAS_LRELU, in, net.dec[i].K, nullptr, w.dec_act[i], net.dec[i].N, rows, h->T, s, -1);
+    if (front) {
+        // decoder_input and conv 0 as ONE product (compose_front); in the rounds its split-K slabs (if any) go to the tail
+        w.defer_reduce = w.dyn;
+        const int rc = launch_gemm(h, net.front, EPI_BIAS_LRELU, zp, h->Dp, nullptr, w.dec_act[0], net.front.N, B, h->T, s, 0,
+                                   w.dyn ? w.perm : nullptr);
         if (w.defer_reduce) in_slab = w.deferred;
         w.defer_reduce = false;
         if (rc) return 1;
-        in = w.dec_act[i];
+        in = w.dec_act[0];
+    } else {
+        if (launch_gemm(h, net.dec_in, EPI_BIAS, zp, h->Dp, nullptr, w.h0, net.dec_in.N, B, h->T, s, 0, w.dyn ? w.perm : nullptr)) return 1;
+        for (int i = 0; i < st; ++i) {
+            // in the rounds the last wide conv leaves its split-K slabs to the tail kernel (sum + bias + LeakyReLU while staging)
+            w.defer_reduce = w.dyn && i == st - 1;
+            const int rc = launch_gemm(h, net.dec[i], EPI_BIAS_LRELU, in, net.dec[i].K, nullptr, w.dec_act[i], net.dec[i].N, rows, h->T, s, -1);
+            if (w.defer_reduce) in_slab = w.deferred;
+            w.defer_reduce = false;
+            if (rc) return 1;
+            in = w.dec_act[i];
+        }
     }
     TailArgs ta;
     plan_tail(net.dec, st, h->T, h->J, &ta);
     ta.B = B; ta.forward_only = forward_only ? 1 : 0; ta.dbg_ts = nullptr;
-    ta.in_slab = in_slab; ta.in_bias = st > 0 ? net.dec[st - 1].bias : nullptr;
+    ta.in_slab = in_slab; ta.in_bias = front ? net.front.bias : (st > 0 ? net.dec[st - 1].bias : nullptr);
+    ta.in_bias_ld = front ? net.dec[0].N : 0;
     for (int i = 0; i < ta.n; ++i) {
         const Layer& f = net.dec[st + i];
         const Layer& g = net.dec_bwd[st + i];
@@ -467,6 +541,15 @@ static int evaluate(gem_handle* h, int stage, int B, const float* zp, const Ener
     ta.e = ea;
     if (launch_tail(h, ta, net.tail_lds, s)) return 1;
     if (forward_only) return 0;
+    if (front) {
+        // dE/dz = Wf^T . (gradient w.r.t. the pre-activation of conv 0): replaces the conv adjoint, its reduce pass and the
+        // decoder_input backward product; in the rounds lbfgs_advance sums the slabs of this product itself (its bias is zero)
+        w.defer_reduce = w.dyn;
+        const int rc = launch_gemm(h, net.front_bwd, EPI_BIAS, w.dec_grad[st], net.front_bwd.K, nullptr, w.dz, h->Dp, B, h->T, s, 0);
+        w.grad_slab = w.defer_reduce ? w.deferred : SlabSrc{};
+        w.defer_reduce = false;
+        return rc;
+    }
     return decoder_backward(h, stage, B, s, st - 1, w.dec_grad[st]);
 }
 
@@ -504,7 +587,11 @@ static int optimize_stage_impl(gem_handle* h, int stage, int B, const float* d_p
     // The active windows are re-packed between the rounds: by compact_kernel, or -- one sequence in fp32 -- inside the
     // decoder_input forward launch of the next round (gemm_rows.h; one launch and its boundary less per round).
     StageNet& net_ = h->net[stage];
-    const bool fuse = w.dyn && net_.tail_start >= 0 && rows_can_fuse_compaction(h, net_.dec_in, h->Dp, net_.dec_in.N, B);
+    const bool front_ = net_.front.w && net_.tail_start == 1 && h->precision == GEM_PRECISION_F32;
+    const Layer& first_ = front_ ? net_.front : net_.dec_in;
+    const int tail_g_ = h->T <= 16 ? 16 / h->T : 1;
+    const bool tail_path_ = net_.tail_start >= 0 && (B + tail_g_ - 1) / tail_g_ <= 5 * h->n_cu;
+    const bool fuse = w.dyn && tail_path_ && rows_can_fuse_compaction(h, first_, h->Dp, first_.N, B, /*slabs=*/front_);
     for (int r = 0; r < rounds && !rc; ++r) {
         w.round = r;
         if (r > 0 && w.dyn) {

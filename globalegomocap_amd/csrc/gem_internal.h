@@ -46,6 +46,10 @@ struct StageNet {
     std::vector<Layer> dec;        // decoder convs, last one without activation
     Layer dec_in_bwd;              // backward-data twins (no bias)
     std::vector<Layer> dec_bwd;    // dec_bwd[i] is the adjoint of dec[i]
+    // decoder_input followed by the first decoder conv (no activation in between: SeqConvVAE.py:62,67-75,131-135) composed into
+    // ONE linear layer z -> pre-activation of conv 0, N = T * pad64(C1) (n = t * C1p + c), K = Dp, and its transpose
+    // (see compose_front in gem_api.hip).  Empty (w == nullptr) when the fused tail does not start at conv 1.
+    Layer front, front_bwd;
     int tail_start = -1;           // decoder convs [tail_start, end) run in the fused tail kernel (-1: none)
     size_t tail_lds = 0;
     std::vector<void*> allocs;
@@ -251,7 +255,7 @@ __device__ inline void slab_layout(const SlabSrc& s, int& nslab, size_t& stride)
         stride = d.slab;
     }
 }
-bool rows_can_fuse_compaction(const gem_handle* h, const Layer& L, int lda, int ldc, int B);
+bool rows_can_fuse_compaction(const gem_handle* h, const Layer& L, int lda, int ldc, int B, bool slabs);
 int launch_splitk_reduce(gem_handle* h, int epi, int nslab, size_t slab, const float* bias, const float* aux, float* C, int M, int N,
                          int ldc, const int* m_dev, hipStream_t s, int dyn_W = 0, int n_tiles = 0);
 // bf16-input MFMA variant of launch_gemm (gemm_bf16.hip): nprod = 1 (plain bf16) or 3 (hi/lo split, fp32-grade)
@@ -300,7 +304,8 @@ struct TailLayerDev { const float* w4; const float* bias; int K, N; };
 struct TailArgs {
     int n, B, G, forward_only, escr, mask_first;
     SlabSrc in_slab;         // a_in still lies in split-K slabs (+ in_bias, LeakyReLU to apply) when in_slab.base != nullptr
-    const float* in_bias;
+    const float* in_bias;    // bias of row r, column c: in_bias[(r % T) * in_bias_ld + c]
+    int in_bias_ld;          // 0: one bias per channel (a conv produced a_in); K0: per (frame, channel) (the composed front layer)
     long long* dbg_ts;       // developer probe (tools/tail_bench): [32] {shader clock, 100 MHz wall clock} pairs of workgroup 0, or nullptr
     TailLayerDev fwd[TAIL_MAX_LAYERS], bwd[TAIL_MAX_LAYERS];
     const float* a_in;       // [B*T, K0] input activation of the first fused layer

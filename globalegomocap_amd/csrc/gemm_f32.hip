@@ -379,7 +379,7 @@ static int launch_glds_f32(gem_handle* h, const Layer& L, const float* A, int ld
 // CUs' matrix time; otherwise (tiny batches, large batches) the tiled kernels below take over.
 template <int S, int RT, bool FUSE>
 static int launch_rows_as(gem_handle* h, const Layer& L, const float* A, int lda, float* C, int ldc, int M, hipStream_t s,
-                          const int* row_map, const rows::Plan& p, bool direct) {
+                          const int* row_map, const rows::Plan& p, bool direct, bool with_bias, bool lrelu) {
     auto k = rows::gemm_rows_kernel<S, RT, FUSE>;
     static PerDeviceOnce once;
     if (once.need(h->cfg.device))          // (the fused-compaction variant also has 2 KB of static LDS: ask for the ring only)
@@ -387,7 +387,7 @@ static int launch_rows_as(gem_handle* h, const Layer& L, const float* A, int lda
                                     S * rows::Geometry<RT>::STAGE_BYTES));
     Workspace& w = h->ws;
     rows::Args a{};
-    a.A = A; a.W = L.w; a.bias = direct ? L.bias : nullptr; a.C = direct ? C : w.splitk;
+    a.A = A; a.W = L.w; a.bias = direct && with_bias ? L.bias : nullptr; a.lrelu = lrelu ? 1 : 0; a.C = direct ? C : w.splitk;
     a.m_dev = w.dyn ? w.n_active : nullptr;
     a.row_map = row_map;
     a.lda = lda; a.ldc = ldc; a.M = M; a.N = L.N; a.K = L.K;
@@ -419,12 +419,12 @@ static bool rows_plan(const gem_handle* h, const Layer& L, int lda, int ldc, int
 
 // Will the decoder_input forward product of a B-window round run in the few-rows kernel, so that it can re-pack the active
 // windows itself (no compact_kernel launch between the rounds)?
-bool rows_can_fuse_compaction(const gem_handle* h, const Layer& L, int lda, int ldc, int B) {
+bool rows_can_fuse_compaction(const gem_handle* h, const Layer& L, int lda, int ldc, int B, bool slabs) {
     static const bool off = getenv("GEM_NO_FUSED_COMPACT") != nullptr;        // developer override (A/B runs)
     rows::Plan p;
     bool use8;
-    return !off && h->precision == GEM_PRECISION_F32 && B <= rows::FUSE_MAX_WINDOWS && rows_plan(h, L, lda, ldc, B, false, &p, &use8) &&
-           p.n_split == 1;
+    return !off && h->precision == GEM_PRECISION_F32 && B <= rows::FUSE_MAX_WINDOWS &&
+           rows_plan(h, L, lda, ldc, B, slabs && h->ws.splitk, &p, &use8);
 }
 
 // returns -1 when the shape is not one for this kernel (the caller falls through to the tiled kernels)
@@ -443,20 +443,21 @@ static int launch_rows(gem_handle* h, const Layer& L, const float* A, int lda, c
         d.dyn_W = 0; d.n_tiles = 0; d.ldc = ldc; d.CT = L.N / 64; d.m_dev = h->ws.dyn ? h->ws.n_active : nullptr;
     }
     (void)aux;
-    if (h->ws.fuse_compact) {          // set by the round loop for the decoder_input forward launch only
+    constexpr bool with_bias = EPI != EPI_NONE, lrelu = EPI == EPI_BIAS_LRELU;
+    if (h->ws.fuse_compact) {          // set by the round loop for the first launch of a round only
         h->ws.fuse_compact = false;
-        if (!direct || !row_map || M > rows::FUSE_MAX_WINDOWS) { set_error("launch_rows: fused compaction on a launch that cannot carry it"); return 1; }
-        return use8 ? launch_rows_as<3, 8, true>(h, L, A, lda, C, ldc, M, s, row_map, p, direct)
-                    : launch_rows_as<4, 5, true>(h, L, A, lda, C, ldc, M, s, row_map, p, direct);
+        if (!row_map || M > rows::FUSE_MAX_WINDOWS) { set_error("launch_rows: fused compaction on a launch that cannot carry it"); return 1; }
+        return use8 ? launch_rows_as<3, 8, true>(h, L, A, lda, C, ldc, M, s, row_map, p, direct, with_bias, lrelu)
+                    : launch_rows_as<4, 5, true>(h, L, A, lda, C, ldc, M, s, row_map, p, direct, with_bias, lrelu);
     }
-    return use8 ? launch_rows_as<3, 8, false>(h, L, A, lda, C, ldc, M, s, row_map, p, direct)
-                : launch_rows_as<4, 5, false>(h, L, A, lda, C, ldc, M, s, row_map, p, direct);
+    return use8 ? launch_rows_as<3, 8, false>(h, L, A, lda, C, ldc, M, s, row_map, p, direct, with_bias, lrelu)
+                : launch_rows_as<4, 5, false>(h, L, A, lda, C, ldc, M, s, row_map, p, direct, with_bias, lrelu);
 }
 
 template <int TAPS, int EPI, int TAG>
 static int launch_tile(gem_handle* h, const Layer& L, const float* A, int lda, const float* aux, float* C, int ldc, int M, int T,
                        hipStream_t s, const int* row_map) {
-    if (TAPS == 1 && (EPI == EPI_BIAS || EPI == EPI_NONE)) {
+    if (TAPS == 1 && (EPI == EPI_BIAS || EPI == EPI_NONE || EPI == EPI_BIAS_LRELU)) {
         const int rc = launch_rows<EPI>(h, L, A, lda, aux, C, ldc, M, s, row_map);
         if (rc >= 0) return rc;
     }
@@ -505,6 +506,7 @@ int launch_gemm(gem_handle* h, const Layer& L, int epi, const float* A, int lda,
         if (family == 0 && epi == EPI_BIAS) rc = launch_tile<1, EPI_BIAS, 1>(h, L, A, lda, aux, C, ldc, M, T, s, row_map);
         else if (epi == EPI_BIAS) rc = launch_tile<1, EPI_BIAS, 0>(h, L, A, lda, aux, C, ldc, M, T, s, row_map);
         else if (epi == EPI_NONE) rc = launch_tile<1, EPI_NONE, 0>(h, L, A, lda, aux, C, ldc, M, T, s, row_map);
+        else if (epi == EPI_BIAS_LRELU) rc = launch_tile<1, EPI_BIAS_LRELU, 1>(h, L, A, lda, aux, C, ldc, M, T, s, row_map);
         else set_error("launch_gemm: unsupported epilogue for a linear layer");
     } else if (L.taps == 3) {
         if (epi == EPI_BIAS) rc = launch_tile<3, EPI_BIAS, 0>(h, L, A, lda, aux, C, ldc, M, T, s, row_map);

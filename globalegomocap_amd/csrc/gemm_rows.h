@@ -47,6 +47,7 @@ struct Args {
     const float* A;           // [rows, lda]
     const float* W;           // [N][K], k contiguous
     const float* bias;        // [N] (direct output only) or nullptr
+    int lrelu;                // direct output only: LeakyReLU(0.01) after the bias
     float* C;                 // [M, ldc]; split-K: raw fp32 slabs, slab z at C + z * slab_stride
     const int* m_dev;         // device row count (evaluation rounds) or nullptr
     const int* row_map;       // gathered A rows or nullptr
@@ -329,7 +330,14 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const Args a) {
 #pragma unroll
             for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4*>(smem + ((w * 4 + wave) * NRT + j) * 1024 + lane * 16);
             const int row = m0 + j * 16 + fr;
-            if (row < M) *reinterpret_cast<f32x4*>(Cb + (size_t)row * a.ldc + col + 16 * wave) = v + bv;
+            if (row < M) {
+                v += bv;
+                if (a.lrelu && a.n_split == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * 0.01f;
+                }
+                *reinterpret_cast<f32x4*>(Cb + (size_t)row * a.ldc + col + 16 * wave) = v;
+            }
         }
 #ifdef GEM_ROWS_CLOCK
         if (blockIdx.x == 8 && tid == 0) g_rows_clock[3] = wall_clock64() - w1;

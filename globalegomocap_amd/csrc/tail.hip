@@ -201,7 +201,7 @@ __global__ __launch_bounds__(TAIL_THREADS, 2) void decoder_tail_kernel(TailArgs 
                         for (int k = 0; k < 8; ++k)
                             if (z0 + k < nslab) v += t[k];
                     }
-                    v += *reinterpret_cast<const f32x4*>(a.in_bias + c);
+                    v += *reinterpret_cast<const f32x4*>(a.in_bias + (r % T) * a.in_bias_ld + c);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : v[q] * LEAKY_SLOPE;
                 }
