@@ -119,6 +119,7 @@ static int gemm_bf16a(gem_handle* h, const Layer& L, int epi, const uint16_t* A,
     if (L.taps == 1) {
         if (epi == EPI_BIAS) rc = launch_bn<1, EPI_BIAS>(h, a, grid, bn128, kernel_bf16, s);
         else if (epi == EPI_NONE) rc = launch_bn<1, EPI_NONE>(h, a, grid, bn128, kernel_bf16, s);
+        else if (epi == EPI_BIAS_LRELU) rc = launch_bn<1, EPI_BIAS_LRELU>(h, a, grid, bn128, kernel_bf16, s);
         else set_error("gemm_bf16a: unsupported epilogue for a linear layer");
     } else if (L.taps == 3) {
         if (epi == EPI_BIAS) rc = launch_bn<3, EPI_BIAS>(h, a, grid, bn128, kernel_bf16, s);
@@ -161,16 +162,24 @@ int evaluate_bf16(gem_handle* h, int stage, int B, const EnergyArgs& ea_in, hipS
     const bool use_tail = net.tail_start >= 1 && (tail_wgs <= 5 * h->n_cu || force_tail);
     const int* perm = w.dyn ? w.perm : nullptr;
     w.grad_slab = SlabSrc{};
+    // decoder_input o conv 0 as ONE product where the weights were composed (compose_front in gem_api.hip), else
     // decoder_input: [B, Dp] x [Dp, T*topp] -> h0 [B*T, topp] bf16 (rows of finished windows are skipped through perm)
-    if (gemm_bf16a(h, net.dec_in, EPI_BIAS, w.trial_b, h->Dp, nullptr, w.h0_b, true, net.dec_in.N, B, s, 0, perm, true, false)) return 1;
+    static const bool no_front = getenv("GEM_NO_FRONT_BF16") != nullptr;          // developer override (A/B runs)
+    const bool front = net.front.wb_hi && n_dec > 1 && !no_front && (!use_tail || net.tail_start == 1);
     const uint16_t* in = w.h0_b;
     EnergyArgs ea = ea_in;
     int back_from;                     // first layer of the batched backward chain
     const uint16_t* gin;
+    if (!front && gemm_bf16a(h, net.dec_in, EPI_BIAS, w.trial_b, h->Dp, nullptr, w.h0_b, true, net.dec_in.N, B, s, 0, perm, true, false)) return 1;
     if (use_tail) {
         const int st = net.tail_start;
         SlabSrc in_slab;
-        for (int i = 0; i < st; ++i) {
+        if (front) {                   // feeds the fp32 tail: fp32 slabs in the rounds, a finished fp32 matrix otherwise
+            if (gemm_bf16a(h, net.front, EPI_BIAS_LRELU, w.trial_b, h->Dp, nullptr, w.dec_act[0], false, net.front.N, B, s, 0, perm, true, w.dyn))
+                return 1;
+            in_slab = w.deferred;
+        }
+        for (int i = 0; i < st && !front; ++i) {
             const bool last_wide = i == st - 1;
             if (last_wide) {           // feeds the fp32 tail: fp32 slabs in the rounds, a finished fp32 matrix otherwise
                 if (gemm_bf16a(h, net.dec[i], EPI_BIAS_LRELU, in, net.dec[i].K, nullptr, w.dec_act[i], false, net.dec[i].N, rows, s, -1,
@@ -185,7 +194,8 @@ int evaluate_bf16(gem_handle* h, int stage, int B, const EnergyArgs& ea_in, hipS
         TailArgs ta;
         plan_tail(net.dec, st, T, h->J, &ta);
         ta.B = B; ta.forward_only = forward_only ? 1 : 0; ta.dbg_ts = nullptr;
-        ta.in_slab = in_slab; ta.in_bias = net.dec[st - 1].bias;
+        ta.in_slab = in_slab; ta.in_bias = front ? net.front.bias : net.dec[st - 1].bias;
+        ta.in_bias_ld = front ? net.dec[0].N : 0;
         for (int i = 0; i < ta.n; ++i) {
             const Layer& f = net.dec[st + i];
             const Layer& g = net.dec_bwd[st + i];
@@ -200,7 +210,12 @@ int evaluate_bf16(gem_handle* h, int stage, int B, const EnergyArgs& ea_in, hipS
         back_from = st - 1;
         gin = w.dec_grad_b[st];
     } else {
-        for (int i = 0; i < n_dec; ++i) {
+        if (front) {
+            if (gemm_bf16a(h, net.front, EPI_BIAS_LRELU, w.trial_b, h->Dp, nullptr, w.dec_act_b[0], true, net.front.N, B, s, 0, perm, true, false))
+                return 1;
+            in = w.dec_act_b[0];
+        }
+        for (int i = front ? 1 : 0; i < n_dec; ++i) {
             const bool last = i + 1 == n_dec;
             if (last) {                // the pose itself: fp32
                 if (gemm_bf16a(h, net.dec[i], EPI_BIAS, in, net.dec[i].K, nullptr, w.dec_act[i], false, net.dec[i].N, rows, s, -1, nullptr,
@@ -219,14 +234,15 @@ int evaluate_bf16(gem_handle* h, int stage, int B, const EnergyArgs& ea_in, hipS
         gin = w.dXp_b;
     }
     // backward-data through the batched layers: gradient w.r.t. the input of conv i, masked by LeakyReLU' of that input
-    for (int i = back_from; i >= 0; --i) {
+    for (int i = back_from; i >= (front ? 1 : 0); --i) {
         const Layer& L = net.dec_bwd[i];
         if (gemm_bf16a(h, L, i > 0 ? EPI_MASK : EPI_NONE, gin, L.K, i > 0 ? w.dec_act_b[i - 1] : nullptr, w.dec_grad_b[i], true, L.N, rows, s,
                        -1, nullptr, i == 0, false)) return 1;
         gin = w.dec_grad_b[i];
     }
     // decoder_input^T: dE/dz fp32; in the rounds lbfgs_advance sums the slabs itself
-    if (gemm_bf16a(h, net.dec_in_bwd, EPI_NONE, gin, net.dec_in_bwd.K, nullptr, w.dz, false, h->Dp, B, s, 0, nullptr, true, w.dyn)) return 1;
+    const Layer& last_l = front ? net.front_bwd : net.dec_in_bwd;         // front: gin is the gradient w.r.t. conv 0's pre-activation
+    if (gemm_bf16a(h, last_l, EPI_NONE, gin, last_l.K, nullptr, w.dz, false, h->Dp, B, s, 0, nullptr, true, w.dyn)) return 1;
     w.grad_slab = w.deferred;
     return 0;
 }

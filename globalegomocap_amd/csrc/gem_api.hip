@@ -179,6 +179,11 @@ static int compose_front(gem_handle* h, StageNet& net, const FoldedConv& f, cons
         }
     net.front.taps = 1; net.front.K = Dp; net.front.N = Nf; net.front.w = Wf;
     net.front_bwd.taps = 1; net.front_bwd.K = Nf; net.front_bwd.N = Dp; net.front_bwd.w = WfT;
+    // bf16 images for the bf16 decoder mode (rounded once from the fp64-composed weights)
+    if (dev_alloc(net.allocs, &net.front.wb_hi, (size_t)Nf * Dp) || dev_alloc(net.allocs, &net.front_bwd.wb_hi, (size_t)Dp * Nf) ||
+        launch_f32_to_bf16(Wf, net.front.wb_hi, (size_t)Nf * Dp, nullptr) || launch_f32_to_bf16(WfT, net.front_bwd.wb_hi, (size_t)Dp * Nf, nullptr))
+        return 1;
+    GEM_HIP(hipDeviceSynchronize());
     return upload(net.allocs, &net.front.bias, bf) || upload(net.allocs, &net.front_bwd.bias, zb);
 }
 
@@ -434,9 +439,15 @@ static int decoder_forward(gem_handle* h, int stage, int B, const float* zp, hip
     StageNet& net = h->net[stage];
     Workspace& w = h->ws;
     const int rows = B * h->T;
-    if (launch_gemm(h, net.dec_in, EPI_BIAS, zp, h->Dp, nullptr, w.h0, net.dec_in.N, B, h->T, s, 0, w.dyn ? w.perm : nullptr)) return 1;
+    const bool front = net.front.w && net.dec.size() > 1 && h->precision == GEM_PRECISION_F32;
     const float* in = w.h0;
-    for (size_t i = 0; i < net.dec.size(); ++i) {
+    if (front) {          // decoder_input o conv 0 as one product (compose_front)
+        if (launch_gemm(h, net.front, EPI_BIAS_LRELU, zp, h->Dp, nullptr, w.dec_act[0], net.front.N, B, h->T, s, 0, w.dyn ? w.perm : nullptr)) return 1;
+        in = w.dec_act[0];
+    } else if (launch_gemm(h, net.dec_in, EPI_BIAS, zp, h->Dp, nullptr, w.h0, net.dec_in.N, B, h->T, s, 0, w.dyn ? w.perm : nullptr)) {
+        return 1;
+    }
+    for (size_t i = front ? 1 : 0; i < net.dec.size(); ++i) {
         const int epi = (i + 1 < net.dec.size()) ? EPI_BIAS_LRELU : EPI_BIAS;
         if (launch_gemm(h, net.dec[i], epi, in, net.dec[i].K, nullptr, w.dec_act[i], net.dec[i].N, rows, h->T, s, -1)) return 1;
         in = w.dec_act[i];
@@ -449,7 +460,8 @@ static int decoder_backward(gem_handle* h, int stage, int B, hipStream_t s, int 
     StageNet& net = h->net[stage];
     Workspace& w = h->ws;
     const int rows = B * h->T;
-    for (int i = from; i >= 0; --i) {
+    const bool front = net.front.w && net.dec.size() > 1 && h->precision == GEM_PRECISION_F32 && from >= 1;
+    for (int i = from; i >= (front ? 1 : 0); --i) {
         const Layer& L = net.dec_bwd[i];
         const float* aux = i > 0 ? w.dec_act[i - 1] : nullptr;      // LeakyReLU' from the sign of the stored activation
         if (launch_gemm(h, L, i > 0 ? EPI_MASK : EPI_NONE, gin, L.K, aux, w.dec_grad[i], L.N, rows, h->T, s, -1)) return 1;
@@ -457,7 +469,8 @@ static int decoder_backward(gem_handle* h, int stage, int B, hipStream_t s, int 
     }
     // in the rounds lbfgs_advance sums the slabs of this product itself (its bias is zero)
     w.defer_reduce = w.dyn;
-    const int rc = launch_gemm(h, net.dec_in_bwd, EPI_BIAS, gin, net.dec_in_bwd.K, nullptr, w.dz, h->Dp, B, h->T, s, 0);
+    const Layer& last = front ? net.front_bwd : net.dec_in_bwd;          // front: gin is the gradient w.r.t. conv 0's pre-activation
+    const int rc = launch_gemm(h, last, EPI_BIAS, gin, last.K, nullptr, w.dz, h->Dp, B, h->T, s, 0);
     w.grad_slab = w.defer_reduce ? w.deferred : SlabSrc{};
     w.defer_reduce = false;
     return rc;
