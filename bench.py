@@ -363,28 +363,49 @@ def main():
         other_modes = {m: {"windows_per_s": round(B * world * a.steps / dt, 2), "ms_per_step": round(dt / a.steps * 1e3, 3),
                            "mpjpe_optimised_mm": round(seq_mpjpe(gl) * 1e3, 3)} for m, (dt, gl) in other.items()}
         roof = None
-        traffic = None
+        traffic = traffic_kernel = None
         tpath = os.path.join(ROOT, "profiles", "traffic_dominant_kernel.json")
         if os.path.exists(tpath) and a.workload == "seq2k":
             # HBM bytes per launch of the dominant kernel from separate rocprofv3 --pmc passes of this same
             # command (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, MI355X_MICROARCH.md section HBM); see profiles/README.md
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            traffic, traffic_kernel = tj.get("hbm_bytes_per_launch"), tj.get("dominant_kernel")
+        roof_other = None
         if profile:
-            ms, n, fl = eng.profile_read(0)
-            if n:
+            # HIP-event timings of the two kernel families that carry the step: family 0 = the matrix products around the latent
+            # (decoder_input o conv 0 composed into one layer, forward + backward-data), family 1 = the fused decoder tail.
+            # `roofline` describes whichever took more of the timed region, `roofline_other` the other one.
+            fam = {}
+            for k in (0, 1):
+                ms, n, fl = eng.profile_read(k)
+                if n:
+                    fam[k] = (ms, n, fl)
+            # bf16x3 issues three bf16 MFMAs per algorithmic product
+            peak = {"f32": PEAK_F32_MATRIX_TFLOPS, "bf16x3": PEAK_BF16_MATRIX_TFLOPS / 3, "bf16": PEAK_BF16_MATRIX_TFLOPS}[a.precision]
+            gemm_name = (("rows::gemm_rows_kernel<4,5,*> (one sequence: 48..256 windows)" if 48 <= B <= 256 else
+                          "gemm_f32_kernel<1,*> / glds::gemm_glds_kernel<true,1,...>") if a.precision == "f32" else
+                         "glds::gemm_glds_kernel<false,1,*,128,128>" if a.precision == "bf16" else "gemm_bf16_kernel<1,*,3>")
+            names = {0: gemm_name + " (decoder_input o conv 0 as one layer: forward + backward-data)",
+                     1: "decoder_tail_kernel (convs 256->128->64->64->64->45, energy terms, adjoint convs; fp32 in every precision mode)"}
+
+            def roof_of(k):
+                ms, n, fl = fam[k]
                 achieved = fl / (ms * 1e-3) / 1e12
-                # bf16x3 issues three bf16 MFMAs per algorithmic product
-                peak = {"f32": PEAK_F32_MATRIX_TFLOPS, "bf16x3": PEAK_BF16_MATRIX_TFLOPS / 3, "bf16": PEAK_BF16_MATRIX_TFLOPS}[a.precision]
-                roof = {"bound": "mfma", "achieved": round(achieved, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
-                        "frac": round(achieved / peak, 4), "traffic": traffic if a.precision == "f32" else None,
-                        "traffic_source": "profiles/traffic_dominant_kernel.json (separate rocprofv3 --pmc passes of this "
-                                          "command, committed; NOT measured in this run)" if traffic and a.precision == "f32" else None,
-                        "kernel": (("rows::gemm_rows_kernel<4,5> / <3,8>" if 48 <= B <= 256 else "gemm_f32_kernel<1,EPI_BIAS,*,*,1> / glds::gemm_glds_kernel<true,1,...>")
-                                   if a.precision == "f32" else
-                                   "glds::gemm_glds_kernel<false,1,*,128,128>" if a.precision == "bf16" else "gemm_bf16_kernel<1,*,3>")
-                                  + " (decoder_input forward + backward-data)",
-                        "launches": int(n), "avg_us": round(ms * 1e3 / n, 2),
-                        "flop_per_launch": fl / n}
+                pk = peak if k == 0 else PEAK_F32_MATRIX_TFLOPS
+                r = {"bound": "mfma", "achieved": round(achieved, 3), "peak": round(pk, 1), "unit": "TFLOP/s", "frac": round(achieved / pk, 4),
+                     "traffic": None, "kernel": names[k], "launches": int(n), "avg_us": round(ms * 1e3 / n, 2), "flop_per_launch": fl / n,
+                     "share_of_step": round(ms * 1e-3 / min(PROFILE_STEPS, a.steps) / (elapsed / a.steps), 3)}
+                if traffic and a.precision == "f32" and traffic_kernel and (("tail" in traffic_kernel) == (k == 1)):
+                    r["traffic"] = traffic
+                    r["traffic_source"] = ("profiles/traffic_dominant_kernel.json (separate rocprofv3 --pmc passes of this command, "
+                                           "committed; NOT measured in this run)")
+                return r
+            if fam:
+                dom = max(fam, key=lambda k: fam[k][0])
+                roof = roof_of(dom)
+                rest = [k for k in fam if k != dom]
+                if rest:
+                    roof_other = roof_of(rest[0])
         cpu = None
         if world == 1 and a.cpu_windows > 0:
             nw = min(a.cpu_windows, B)
@@ -461,7 +482,7 @@ def main():
             "dtype": {"f32": "f32", "bf16x3": "f32 via 3x bf16 split MFMA (wide products), f32 elsewhere",
                       "bf16": "bf16 wide products / f32 accumulate, tail and energies"}[a.precision], "data": "synthetic",
             "config": {"workload": "%s: %d-frame sequence per GPU = %d chunks x %d windows = %d windows, %s wide products, "
-                                   "local+global stage, L-BFGS max_iter 25 / max_eval 31"
+                                   "local+global stage, L-BFGS max_iter 25 / max_eval 31; decoder_input and the first decoder conv run as ONE composed linear layer"
                                    % ({"seq2k": "BASELINE configs[1] (one ~2k-frame sequence, all windows in one batch)",
                                        "w8192": "BASELINE configs[3] per-GPU shard (8192 windows; 683 chunks = 8196)"}
                                       .get(a.workload, "custom workload (--workload %s)" % a.workload),
@@ -476,6 +497,7 @@ def main():
             "post": post,
             "lift": lift,
             "roofline": roof,
+            "roofline_other": roof_other,
             "cpu_baseline": cpu,
             "other_precisions": other_modes or None,
             "configs2": configs2,

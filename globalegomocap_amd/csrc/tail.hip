@@ -343,7 +343,13 @@ int launch_tail(gem_handle* h, const TailArgs& a, size_t lds_bytes, hipStream_t 
     const bool prof = h->prof.on;
     if (prof) {
         GEM_HIP(hipEventCreate(&rec.a)); GEM_HIP(hipEventCreate(&rec.b));
-        rec.family = 1; rec.flops = 0;
+        rec.family = 1;
+        // matrix work of the fused layers on the T real rows of a window: 2 * 3 taps * K * N * T per layer, forward + adjoint
+        double per_window = 0.0;
+        for (int i = 0; i < a.n; ++i) per_window += 2.0 * 3.0 * a.fwd[i].K * a.fwd[i].N * a.e.T;
+        if (!a.forward_only) per_window *= 2.0;
+        rec.flops = per_window * a.B;
+        if (h->ws.dyn) { rec.log_idx = h->ws.cur_log; rec.flops_per_window = per_window; }      // rows = active windows of the round
         GEM_HIP(hipEventRecord(rec.a, s));
     }
     const int wgs = (a.B + a.G - 1) / a.G;

@@ -65,7 +65,18 @@ kernel_stats("f32", "kernel_stats_%s.csv" % tag)
 kernel_stats("f32_1536", "kernel_stats_%s_f32_1536_windows.csv" % tag)
 kernel_stats("bf16_1536", "kernel_stats_%s_bf16_1536_windows.csv" % tag)
 kernel_stats("bf16_8192", "kernel_stats_%s_bf16_8196_windows.csv" % tag)
-o = traffic("f32", "rows::gemm_rows_kernel", "traffic_%s.json" % tag,
+# the dominant kernel of the headline run = the kernel (all instantiations of a template counted together) with the most time
+def total_ms(sub, substr):
+    f = glob.glob(os.path.join(src, sub, "trace", "*", "*kernel_stats.csv"))
+    if not f:
+        return 0.0
+    return sum(float(r["TotalDurationNs"]) for r in csv.DictReader(open(f[0])) if substr in r["Name"]) / 1e6
+
+
+cands = {"decoder_tail_kernel": total_ms("f32", "decoder_tail_kernel"), "rows::gemm_rows_kernel": total_ms("f32", "rows::gemm_rows_kernel")}
+dom = max(cands, key=cands.get)
+print("headline run, total ms per kernel family:", cands, "->", dom)
+o = traffic("f32", dom, "traffic_%s.json" % tag,
             "python bench.py --steps 2 --warmup 1 --cpu-windows 0 --no-extra --no-profile")
 if o and "dominant_kernel" in o:
     json.dump({k: o.get(k) for k in ("note", "dominant_kernel", "hbm_bytes_per_launch")}, open(os.path.join(dst, "traffic_dominant_kernel.json"), "w"), indent=1)
