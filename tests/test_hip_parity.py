@@ -681,6 +681,60 @@ def test_zero_weights_stop_at_the_first_evaluation_and_return_the_decoded_start(
     np.testing.assert_allclose(one.cpu().numpy(), out[:1].cpu().numpy(), rtol=0, atol=2e-6)
 
 
+@pytest.mark.parametrize("mode,B,tol_x,tol_e,tol_g", [("f32", 64, 2e-5, 1e-4, 1e-3), ("f32", 1344, 2e-5, 1e-4, 1e-3), ("bf16", 64, 3e-3, 5e-2, 4e-1)])
+def test_composed_front_layer_against_the_two_layers_it_replaces(torch_cuda, monkeypatch, mode, B, tol_x, tol_e, tol_g):
+    """decoder_input followed by the first decoder conv (no activation between them: SeqConvVAE.py:62,67-75,131-135) runs as ONE
+    composed linear layer (compose_front, gem_api.hip; weights composed in fp64 at load time).  The same engine with
+    GEM_NO_FRONT=1 keeps the two layers: decoded pose, energies and dE/dz of both must agree to rounding (fp32: summation order;
+    bf16: one rounding of the composed weights against two bf16 products with a bf16 intermediate), in the tail path (64
+    windows) and in the all-batched path (1344 windows), and a whole stage must end at the same energies."""
+    import torch
+    from globalegomocap_amd.engine import stats_to_numpy
+    sd = vae_schema.synthetic_state_dict(FULL, 5)
+    seq = synth.make_sequence(n_frames=200, seed=36)
+    est = np.asarray(seq["estimated_local_skeleton"], dtype=np.float32)
+    heat = np.asarray(seq["heatmap_list"], dtype=np.float32)
+    rng = np.random.default_rng(10)
+    starts = rng.integers(0, 190, B).astype(np.int32)
+    pose = np.stack([est[s:s + 10] for s in starts])
+    mb = O.mean_bone_length(est)
+    eps = rng.normal(size=(B, 2048)).astype(np.float32)
+    res = {}
+    for tag in ("composed", "separate"):
+        if tag == "separate":
+            monkeypatch.setenv("GEM_NO_FRONT", "1")
+        else:
+            monkeypatch.delenv("GEM_NO_FRONT", raising=False)
+        eng = _engine(FULL, max_windows=B)
+        eng.load_vae(0, sd)                      # the layers are composed when the weights are loaded
+        eng.set_precision(mode)
+        mu_d, lv_d, z_d = eng.encode(0, pose.reshape(B, 10, 45), eps)
+        E, parts, dz, X = eng.energy_grad(0, z_d, pose, mb, _ew(W_ALL), heat, starts)
+        n_stage = min(B, 64)
+        out, stats = eng.optimize_stage(0, pose[:n_stage], mb, eps[:n_stage], _ew((1e-6, 1e-5, 1e-2, 0.0, 1e-2)), heat, starts[:n_stage])
+        res[tag] = (E.cpu().numpy(), dz.cpu().numpy(), X.cpu().numpy(), stats_to_numpy(stats))
+        eng.close()
+    (Ec, dzc, Xc, stc), (Es, dzs, Xs, sts) = res["composed"], res["separate"]
+    assert np.abs(Xc - Xs).max() <= tol_x * max(1.0, np.abs(Xs).max())
+    np.testing.assert_allclose(Ec, Es, rtol=tol_e)
+    # dE/dz per window: a pre-activation that is zero to rounding may take the other LeakyReLU branch in one of the two
+    # evaluations (a kink of the network, not an error of either): allow that for 1 % of the windows
+    rel = np.abs(dzc - dzs).max(axis=1) / np.abs(dzs).max(axis=1)
+    assert np.quantile(rel, 0.99) <= tol_g and rel.max() <= max(0.25, tol_g), (np.sort(rel)[-5:], tol_g)
+    assert (stc["status"] == 1).all() and (sts["status"] == 1).all()
+    np.testing.assert_allclose(stc["final_loss"], sts["final_loss"], rtol=5e-3 if mode == "f32" else 5e-2)
+    if mode == "f32":
+        vae = O.fold_vae(sd)
+        z = z_d.cpu().numpy()
+        for b in (0, B // 2, B - 1):              # and both agree with the oracle
+            Xo, acts = O.decode(vae, z[b:b + 1], keep=True)
+            f, p_, dX = O.energy_and_grad(Xo[0], pose[b], mb, O.Weights(*W_ALL), oracle_camera(), heat[starts[b]:starts[b] + 10])
+            dzo = O.decode_backward(vae, dX[None], acts)[0]
+            assert np.abs(Xc[b] - Xo[0]).max() <= 5e-5 * max(1.0, np.abs(Xo[0]).max()), b
+            assert abs(float(Ec[b]) - f) <= 2e-4 * abs(f) + 1e-7, b
+            assert np.abs(dzc[b] - dzo).max() <= 2e-3 * np.abs(dzo).max() + 1e-8, b
+
+
 @pytest.mark.parametrize("B", [240, 229, 175, 100])
 def test_one_sequence_batches_take_the_row_streaming_gemm(torch_cuda, B):
     """BASELINE configs[1] regime (one sequence: 100..256 windows in a batch): the decoder_input products run in the
