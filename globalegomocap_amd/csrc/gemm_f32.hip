@@ -14,6 +14,7 @@
 // 16-byte pad per row so the ds_read_b128 fragment reads of 32 different rows spread over the banks).
 // The MFMA k-pairing is permuted (step s pairs k=s with k=BK/2+s) so each lane's 16 A and 16 B values of
 // a K-step are four contiguous 16-byte LDS reads; a sum over k does not care about the pairing.
+#include <cstdio>
 #include <cstdlib>
 
 #include "gem_internal.h"
@@ -414,6 +415,17 @@ static bool rows_plan(const gem_handle* h, const Layer& L, int lda, int ldc, int
     const rows::Plan p8 = rows::plan(M, L.N, L.K, 8, h->n_cu, slabs, h->ws.splitk_elems, ldc);
     *use8 = p8.n_rb > 0 && (p5.n_rb == 0 || p8.cost < p5.cost - 1e-9);          // ties: the smaller ring
     *out = *use8 ? p8 : p5;
+    static const char* force = getenv("GEM_ROWS_FORCE");      // developer override: "N:n_rb,n_split" for layers with that N
+    if (force) {
+        int fn = 0, frb = 0, fsk = 0;
+        if (sscanf(force, "%d:%d,%d", &fn, &frb, &fsk) == 3 && fn == L.N && frb > 0 && fsk > 0 && (fsk == 1 || slabs)) {
+            const int R = (M + 15) / 16, nk = L.K / rows::BK, rpb = (R + frb - 1) / frb;
+            if (rpb <= 8 && (long)frb * (L.N / rows::BN) * fsk <= h->n_cu) {
+                *use8 = rpb > 5;
+                *out = rows::Plan{frb, fsk, (nk + fsk - 1) / fsk, 1.0, 0.0};
+            }
+        }
+    }
     return out->n_rb != 0 && out->fill >= 0.75;
 }
 
