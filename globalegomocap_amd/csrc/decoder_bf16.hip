@@ -32,6 +32,22 @@ int launch_f32_to_bf16(const float* src, uint16_t* dst, size_t n, hipStream_t s)
     return 0;
 }
 
+// hi = bf16(w), lo = bf16(w - float(hi)): the two images of the split-bf16 ("bf16x3") mode, for weights composed on the device
+__global__ void f32_split_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ hi, uint16_t* __restrict__ lo, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = src[i];
+    const unsigned int h2 = bf16a::pack_bf16(v, 0.f) & 0xFFFFu;
+    hi[i] = (uint16_t)h2;
+    lo[i] = (uint16_t)(bf16a::pack_bf16(v - __builtin_bit_cast(float, h2 << 16), 0.f) & 0xFFFFu);
+}
+int launch_f32_split_bf16(const float* src, uint16_t* hi, uint16_t* lo, size_t n, hipStream_t s) {
+    if (!n) return 0;
+    hipLaunchKernelGGL(f32_split_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, hi, lo, n);
+    GEM_HIP(hipGetLastError());
+    return 0;
+}
+
 // sums fp32 split-K slabs, applies bias / LeakyReLU, writes bf16 (the fp32-output reduce is splitk_reduce_kernel)
 template <int EPI>
 __global__ __launch_bounds__(256) void splitk_reduce_bf16_kernel(const float* __restrict__ slabs, int nslab, size_t slab_stride,

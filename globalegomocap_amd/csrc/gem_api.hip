@@ -181,7 +181,9 @@ static int compose_front(gem_handle* h, StageNet& net, const FoldedConv& f, cons
     net.front_bwd.taps = 1; net.front_bwd.K = Nf; net.front_bwd.N = Dp; net.front_bwd.w = WfT;
     // bf16 images for the bf16 decoder mode (rounded once from the fp64-composed weights)
     if (dev_alloc(net.allocs, &net.front.wb_hi, (size_t)Nf * Dp) || dev_alloc(net.allocs, &net.front_bwd.wb_hi, (size_t)Dp * Nf) ||
-        launch_f32_to_bf16(Wf, net.front.wb_hi, (size_t)Nf * Dp, nullptr) || launch_f32_to_bf16(WfT, net.front_bwd.wb_hi, (size_t)Dp * Nf, nullptr))
+        dev_alloc(net.allocs, &net.front.wb_lo, (size_t)Nf * Dp) || dev_alloc(net.allocs, &net.front_bwd.wb_lo, (size_t)Dp * Nf) ||
+        launch_f32_split_bf16(Wf, net.front.wb_hi, net.front.wb_lo, (size_t)Nf * Dp, nullptr) ||
+        launch_f32_split_bf16(WfT, net.front_bwd.wb_hi, net.front_bwd.wb_lo, (size_t)Dp * Nf, nullptr))
         return 1;
     GEM_HIP(hipDeviceSynchronize());
     return upload(net.allocs, &net.front.bias, bf) || upload(net.allocs, &net.front_bwd.bias, zb);
@@ -439,7 +441,7 @@ static int decoder_forward(gem_handle* h, int stage, int B, const float* zp, hip
     StageNet& net = h->net[stage];
     Workspace& w = h->ws;
     const int rows = B * h->T;
-    const bool front = net.front.w && net.dec.size() > 1 && h->precision == GEM_PRECISION_F32;
+    const bool front = net.front.w && net.dec.size() > 1 && h->precision != GEM_PRECISION_BF16;
     const float* in = w.h0;
     if (front) {          // decoder_input o conv 0 as one product (compose_front)
         if (launch_gemm(h, net.front, EPI_BIAS_LRELU, zp, h->Dp, nullptr, w.dec_act[0], net.front.N, B, h->T, s, 0, w.dyn ? w.perm : nullptr)) return 1;
@@ -460,7 +462,7 @@ static int decoder_backward(gem_handle* h, int stage, int B, hipStream_t s, int 
     StageNet& net = h->net[stage];
     Workspace& w = h->ws;
     const int rows = B * h->T;
-    const bool front = net.front.w && net.dec.size() > 1 && h->precision == GEM_PRECISION_F32 && from >= 1;
+    const bool front = net.front.w && net.dec.size() > 1 && h->precision != GEM_PRECISION_BF16 && from >= 1;
     for (int i = from; i >= (front ? 1 : 0); --i) {
         const Layer& L = net.dec_bwd[i];
         const float* aux = i > 0 ? w.dec_act[i - 1] : nullptr;      // LeakyReLU' from the sign of the stored activation
@@ -515,7 +517,7 @@ static int evaluate(gem_handle* h, int stage, int B, const float* zp, const Ener
     }
     // wide layers as batched GEMMs, the narrow tail + energy + its adjoints in one kernel
     const int st = net.tail_start, rows = B * h->T;
-    const bool front = net.front.w && st == 1 && h->precision == GEM_PRECISION_F32;
+    const bool front = net.front.w && st == 1 && h->precision != GEM_PRECISION_BF16;      // (the bf16 decoder mode has its own evaluate)
     const float* in = w.h0;
     SlabSrc in_slab;
     if (front) {
@@ -600,7 +602,7 @@ static int optimize_stage_impl(gem_handle* h, int stage, int B, const float* d_p
     // The active windows are re-packed between the rounds: by compact_kernel, or -- one sequence in fp32 -- inside the
     // decoder_input forward launch of the next round (gemm_rows.h; one launch and its boundary less per round).
     StageNet& net_ = h->net[stage];
-    const bool front_ = net_.front.w && net_.tail_start == 1 && h->precision == GEM_PRECISION_F32;
+    const bool front_ = net_.front.w && net_.tail_start == 1 && h->precision != GEM_PRECISION_BF16;
     const Layer& first_ = front_ ? net_.front : net_.dec_in;
     const int tail_g_ = h->T <= 16 ? 16 / h->T : 1;
     const bool tail_path_ = net_.tail_start >= 0 && (B + tail_g_ - 1) / tail_g_ <= 5 * h->n_cu;

@@ -266,6 +266,7 @@ int launch_gemm_bf16(gem_handle* h, const Layer& L, int epi, int nprod, const fl
 struct EnergyArgs;
 int evaluate_bf16(gem_handle* h, int stage, int B, const EnergyArgs& ea, hipStream_t s, bool forward_only);
 int launch_f32_to_bf16(const float* src, uint16_t* dst, size_t n, hipStream_t s);
+int launch_f32_split_bf16(const float* src, uint16_t* hi, uint16_t* lo, size_t n, hipStream_t s);
 
 int launch_pack_pose(const float* src, float* dst, int rows, int C, hipStream_t s);      // [rows,C] -> [rows,64]
 int launch_unpack_pose(const float* src, float* dst, int rows, int C, hipStream_t s);    // [rows,64] -> [rows,C]

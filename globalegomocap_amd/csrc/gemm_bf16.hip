@@ -382,6 +382,7 @@ int launch_gemm_bf16(gem_handle* h, const Layer& L, int epi, int nprod, const fl
     if (L.taps == 1) {
         if (epi == EPI_BIAS) return launch_np<1, EPI_BIAS>(h, L, nprod, A, lda, aux, C, ldc, M, T, s, row_map);
         if (epi == EPI_NONE) return launch_np<1, EPI_NONE>(h, L, nprod, A, lda, aux, C, ldc, M, T, s, row_map);
+        if (epi == EPI_BIAS_LRELU) return launch_np<1, EPI_BIAS_LRELU>(h, L, nprod, A, lda, aux, C, ldc, M, T, s, row_map);
     } else if (L.taps == 3) {
         if (epi == EPI_BIAS) return launch_np<3, EPI_BIAS>(h, L, nprod, A, lda, aux, C, ldc, M, T, s, row_map);
         if (epi == EPI_BIAS_LRELU) return launch_np<3, EPI_BIAS_LRELU>(h, L, nprod, A, lda, aux, C, ldc, M, T, s, row_map);
