@@ -25,6 +25,7 @@ def make(n_parts):
         lo, hi = p * B // n_parts, (p + 1) * B // n_parts
         e = WindowEngine(shape, cam, max_windows=hi - lo)
         e.load_vae(0, sd_l); e.load_vae(1, sd_g)
+        if os.environ.get('GEM_EXP_GRAPHS'): e.enable_graphs(True)
         mb = e.mean_bone_length(seq["est_local"][:100]).reshape(1, 15).expand(hi - lo, 15).contiguous()
         parts.append(dict(e=e, f0=torch.as_tensor(starts[lo:hi], device=dev), mb=mb, el=eps[lo:hi, 0].contiguous().to(dev),
                           eg=eps[lo:hi, 1].contiguous().to(dev), s=torch.cuda.Stream()))
@@ -41,6 +42,6 @@ def run(parts, steps):
 
 for n in (1, 2, 3, 4):
     parts = make(n)
-    run(parts, 2)
+    run(parts, 3)
     ms = run(parts, 8)
     print("streams %d: %.2f ms/step  %.0f windows/s" % (n, ms, B / ms * 1e3), flush=True)
