@@ -784,6 +784,42 @@ def test_one_sequence_batches_take_the_row_streaming_gemm(torch_cuda, B):
     assert np.isfinite(out.cpu().numpy()).all()
 
 
+@pytest.mark.parametrize("B", [400, 1280])
+def test_batches_between_the_regimes_agree_with_a_small_batch(torch_cuda, B):
+    """400..1280 windows in fp32: too many rows for the few-rows GEMM, still few enough workgroups for the fused tail -- the
+    composed front layer runs in the tiled kernels, its slabs go to the tail, compact_kernel re-packs the windows.  The first 40
+    windows must come out as they do in a 40-window batch: same evaluation counts, energies to 1e-5, poses to 0.01 mm."""
+    from globalegomocap_amd.engine import stats_to_numpy
+    sd = vae_schema.synthetic_state_dict(FULL, 5)
+    seq = synth.make_sequence(n_frames=200, seed=36)
+    est = np.asarray(seq["estimated_local_skeleton"], dtype=np.float32)
+    heat = np.asarray(seq["heatmap_list"], dtype=np.float32)
+    rng = np.random.default_rng(10)
+    starts = rng.integers(0, 190, B).astype(np.int32)
+    pose = np.stack([est[s:s + 10] for s in starts])
+    eps = rng.normal(size=(B, 2048)).astype(np.float32)
+    big, small = _engine(FULL, max_windows=B), _engine(FULL, max_windows=40)
+    big.load_vae(0, sd)
+    small.load_vae(0, sd)
+    mb = big.mean_bone_length(est)
+    _, _, z = big.encode(0, pose.reshape(B, 10, 45), eps)
+    E, _, dz, X = big.energy_grad(0, z, pose, mb, _ew(W_ALL), heat, starts)
+    Es, _, dzs, Xs = small.energy_grad(0, z[:40], pose[:40], mb, _ew(W_ALL), heat, starts[:40])
+    np.testing.assert_allclose(X[:40].cpu().numpy(), Xs.cpu().numpy(), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(E[:40].cpu().numpy(), Es.cpu().numpy(), rtol=1e-6)
+    assert np.abs((dz[:40] - dzs).cpu().numpy()).max() <= 1e-4 * np.abs(dzs.cpu().numpy()).max()
+    w = _ew((1e-6, 1e-5, 1e-2, 0.0, 1e-2))
+    out, stats = big.optimize_stage(0, pose, mb, eps, w, heat, starts)
+    outs, stats_s = small.optimize_stage(0, pose[:40], mb, eps[:40], w, heat, starts[:40])
+    st, ss = stats_to_numpy(stats), stats_to_numpy(stats_s)
+    assert (st["status"] == 1).all()
+    assert (st["func_evals"][:40] == ss["func_evals"]).sum() >= 38
+    np.testing.assert_allclose(st["final_loss"][:40], ss["final_loss"], rtol=1e-5)
+    assert np.linalg.norm((out[:40] - outs).cpu().numpy(), axis=-1).mean() < 0.01e-3
+    big.close()
+    small.close()
+
+
 def test_mid_size_batch_runs_the_fused_tail_in_several_waves(torch_cuda):
     """300..1280 windows: more tail workgroups than CUs.  One evaluation against the same windows in a small batch, and a
     whole stage whose duplicated windows (first 40 = last 40, i.e. different workgroup waves) must agree bitwise."""
