@@ -159,6 +159,9 @@ __device__ __forceinline__ void tail_gemm(const float* in, int ld_in, const floa
     else tail_gemm_nt<1>(in, ld_in, zero_line, L, next, has_next, T, R, bpre, epi);
 }
 
+// NL = number of fused layers (compile time: the two layer loops unroll, so every layer's descriptor sits at a fixed
+// kernel-argument offset instead of being fetched by index behind each barrier)
+template <int NL>
 __global__ __launch_bounds__(TAIL_THREADS, 2) void decoder_tail_kernel(TailArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -230,13 +233,14 @@ __global__ __launch_bounds__(TAIL_THREADS, 2) void decoder_tail_kernel(TailArgs 
     // ---- forward layers
     f32x4 bpre[4];
     tail_prefetch_first(a.fwd[0], bpre);
-    for (int i = 0; i < a.n; ++i) {
-        const bool last = (i + 1 == a.n);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const bool last = (i + 1 == NL);
         float* out = lds + a.off_act[i + 1];
         const int ldo = a.ld_act[i + 1];
         float* Xp = last ? a.Xp : nullptr;
         // (by value: taking the address of a kernel-argument member would put the whole struct in scratch)
-        const TailLayerDev nxt = !last ? a.fwd[i + 1] : a.bwd[a.n - 1];
+        const TailLayerDev nxt = !last ? a.fwd[i + 1 < NL ? i + 1 : i] : a.bwd[NL - 1];
         tail_gemm(lds + a.off_act[i], a.ld_act[i], lds + a.off_zero, a.fwd[i], nxt, !last || !a.forward_only, T, R, bpre,
                   [&](const f32x4& acc, int r0, int col, float bv) {
 #pragma unroll
@@ -258,19 +262,20 @@ __global__ __launch_bounds__(TAIL_THREADS, 2) void decoder_tail_kernel(TailArgs 
     if (a.G == 1) {
         // one window per workgroup: all eight wavefronts share its energy terms
         float* scr = lds + a.off_escr;
-        energy_window<true, TAIL_THREADS>(a.e, a.e.perm ? a.e.perm[w0] : w0, tid, lds + a.off_act[a.n], a.ld_act[a.n], scr,
-                                          scr + a.escr, scr + 2 * a.escr, scr + 3 * a.escr, g_cur, a.ld_g, a.fwd[a.n - 1].N);
+        energy_window<true, TAIL_THREADS>(a.e, a.e.perm ? a.e.perm[w0] : w0, tid, lds + a.off_act[NL], a.ld_act[NL], scr,
+                                          scr + a.escr, scr + 2 * a.escr, scr + 3 * a.escr, g_cur, a.ld_g, a.fwd[NL - 1].N);
     } else if (wave < nwin) {
         float* scr = lds + a.off_escr + wave * 4 * a.escr;
         energy_window<false>(a.e, a.e.perm ? a.e.perm[w0 + wave] : w0 + wave, lane,
-                             lds + a.off_act[a.n] + wave * T * a.ld_act[a.n], a.ld_act[a.n], scr, scr + a.escr,
-                             scr + 2 * a.escr, scr + 3 * a.escr, g_cur + wave * T * a.ld_g, a.ld_g, a.fwd[a.n - 1].N);
+                             lds + a.off_act[NL] + wave * T * a.ld_act[NL], a.ld_act[NL], scr, scr + a.escr,
+                             scr + 2 * a.escr, scr + 3 * a.escr, g_cur + wave * T * a.ld_g, a.ld_g, a.fwd[NL - 1].N);
     }
     __syncthreads();
     TAIL_PROBE();
 
     // ---- backward-data layers (adjoint convs), LeakyReLU' from the sign of the LDS activations
-    for (int i = a.n - 1; i >= 0; --i) {
+#pragma unroll
+    for (int i = NL - 1; i >= 0; --i) {
         const float* act = lds + a.off_act[i];
         const int lda = a.ld_act[i];
         const int ldg = a.ld_g;
@@ -336,8 +341,10 @@ size_t plan_tail(const std::vector<Layer>& dec, int start, int T, int J, TailArg
 int launch_tail(gem_handle* h, const TailArgs& a, size_t lds_bytes, hipStream_t s) {
     static PerDeviceOnce attr_once;
     if (attr_once.need(h->cfg.device)) {
-        GEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024));
+        const void* ks[] = {reinterpret_cast<const void*>(decoder_tail_kernel<1>), reinterpret_cast<const void*>(decoder_tail_kernel<2>),
+                            reinterpret_cast<const void*>(decoder_tail_kernel<3>), reinterpret_cast<const void*>(decoder_tail_kernel<4>),
+                            reinterpret_cast<const void*>(decoder_tail_kernel<5>), reinterpret_cast<const void*>(decoder_tail_kernel<6>)};
+        for (const void* k : ks) GEM_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     Profile::Rec rec;
     const bool prof = h->prof.on;
@@ -353,7 +360,15 @@ int launch_tail(gem_handle* h, const TailArgs& a, size_t lds_bytes, hipStream_t 
         GEM_HIP(hipEventRecord(rec.a, s));
     }
     const int wgs = (a.B + a.G - 1) / a.G;
-    hipLaunchKernelGGL(decoder_tail_kernel, dim3(wgs), dim3(TAIL_THREADS), lds_bytes, s, a);
+    switch (a.n) {
+        case 1: hipLaunchKernelGGL(decoder_tail_kernel<1>, dim3(wgs), dim3(TAIL_THREADS), lds_bytes, s, a); break;
+        case 2: hipLaunchKernelGGL(decoder_tail_kernel<2>, dim3(wgs), dim3(TAIL_THREADS), lds_bytes, s, a); break;
+        case 3: hipLaunchKernelGGL(decoder_tail_kernel<3>, dim3(wgs), dim3(TAIL_THREADS), lds_bytes, s, a); break;
+        case 4: hipLaunchKernelGGL(decoder_tail_kernel<4>, dim3(wgs), dim3(TAIL_THREADS), lds_bytes, s, a); break;
+        case 5: hipLaunchKernelGGL(decoder_tail_kernel<5>, dim3(wgs), dim3(TAIL_THREADS), lds_bytes, s, a); break;
+        case 6: hipLaunchKernelGGL(decoder_tail_kernel<6>, dim3(wgs), dim3(TAIL_THREADS), lds_bytes, s, a); break;
+        default: set_error("launch_tail: unsupported number of fused layers"); return 1;
+    }
     GEM_HIP(hipGetLastError());
     if (prof) { GEM_HIP(hipEventRecord(rec.b, s)); h->prof.recs.push_back(rec); }
     return 0;
