@@ -41,9 +41,17 @@ FEATURE_OFFSET_LOCAL, FEATURE_OFFSET_GLOBAL = 0.0, 3.0
 CAM_JITTER = (0.3, 0.002)           # the bench's camera noise: 0.3 deg, 2 mm per frame
 CLI = dict(vae_weight=0.0, gmm_weight=0.0, smoothness_weight=0.001, bone_length_weight=0.01, weight_3d=0.01,
            reproj_weight=0.01)      # optimize_whole_sequence.py:14-19
+# second fixture (`--variant allterms` -> pipeline_full_allterms.npz): every energy term switched on (the CLI default has
+# vae_weight = 0), other weights, another sequence and noise stream
+VARIANTS = {"default": dict(cli=CLI, seq_seed=2, eps_seed=4321, name="pipeline_full.npz", full=True),
+            "allterms": dict(cli=dict(vae_weight=0.002, gmm_weight=0.0, smoothness_weight=0.003, bone_length_weight=0.02, weight_3d=0.02,
+                                      reproj_weight=0.005), seq_seed=5, eps_seed=99, name="pipeline_full_allterms.npz", full=False)}
 
 
 def main():
+    global CLI, SEQ_SEED, EPS_SEED
+    variant = VARIANTS[sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else "default"]
+    CLI, SEQ_SEED, EPS_SEED = variant["cli"], variant["seq_seed"], variant["eps_seed"]
     os.makedirs(OUT, exist_ok=True)
     work = tempfile.mkdtemp(prefix="gem_golden_full_")
     torch, ref_opt, ConvVAE, FishEye = import_reference(work)
@@ -119,7 +127,7 @@ def main():
         torch.manual_seed(EPS_SEED)
         return ref_opt.main(os.path.join("data", "chunk0"), camera_model_path=cam_json, final_smooth=final_smooth, **CLI)
 
-    for tag, fs in (("smooth", True), ("raw", False)):
+    for tag, fs in ((("smooth", True), ("raw", False)) if variant["full"] else (("smooth", True),)):
         errors, est_seq, mid_local, opt_seq, gt_seq = run(fs, 1)
         out["opt_" + tag] = np.asarray(opt_seq)
         out["mid_local_" + tag] = np.asarray(mid_local)
@@ -148,12 +156,13 @@ def main():
             out["stage_out"] = np.stack([b for _, b in log["stage_io"]])           # [24,10,15,3] f32
             print("  local  evals", out["func_evals"][0::2], "n_iter", out["n_iter"][0::2])
             print("  global evals", out["func_evals"][1::2], "n_iter", out["n_iter"][1::2])
-    errors8 = run(True, 8)[0]
-    out["err_smooth_8threads/optimized_global_mpjpe"] = np.asarray(errors8["optimized_global_mpjpe"])
-    out["func_evals_8threads"] = np.array([c["func_evals"] for c in log["calls"]])
-    print("  reference self-noise 1 vs 8 threads: %.4f mm on optimized_global_mpjpe"
-          % (abs(errors8["optimized_global_mpjpe"] - float(out["err_smooth/optimized_global_mpjpe"])) * 1000))
-    path = os.path.join(OUT, "pipeline_full.npz")
+    if variant["full"]:
+        errors8 = run(True, 8)[0]
+        out["err_smooth_8threads/optimized_global_mpjpe"] = np.asarray(errors8["optimized_global_mpjpe"])
+        out["func_evals_8threads"] = np.array([c["func_evals"] for c in log["calls"]])
+        print("  reference self-noise 1 vs 8 threads: %.4f mm on optimized_global_mpjpe"
+              % (abs(errors8["optimized_global_mpjpe"] - float(out["err_smooth/optimized_global_mpjpe"])) * 1000))
+    path = os.path.join(OUT, variant["name"])
     np.savez_compressed(path, **out)
     print("%8.1f KB  %s" % (os.path.getsize(path) / 1024, path))
 

@@ -70,13 +70,16 @@ def _report(name, payload):
 # ------------------------------------------------------------------------------------------------------------------
 # the reference's full-size run
 # ------------------------------------------------------------------------------------------------------------------
-def test_full_size_stages_against_reference_golden(torch_cuda, golden, full_vaes):
+@pytest.mark.parametrize("name", ["pipeline_full", "pipeline_full_allterms"])
+def test_full_size_stages_against_reference_golden(torch_cuda, golden, name):
     """The 24 stage calls of the reference's main() at D = 2048, each from the reference's OWN stage input: closure traces,
     (n_iter, func_evals) and result poses.  Global stages (smooth energy) are pinned to rounding; local stages up to the
     kinks of the bilinear heat-map sampling (see tests/test_oracle_golden.py for the same statement about the CPU oracle)."""
     from globalegomocap_amd.engine import stats_to_numpy
-    g = golden("pipeline_full")
-    data, sd_l, sd_g, w_l, w_g = full_vaes
+    from helpers import FULL_GOLDENS
+    g = golden(name)
+    lim = FULL_GOLDENS[name]
+    data, sd_l, sd_g, w_l, w_g = full_golden_case(g)
     eng = _engine(12, sd_l, sd_g)
     mb = eng.mean_bone_length(data["estimated_local_skeleton"].astype(np.float32))
     starts = window_starts(100)
@@ -103,17 +106,18 @@ def test_full_size_stages_against_reference_golden(torch_cuda, golden, full_vaes
             # (global-stage energies are sums of squared few-mm residuals: decoded poses that differ by 2e-6 m -- the fp32
             # summation order of the decoder -- move them by a few 1e-4 relative; local-stage energies are O(1))
             np.testing.assert_allclose(tr[k, :4], ref_tr[:4], rtol=5e-4 if st else 2e-4, atol=1e-9, err_msg="row %d" % row)
-            assert abs(int(sn["func_evals"][k]) - n_ref) <= 1 and abs(int(sn["n_iter"][k]) - int(g["n_iter"][row])) <= 1, rows_report[-1]
+            assert abs(int(sn["func_evals"][k]) - n_ref) <= 1, rows_report[-1]
+            assert abs(int(sn["n_iter"][k]) - int(g["n_iter"][row])) <= (1 if st else lim["local_iters"]), rows_report[-1]
             if st:
                 assert int(sn["func_evals"][k]) == n_ref and int(sn["n_iter"][k]) == int(g["n_iter"][row]), rows_report[-1]
                 np.testing.assert_allclose(tr[k, :n_ref], ref_tr[:n_ref], rtol=1e-3, atol=1e-9, err_msg="row %d" % row)
                 assert abs(sn["final_loss"][k] - np.nanmin(ref_tr)) <= 1e-4 * abs(np.nanmin(ref_tr)), rows_report[-1]
-                assert d.mean() < 0.05e-3 and d.max() < 0.2e-3, rows_report[-1]
+                assert d.mean() < 0.05e-3 and d.max() < lim["global_max"], rows_report[-1]
             else:
-                assert abs(sn["final_loss"][k] - np.nanmin(ref_tr)) <= 2e-3 * abs(np.nanmin(ref_tr)), rows_report[-1]
-                assert d.mean() < 2e-3, rows_report[-1]
+                assert abs(sn["final_loss"][k] - np.nanmin(ref_tr)) <= lim["local_loss"] * abs(np.nanmin(ref_tr)), rows_report[-1]
+                assert d.mean() < lim["local_mean"], rows_report[-1]
                 local_diff.append(d.mean())
-    _report("full_size_stage_deviation.json", rows_report)
+    _report("full_size_stage_deviation.json" if name == "pipeline_full" else "full_size_stage_deviation_%s.json" % name, rows_report)
     print("per-stage deviation from the reference (mm, mean over the window's 150 joints):")
     for r in rows_report:
         print("  row %(row)2d %(stage)-6s evals %(evals_hip)d/%(evals_ref)d  n_iter %(n_iter_hip)d/%(n_iter_ref)d  "

@@ -245,7 +245,8 @@ def test_full_size_main_torch_port_matches_reference(golden):
     assert abs(mp - float(g["err_smooth/optimized_global_mpjpe"])) < 0.05e-3
 
 
-def test_full_size_stages_numpy_oracle_match_reference(golden):
+@pytest.mark.parametrize("name", ["pipeline_full", "pipeline_full_allterms"])
+def test_full_size_stages_numpy_oracle_match_reference(golden, name):
     """Every one of the 24 stage calls of the reference's full-size main(), run in isolation (the reference's own stage input)
     through the numpy oracle -- its own L-BFGS state machine, the one the HIP kernel mirrors.
 
@@ -255,8 +256,9 @@ def test_full_size_stages_numpy_oracle_match_reference(golden):
     differ by 1e-6 m part ways at the first texel edge a joint crosses on different sides, so their traces agree at the
     start, most windows end within 0.02 mm of the reference and a few up to ~1 mm away (still at the same energy to 1e-3)."""
     from globalegomocap_amd.sequence import window_starts
-    from helpers import full_golden_case
-    g = golden("pipeline_full")
+    from helpers import full_golden_case, FULL_GOLDENS
+    g = golden(name)
+    lim = FULL_GOLDENS[name]
     data, sd_l, sd_g, w_l, w_g = full_golden_case(g)
     vaes, W = (O.fold_vae(sd_l), O.fold_vae(sd_g)), (O.Weights(*w_l), O.Weights(*w_g))
     cam = oracle_camera()
@@ -281,15 +283,15 @@ def test_full_size_stages_numpy_oracle_match_reference(golden):
         assert n_ref == int(g["func_evals"][row])
         d = np.linalg.norm(out - g["stage_out"][row], axis=-1)
         np.testing.assert_allclose(losses[:5], ref_tr[:5], rtol=2e-4, atol=1e-9)
-        assert abs(stats["func_evals"] - n_ref) <= 1 and abs(stats["n_iter"] - int(g["n_iter"][row])) <= 1, row
+        assert abs(stats["func_evals"] - n_ref) <= 1 and abs(stats["n_iter"] - int(g["n_iter"][row])) <= (1 if st else lim["local_iters"]), row
         if st:      # global stage: smooth energy
             assert stats["func_evals"] == n_ref and stats["n_iter"] == int(g["n_iter"][row]), row
             np.testing.assert_allclose(losses, ref_tr[:n_ref], rtol=1e-3, atol=1e-9)
             assert abs(stats["loss"] - np.nanmin(ref_tr)) <= 1e-4 * abs(np.nanmin(ref_tr)), row
-            assert d.mean() < 0.05e-3 and d.max() < 0.2e-3, (row, d.mean(), d.max())
+            assert d.mean() < 0.05e-3 and d.max() < lim["global_max"], (row, d.mean(), d.max())
         else:
-            assert abs(stats["loss"] - np.nanmin(ref_tr)) <= 2e-3 * abs(np.nanmin(ref_tr)), row
-            assert d.mean() < 2e-3, (row, d.mean())
+            assert abs(stats["loss"] - np.nanmin(ref_tr)) <= lim["local_loss"] * abs(np.nanmin(ref_tr)), row
+            assert d.mean() < lim["local_mean"], (row, d.mean())
             local_diff.append(d.mean())
     assert np.median(local_diff) < 0.05e-3, np.sort(local_diff)
 
