@@ -341,6 +341,52 @@ def main():
         e2.close()
         del seq2
 
+    # ---- side record (not `value`): BASELINE configs[4] -- "streaming 100k-frame sequence over 8 GPUs, hipGraph-captured":
+    # the per-GPU shard, 1563 overlapping windows (stride 8) of ONE continuous 12 506-frame stream, frames stored once, no chunk
+    # structure, every call after the second replayed from a hipGraph
+    configs4 = None
+    if a.precision == "f32" and not a.no_extra and world == 1 and a.workload == "seq2k":
+        configs4 = {}
+        B4 = 1563
+        starts4 = (8 * np.arange(B4)).astype(np.int32)
+        nf4 = int(starts4[-1]) + 10
+        seq4 = synth.make_sequence_device(nf4, seed=4000, device=device, camera=cam, cam_jitter=CAM_JITTER)
+        e4 = WindowEngine(shape, cam, max_windows=B4)
+        e4.load_vae(LOCAL_STAGE, sd_local)
+        e4.load_vae(GLOBAL_STAGE, sd_global)
+        mb4 = e4.mean_bone_length(seq4["est_local"]).reshape(1, 15).expand(B4, 15).contiguous()
+        g4 = torch.Generator().manual_seed(654)
+        eps4 = torch.randn(B4, 2, shape.latent_dim, generator=g4)
+        el4, eg4 = eps4[:, 0].contiguous().to(device), eps4[:, 1].contiguous().to(device)
+        f04 = torch.as_tensor(starts4, device=device)
+        gt4 = seq4["gt_global"][:8 * B4 + 2]
+        n4 = max(3, min(a.steps, 10))
+        for mode in ("f32", "bf16"):
+            e4.set_precision(mode)
+            e4.enable_graphs(True)
+            for _ in range(3):                   # eager, capture, first replay
+                e4.optimize_windows(seq4["est_local"], seq4["cams"], seq4["heat"], f04, mb4, el4, eg4, w_local, w_global)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            host = 0.0
+            for _ in range(n4):
+                th = time.perf_counter()
+                m4, gl4, st4 = e4.optimize_windows(seq4["est_local"], seq4["cams"], seq4["heat"], f04, mb4, el4, eg4, w_local, w_global)
+                host += time.perf_counter() - th
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            gs = e4.graph_stats()
+            sn4 = stats_to_numpy(st4)
+            merged = final_smooth(merge_batches(gl4.cpu().numpy()))
+            configs4[mode] = {"windows": B4, "windows_per_s": round(B4 * n4 / dt, 1), "ms_per_step": round(dt / n4 * 1e3, 3),
+                              "host_enqueue_ms_per_step": round(host / n4 * 1e3, 3), "graph_replays": int(gs["replays"]),
+                              "mpjpe_optimised_mm": round(mpjpe(merged, gt4) * 1e3, 3), "all_finished": bool((sn4["status"] == 1).all())}
+            e4.enable_graphs(False)
+        configs4["workload"] = ("BASELINE configs[4] per-GPU shard: %d overlapping windows (stride 8) of one continuous %d-frame stream, "
+                                "local+global stage, whole call replayed from a hipGraph" % (B4, nf4))
+        e4.close()
+        del seq4
+
     if rank == 0:
         st = stats_to_numpy(stats)
         assert (st["status"] == 1).all(), "a window did not finish"
@@ -501,6 +547,7 @@ def main():
             "cpu_baseline": cpu,
             "other_precisions": other_modes or None,
             "configs2": configs2,
+            "configs4": configs4,
             "sequences_in_flight": in_flight,
         }
         print(json.dumps(line), flush=True)
