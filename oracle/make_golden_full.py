@@ -44,6 +44,8 @@ CLI = dict(vae_weight=0.0, gmm_weight=0.0, smoothness_weight=0.001, bone_length_
 # second fixture (`--variant allterms` -> pipeline_full_allterms.npz): every energy term switched on (the CLI default has
 # vae_weight = 0), other weights, another sequence and noise stream
 VARIANTS = {"default": dict(cli=CLI, seq_seed=2, eps_seed=4321, name="pipeline_full.npz", full=True),
+            # third fixture: the reference's OTHER fisheye calibration (more polynomial terms, another principal point)
+            "altcam": dict(cli=CLI, seq_seed=9, eps_seed=7, name="pipeline_full_altcam.npz", full=False, calibration="alt"),
             "allterms": dict(cli=dict(vae_weight=0.002, gmm_weight=0.0, smoothness_weight=0.003, bone_length_weight=0.02, weight_3d=0.02,
                                       reproj_weight=0.005), seq_seed=5, eps_seed=99, name="pipeline_full_allterms.npz", full=False)}
 
@@ -55,7 +57,8 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     work = tempfile.mkdtemp(prefix="gem_golden_full_")
     torch, ref_opt, ConvVAE, FishEye = import_reference(work)
-    cam_json = DEFAULT_CALIBRATION
+    from globalegomocap_amd.camera import ALT_CALIBRATION
+    cam_json = ALT_CALIBRATION if variant.get("calibration") == "alt" else DEFAULT_CALIBRATION
     cam = FisheyeCamera.from_json(cam_json)
     # local VAE: mildly non-linear (its stage has the kinks of the bilinear heat-map sampling anyway); global VAE: affine, so
     # that the global stage's energy is smooth and its L-BFGS trajectory can be pinned to rounding (FEATURE_OFFSET_*)
@@ -120,6 +123,7 @@ def main():
            "cams": np.asarray(seq["camera_pose_list"]), "heat_centres": seq["heatmap_centres"]}
     for k, v in CLI.items():
         out["cli/" + k] = v
+    out["calibration"] = np.asarray(variant.get("calibration", "default"))
 
     def run(final_smooth, threads):
         torch.set_num_threads(threads)

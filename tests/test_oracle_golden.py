@@ -245,7 +245,7 @@ def test_full_size_main_torch_port_matches_reference(golden):
     assert abs(mp - float(g["err_smooth/optimized_global_mpjpe"])) < 0.05e-3
 
 
-@pytest.mark.parametrize("name", ["pipeline_full", "pipeline_full_allterms"])
+@pytest.mark.parametrize("name", ["pipeline_full", "pipeline_full_allterms", "pipeline_full_altcam"])
 def test_full_size_stages_numpy_oracle_match_reference(golden, name):
     """Every one of the 24 stage calls of the reference's full-size main(), run in isolation (the reference's own stage input)
     through the numpy oracle -- its own L-BFGS state machine, the one the HIP kernel mirrors.
@@ -256,12 +256,12 @@ def test_full_size_stages_numpy_oracle_match_reference(golden, name):
     differ by 1e-6 m part ways at the first texel edge a joint crosses on different sides, so their traces agree at the
     start, most windows end within 0.02 mm of the reference and a few up to ~1 mm away (still at the same energy to 1e-3)."""
     from globalegomocap_amd.sequence import window_starts
-    from helpers import full_golden_case, FULL_GOLDENS
+    from helpers import full_golden_case, FULL_GOLDENS, golden_calibration
     g = golden(name)
     lim = FULL_GOLDENS[name]
     data, sd_l, sd_g, w_l, w_g = full_golden_case(g)
     vaes, W = (O.fold_vae(sd_l), O.fold_vae(sd_g)), (O.Weights(*w_l), O.Weights(*w_g))
-    cam = oracle_camera()
+    cam = oracle_camera(golden_calibration(g))
     mb = O.mean_bone_length(data["estimated_local_skeleton"].astype(np.float32))
     heat, starts = data["heatmap_list"], window_starts(100)
     local_diff = []
@@ -282,7 +282,8 @@ def test_full_size_stages_numpy_oracle_match_reference(golden, name):
         n_ref = int(np.isfinite(ref_tr).sum())
         assert n_ref == int(g["func_evals"][row])
         d = np.linalg.norm(out - g["stage_out"][row], axis=-1)
-        np.testing.assert_allclose(losses[:5], ref_tr[:5], rtol=2e-4, atol=1e-9)
+        # (global-stage energies are sums of squared few-mm residuals: decoded poses that differ by 2e-6 m move them by a few 1e-4)
+        np.testing.assert_allclose(losses[:lim["prefix"]], ref_tr[:lim["prefix"]], rtol=5e-4 if st else 2e-4, atol=1e-9)
         assert abs(stats["func_evals"] - n_ref) <= 1 and abs(stats["n_iter"] - int(g["n_iter"][row])) <= (1 if st else lim["local_iters"]), row
         if st:      # global stage: smooth energy
             assert stats["func_evals"] == n_ref and stats["n_iter"] == int(g["n_iter"][row]), row
@@ -293,7 +294,7 @@ def test_full_size_stages_numpy_oracle_match_reference(golden, name):
             assert abs(stats["loss"] - np.nanmin(ref_tr)) <= lim["local_loss"] * abs(np.nanmin(ref_tr)), row
             assert d.mean() < lim["local_mean"], (row, d.mean())
             local_diff.append(d.mean())
-    assert np.median(local_diff) < 0.05e-3, np.sort(local_diff)
+    assert np.median(local_diff) < lim["local_median"], np.sort(local_diff)
 
 
 def test_full_size_main_numpy_oracle_matches_reference(golden):
