@@ -1,8 +1,11 @@
-// fp32 MFMA GEMM for FEW rows (gfx950): the decoder_input products of one sequence,
+// fp32 MFMA GEMM for FEW rows (gfx950): the linear layers around the latent code for one sequence,
 //
-//   forward        h0[M, 5120] = z[perm[M], 2048] . Wd^T + b        (SeqConvVAE.py:62,131-133)
-//   backward-data  dz[M, 2048] = dh0[M, 5120] . Wd                   (its adjoint; the VAE is frozen, optimizer.py:261-270)
+//   forward        pre0[M, T*256] = z[perm[M], 2048] . Wf^T + bf      decoder_input composed with the first decoder conv
+//                                                                     (compose_front, gem_api.hip; SeqConvVAE.py:62,67-75,131-135)
+//   backward-data  dz[M, 2048]    = dpre0[M, T*256] . Wf              (its adjoint; the VAE is frozen, optimizer.py:261-270)
 //
+// (or the separate decoder_input products [M, 2048] x [2048, 5120] and back when the composition is off; the shapes quoted
+// below are those)
 // with M = the windows that are still iterating (<= 240 for BASELINE configs[1]).  A 64x64-tiled GEMM has 4 row tiles here:
 // it needs split-K 4..10 to give every CU work (20-40 MB of fp32 slabs per launch plus a reduce pass), pays for 256 rows
 // whenever more than 192 windows are active, and hides HBM latency only through 5 co-resident workgroups per CU.
