@@ -784,6 +784,30 @@ def test_one_sequence_batches_take_the_row_streaming_gemm(torch_cuda, B):
     assert np.isfinite(out.cpu().numpy()).all()
 
 
+def test_fused_compaction_is_bitwise_the_compact_kernel(torch_cuda, tmp_path):
+    """In the one-sequence fp32 rounds the first launch of a round (gemm_rows.h, FUSE) re-packs the windows that are still
+    iterating itself; GEM_NO_FUSED_COMPACT=1 (read once per process) keeps compact_kernel.  Both are stable partitions, so whole
+    stages -- local and global, 64 / 240 / 300 windows -- must come out bit for bit the same (tools/check_fused_compaction.py,
+    one child process per setting)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for tag, extra in (("fused", {}), ("kernel", {"GEM_NO_FUSED_COMPACT": "1"})):
+        env = dict(os.environ, **extra)
+        env.pop("GEM_NO_FUSED_COMPACT", None) if not extra else None
+        path = str(tmp_path / ("%s.npz" % tag))
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_fused_compaction.py"), path], env=env, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(path))
+    a, b = outs
+    assert set(a.files) == set(b.files) and len(a.files) == 12
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k
+    assert (a["stats_240_0"][:, 3] == 1).all() and a["stats_240_0"][:, 1].mean() > 25
+
+
 @pytest.mark.parametrize("B", [400, 1280])
 def test_batches_between_the_regimes_agree_with_a_small_batch(torch_cuda, B):
     """400..1280 windows in fp32: too many rows for the few-rows GEMM, still few enough workgroups for the fused tail -- the
