@@ -34,10 +34,16 @@ __device__ __forceinline__ void energy_sync() {
 template <bool BLOCK_SYNC, int NT = 64>
 __device__ __forceinline__ void energy_window(const EnergyArgs& a, int b, int lane, const float* xsrc, int ldx, float* xs,
                                               float* gs, float* bs, float* as, float* gdst, int ldg, int gcols,
-                                              uint16_t* gdst_b = nullptr) {
+                                              uint16_t* gdst_b = nullptr, const float* x0_w = nullptr, const float* mb_w = nullptr,
+                                              const int* par_w = nullptr, const int* ch_w = nullptr) {
     static_assert(NT == 64 || BLOCK_SYNC, "more than one wavefront per window needs workgroup barriers");
     const int T = a.T, J = a.J, JC = J * 3, n = T * JC;
-    const float* x0 = a.X0 + (size_t)b * n;
+    // x0_w / mb_w / par_w / ch_w: this window's stage-input pose, mean bone lengths and the skeleton tables when the caller has
+    // already brought them on chip (the fused tail loads them into LDS while its first layers run); else from global memory
+    const float* x0 = x0_w ? x0_w : a.X0 + (size_t)b * n;
+    const float* mbone = mb_w ? mb_w : a.mean_bone + (size_t)b * J;
+    const int* parents = par_w ? par_w : a.parents;
+    const int* children = ch_w ? ch_w : a.children;
 
     double e3d = 0, esm = 0, ebone = 0, evae = 0, erep = 0;
     for (int e = lane; e < n; e += NT) {
@@ -63,12 +69,12 @@ __device__ __forceinline__ void energy_window(const EnergyArgs& a, int b, int la
     // bone length: per (t, joint)
     for (int p = lane; p < T * J; p += NT) {
         const int t = p / J, j = p - t * J;
-        const int par = a.parents[j];
+        const int par = parents[j];
         const float* xj = xs + (t * J + j) * 3;
         const float* xp = xs + (t * J + par) * 3;
         const float bx = xj[0] - xp[0], by = xj[1] - xp[1], bz = xj[2] - xp[2];
         const float len = sqrtf(bx * bx + by * by + bz * bz);
-        const float diff = len - a.mean_bone[(size_t)b * J + j];
+        const float diff = len - mbone[j];
         ebone += (double)(diff * diff);
         const float coef = len > 0.f ? 2.f * a.wb * diff / len : 0.f;     // d|v|/dv := 0 at v = 0 (torch)
         float* o = bs + (t * J + j) * 3;
@@ -88,7 +94,7 @@ __device__ __forceinline__ void energy_window(const EnergyArgs& a, int b, int la
     for (int p = lane; p < T * J; p += NT) {
         const int t = p / J, j = p - t * J;
         float gx = bs[p * 3 + 0], gy = bs[p * 3 + 1], gz = bs[p * 3 + 2];
-        const int* ch = a.children + j * MAXJ;
+        const int* ch = children + j * MAXJ;
         for (int q = 0; q < MAXJ && ch[q] >= 0; ++q) {
             const float* o = bs + (t * J + ch[q]) * 3;
             gx -= o[0]; gy -= o[1]; gz -= o[2];

@@ -313,7 +313,7 @@ struct TailArgs {
     float* g_out;            // [B*T, K0] gradient w.r.t. its pre-activation
     uint16_t* g_out_b;       // the same as bf16 (bf16 decoder mode: consumed by the bf16 backward GEMMs) or nullptr
     float* Xp;               // [B*T, 64] decoded pose
-    int off_act[TAIL_MAX_LAYERS + 1], ld_act[TAIL_MAX_LAYERS + 1], off_g[2], ld_g, off_red, off_escr, off_zero;   // LDS plan (floats)
+    int off_act[TAIL_MAX_LAYERS + 1], ld_act[TAIL_MAX_LAYERS + 1], off_g[2], ld_g, off_red, off_escr, off_zero, off_pre;   // LDS plan (floats); off_pre: per-window inputs of the energy terms (G == 1)
     EnergyArgs e;
 };
 size_t plan_tail(const std::vector<Layer>& dec, int start, int T, int J, TailArgs* out);

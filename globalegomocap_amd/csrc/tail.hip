@@ -226,6 +226,17 @@ __global__ __launch_bounds__(TAIL_THREADS, 2) void decoder_tail_kernel(TailArgs 
         }
         if (tid < 64) lds[a.off_zero + tid] = 0.f;            // the zero line the padded conv rows read
     }
+    // What the energy terms need besides the decoded pose does not depend on the layers: requested now (registers), parked in LDS
+    // behind the first layer -- instead of two global round trips between the last forward layer and the first adjoint layer.
+    float pre_x0 = 0.f, pre_mb = 0.f;
+    int pre_par = 0, pre_ch = -1;
+    const bool pre_on = a.G == 1 && !a.forward_only;
+    if (pre_on) {
+        const int J = a.e.J, n = T * J * 3, bw = a.e.perm ? a.e.perm[w0] : w0;
+        if (tid < n) pre_x0 = a.e.X0[(size_t)bw * n + tid];
+        if (tid < J) { pre_mb = a.e.mean_bone[(size_t)bw * J + tid]; pre_par = a.e.parents[tid]; }
+        if (tid < J * MAXJ) pre_ch = a.e.children[tid];
+    }
     TAIL_PROBE();
     __syncthreads();
     TAIL_PROBE();
@@ -251,6 +262,14 @@ __global__ __launch_bounds__(TAIL_THREADS, 2) void decoder_tail_kernel(TailArgs 
                           if (Xp && r0 + e < R) Xp[(row0 + r0 + e) * PAD + col] = v;
                       }
                   });
+        if (i == 0 && pre_on) {
+            const int J = a.e.J, n = T * J * 3;
+            float* pre = lds + a.off_pre;
+            int* prei = reinterpret_cast<int*>(pre + n + J);
+            if (tid < n) pre[tid] = pre_x0;
+            if (tid < J) { pre[n + tid] = pre_mb; prei[tid] = pre_par; }
+            if (tid < J * MAXJ) prei[J + tid] = pre_ch;
+        }
         __syncthreads();
         TAIL_PROBE();
     }
@@ -262,8 +281,12 @@ __global__ __launch_bounds__(TAIL_THREADS, 2) void decoder_tail_kernel(TailArgs 
     if (a.G == 1) {
         // one window per workgroup: all eight wavefronts share its energy terms
         float* scr = lds + a.off_escr;
+        const int J = a.e.J, n = T * J * 3;
+        const float* pre = lds + a.off_pre;
+        const int* prei = reinterpret_cast<const int*>(pre + n + J);
         energy_window<true, TAIL_THREADS>(a.e, a.e.perm ? a.e.perm[w0] : w0, tid, lds + a.off_act[NL], a.ld_act[NL], scr,
-                                          scr + a.escr, scr + 2 * a.escr, scr + 3 * a.escr, g_cur, a.ld_g, a.fwd[NL - 1].N);
+                                          scr + a.escr, scr + 2 * a.escr, scr + 3 * a.escr, g_cur, a.ld_g, a.fwd[NL - 1].N,
+                                          nullptr, pre, pre + n, prei, prei + J);
     } else if (wave < nwin) {
         float* scr = lds + a.off_escr + wave * 4 * a.escr;
         energy_window<false>(a.e, a.e.perm ? a.e.perm[w0 + wave] : w0 + wave, lane,
@@ -334,6 +357,8 @@ size_t plan_tail(const std::vector<Layer>& dec, int start, int T, int J, TailArg
     off += a.G * 4 * a.escr;
     a.off_zero = off;                      // 64 zero floats
     off += 64;
+    a.off_pre = off;                       // G == 1: stage-input pose, mean bone lengths, parent / children tables of the window
+    if (a.G == 1) off += (T * J * 3 + 2 * J + J * MAXJ + 3) / 4 * 4;
     if (out) *out = a;
     return (size_t)off * sizeof(float);
 }
