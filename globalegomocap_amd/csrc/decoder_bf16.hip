@@ -172,21 +172,66 @@ int evaluate_bf16(gem_handle* h, int stage, int B, const EnergyArgs& ea_in, hipS
     StageNet& net = h->net[stage];
     Workspace& w = h->ws;
     const int T = h->T, rows = B * T, n_dec = (int)net.dec.size();
-    static const bool force_tail = getenv("GEM_FORCE_TAIL") != nullptr;
+    static const bool force_tail = dev_env("GEM_FORCE_TAIL") != nullptr;
     const int tail_g = T <= 16 ? 16 / T : 1;
     const int tail_wgs = (B + tail_g - 1) / tail_g;
-    const bool use_tail = net.tail_start >= 1 && (tail_wgs <= 5 * h->n_cu || force_tail);
+    // Three ways to run the narrow layers + energies: the bf16 multi-window tail (tail_bf16.hip: 8 windows per workgroup, one
+    // launch), the fp32 one-window tail (tail.hip: lowest latency for a few hundred windows), or batched bf16 GEMMs + the
+    // stand-alone energy kernel (networks the tails do not cover).  GEM_TAIL16=1 / 0 forces / forbids the first (GEM_DEV=1).
+    const char* t16_env = dev_env("GEM_TAIL16");       // (read per call: the tests flip it inside one process)
+    const bool batched_narrow = dev_env("GEM_BATCHED_NARROW") != nullptr;      // neither tail: every layer a batched GEMM (A/B runs, tests)
+    const int t16_min = 8 * 32;                      // from 32 workgroups on the multi-window tail wins (measured: DESIGN.md 4)
+    const bool use_tail16 = net.tb_stream && net.tail_start >= 1 && !batched_narrow && !(t16_env && t16_env[0] == '0') &&
+                            (B >= t16_min || (t16_env && t16_env[0] == '1'));
+    const bool use_tail = !use_tail16 && !batched_narrow && net.tail_start >= 1 && (tail_wgs <= 5 * h->n_cu || force_tail);
     const int* perm = w.dyn ? w.perm : nullptr;
     w.grad_slab = SlabSrc{};
     // decoder_input o conv 0 as ONE product where the weights were composed (compose_front in gem_api.hip), else
     // decoder_input: [B, Dp] x [Dp, T*topp] -> h0 [B*T, topp] bf16 (rows of finished windows are skipped through perm)
-    static const bool no_front = getenv("GEM_NO_FRONT_BF16") != nullptr;          // developer override (A/B runs)
-    const bool front = net.front.wb_hi && n_dec > 1 && !no_front && (!use_tail || net.tail_start == 1);
+    static const bool no_front = dev_env("GEM_NO_FRONT_BF16") != nullptr;          // developer override (A/B runs)
+    const bool front = net.front.wb_hi && n_dec > 1 && !no_front && ((!use_tail && !use_tail16) || net.tail_start == 1);
     const uint16_t* in = w.h0_b;
     EnergyArgs ea = ea_in;
     int back_from;                     // first layer of the batched backward chain
     const uint16_t* gin;
     if (!front && gemm_bf16a(h, net.dec_in, EPI_BIAS, w.trial_b, h->Dp, nullptr, w.h0_b, true, net.dec_in.N, B, s, 0, perm, true, false)) return 1;
+    if (use_tail16) {
+        const int st = net.tail_start;
+        SlabSrc in_slab;
+        // the layer in front of the tail: in the rounds its fp32 split-K slabs (if it was cut) go straight to the tail, which sums
+        // them and applies bias + LeakyReLU while staging; otherwise it writes the bf16 activation itself
+        if (front) {
+            if (gemm_bf16a(h, net.front, EPI_BIAS_LRELU, w.trial_b, h->Dp, nullptr, w.dec_act_b[0], true, net.front.N, B, s, 0, perm, true, w.dyn))
+                return 1;
+            in_slab = w.deferred;
+        }
+        for (int i = 0; i < st && !front; ++i) {
+            const bool last_wide = i == st - 1;
+            if (gemm_bf16a(h, net.dec[i], EPI_BIAS_LRELU, in, net.dec[i].K, nullptr, w.dec_act_b[i], true, net.dec[i].N, rows, s, -1, nullptr,
+                           true, last_wide && w.dyn)) return 1;
+            if (last_wide) in_slab = w.deferred;
+            in = w.dec_act_b[i];
+        }
+        TailB16Args ta;
+        plan_tail_bf16(net.dec, st, T, h->J, &ta);
+        ta.B = B; ta.forward_only = forward_only ? 1 : 0;
+        ta.in_slab = in_slab; ta.in_bias = front ? net.front.bias : net.dec[st - 1].bias;
+        ta.in_bias_ld = front ? net.dec[0].N : 0;
+        for (int i = 0; i < ta.n; ++i) {
+            const Layer& f = net.dec[st + i];
+            const Layer& g = net.dec_bwd[st + i];
+            ta.fwd[i] = TailB16Layer{f.K, f.N, f.bias};
+            ta.bwd[i] = TailB16Layer{g.K, g.N, nullptr};
+        }
+        ta.a_in_b = w.dec_act_b[st - 1]; ta.g_out_b = w.dec_grad_b[st];
+        ta.Xp = (w.dyn && !forward_only) ? nullptr : w.dec_act.back();
+        ta.wstream = net.tb_stream; ta.steps_f = net.tb_steps_f; ta.steps_total = net.tb_steps_f + net.tb_steps_b;
+        ta.e = ea;
+        if (launch_tail_bf16(h, ta, net.tb_lds, s)) return 1;
+        if (forward_only) return 0;
+        back_from = st - 1;
+        gin = w.dec_grad_b[st];
+    } else
     if (use_tail) {
         const int st = net.tail_start;
         SlabSrc in_slab;

@@ -534,7 +534,7 @@ int launch_lift(gem_handle* h, const float* heat, const double* depth, int F, co
     }
     const int Jr = a.J / (a.J % 4 == 0 ? 4 : a.J % 2 == 0 ? 2 : 1);      // J / gcd(J, 4)
     const int A = 256 / Jr * Jr;
-    static const bool simple = getenv("GEM_LIFT_SIMPLE") != nullptr;
+    static const bool simple = dev_env("GEM_LIFT_SIMPLE") != nullptr;
     if (!simple && (a.H * a.W * a.J) % 4 == 0 && 4 * A / a.J <= 80 && (reinterpret_cast<uintptr_t>(heat) & 15) == 0)
         hipLaunchKernelGGL(lift_skeleton_stream_kernel, dim3(F), dim3(256), 0, s, a, A);
     else

@@ -20,6 +20,18 @@ bool hip_ok(hipError_t e, const char* what) {
     return false;
 }
 
+const char* dev_env(const char* name) {
+    const char* on = getenv("GEM_DEV");
+    if (!on || on[0] != '1') return nullptr;
+    return getenv(name);
+}
+
+// Every captured call bakes weight and workspace pointers into its kernel arguments: whatever re-allocates them drops the cache.
+static void drop_graphs(gem_handle* h) {
+    for (auto& g : h->graphs) { if (g.exec) (void)hipGraphExecDestroy(g.exec); if (g.graph) (void)hipGraphDestroy(g.graph); }
+    h->graphs.clear();
+}
+
 template <typename T>
 static int dev_alloc(std::vector<void*>& owner, T** p, size_t n) {
     void* q = nullptr;
@@ -96,7 +108,8 @@ static FoldedConv fold_conv(const float* w, const float* b, const float* bn /* 4
     return f;
 }
 
-static int make_conv_layers(StageNet& net, const FoldedConv& f, Layer* fwd, Layer* bwd) {
+static int make_conv_layers(StageNet& net, const FoldedConv& f, Layer* fwd, Layer* bwd, std::vector<float>* keep_fwd = nullptr,
+                            std::vector<float>* keep_bwd = nullptr) {
     const int Kp = pad64(f.ci), Np = pad64(f.co);
     std::vector<float> wf((size_t)3 * Np * Kp, 0.f), bf(Np, 0.f);
     for (int k = 0; k < 3; ++k)
@@ -123,7 +136,9 @@ static int make_conv_layers(StageNet& net, const FoldedConv& f, Layer* fwd, Laye
         if (upload(net.allocs, &bwd->w, wb) || upload(net.allocs, &bwd->w4, to_w4(wb, Kp, Np)) || upload_bf16(net.allocs, bwd, wb))
             return 1;
         bwd->bias = nullptr;
+        if (keep_bwd) *keep_bwd = std::move(wb);
     }
+    if (keep_fwd) *keep_fwd = std::move(wf);
     return 0;
 }
 
@@ -295,7 +310,7 @@ void gem_destroy(gem_handle* h) {
     (void)hipSetDevice(h->cfg.device);
     (void)hipDeviceSynchronize();
     for (auto& r : h->prof.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
-    for (auto& g : h->graphs) { if (g.exec) (void)hipGraphExecDestroy(g.exec); if (g.graph) (void)hipGraphDestroy(g.graph); }
+    drop_graphs(h);
     free_all(h->net[0].allocs);
     free_all(h->net[1].allocs);
     free_all(h->ws.allocs);
@@ -327,6 +342,7 @@ int gem_load_vae(gem_handle* h, int stage, int n_blobs, const float* const* blob
 
     StageNet& net = h->net[stage];
     if (net.loaded) GEM_HIP(hipDeviceSynchronize());      // reloading: launches that still read the old weights must be done
+    drop_graphs(h);                                       // captured calls hold pointers to the weights freed below
     free_all(net.allocs);
     net = StageNet();
     int bi = 0;
@@ -384,7 +400,9 @@ int gem_load_vae(gem_handle* h, int stage, int n_blobs, const float* const* blob
         bi += bn ? 6 : 2;
         if (net.dec.empty()) first_conv = f;
         Layer Lf, Lb;
-        if (make_conv_layers(net, f, &Lf, &Lb)) return 1;
+        net.host_fwd.emplace_back();
+        net.host_bwd.emplace_back();
+        if (make_conv_layers(net, f, &Lf, &Lb, &net.host_fwd.back(), &net.host_bwd.back())) return 1;
         net.dec.push_back(Lf);
         net.dec_bwd.push_back(Lb);
         return 0;
@@ -397,14 +415,18 @@ int gem_load_vae(gem_handle* h, int stage, int n_blobs, const float* const* blob
     net.tail_start = -1;
     // The chain may start at conv 0 (GEM_TAIL_START=0), but its 512x256 weights (3 MB per workgroup and round from
     // L2) cost more than the batched GEMM they replace: 13.4 k vs 14.3 k windows/s at 240 windows.
-    const int first = getenv("GEM_TAIL_START") ? atoi(getenv("GEM_TAIL_START")) : 1;
-    if (!getenv("GEM_NO_TAIL"))
+    const int first = dev_env("GEM_TAIL_START") ? atoi(dev_env("GEM_TAIL_START")) : 1;
+    if (!dev_env("GEM_NO_TAIL"))
         for (int st = first; st < (int)net.dec.size(); ++st) {
             const size_t bytes = plan_tail(net.dec, st, T, h->J, nullptr);
             if (bytes && bytes <= 160 * 1024) { net.tail_start = st; net.tail_lds = bytes; break; }
         }
     // decoder_input o conv 0 as one layer, when the tail takes over right behind conv 0 (GEM_NO_FRONT=1 keeps the two layers)
-    if (net.tail_start == 1 && !getenv("GEM_NO_FRONT") && compose_front(h, net, first_conv, dec_in_bias_tm.data())) return 1;
+    if (net.tail_start == 1 && !dev_env("GEM_NO_FRONT") && compose_front(h, net, first_conv, dec_in_bias_tm.data())) return 1;
+    // the same tail layers as per-wave bf16 fragment streams for the multi-window bf16 tail (tail_bf16.hip)
+    if (build_tail_bf16_stream(h, net)) return 1;
+    net.host_fwd.clear(); net.host_fwd.shrink_to_fit();
+    net.host_bwd.clear(); net.host_bwd.shrink_to_fit();
     net.loaded = true;
     return 0;
 }
@@ -505,7 +527,7 @@ static int evaluate(gem_handle* h, int stage, int B, const float* zp, const Ener
     // (fp32, windows/s: 480 windows 19.6 k vs 16.7 k, 960 windows 21.7 k vs 20.6 k, 1500 windows 23.4 k vs 23.7 k).
     // GEM_FORCE_TAIL=1 keeps it on for any batch.
     if (h->precision == GEM_PRECISION_BF16) return evaluate_bf16(h, stage, B, ea, s, forward_only);      // zp == ws.trial, mirrored in ws.trial_b
-    static const bool force_tail = getenv("GEM_FORCE_TAIL") != nullptr;
+    static const bool force_tail = dev_env("GEM_FORCE_TAIL") != nullptr;
     const int tail_g = h->T <= 16 ? 16 / h->T : 1;
     const int tail_wgs = (B + tail_g - 1) / tail_g;
     const int tail_cap = 5 * h->n_cu;
@@ -584,13 +606,13 @@ static int optimize_stage_impl(gem_handle* h, int stage, int B, const float* d_p
     if (launch_lbfgs_init(h, B, opt, s)) return 1;
     // Rounds run on the windows that are still iterating: after every advance they are re-packed to the front
     // (perm / n_active on the device) and the kernels of the next round read their row count from there.
-    static const bool no_compact = getenv("GEM_NO_COMPACT") != nullptr;
+    static const bool no_compact = dev_env("GEM_NO_COMPACT") != nullptr;
     if (!no_compact) {
         if (launch_compact(h, B, 1, s)) return 1;
         w.dyn = true;
     }
     // texel-block cache of the reprojection term: valid for this stage's heat-maps / windows only
-    static const bool no_tex = getenv("GEM_NO_TEXCACHE") != nullptr;
+    static const bool no_tex = dev_env("GEM_NO_TEXCACHE") != nullptr;
     w.tex_on = !no_tex && h->tex_cache && w.tex_key && wt.reproj != 0.0;
     if (w.tex_on) GEM_HIP(hipMemsetAsync(w.tex_key, 0xFF, (size_t)B * h->T * h->J * sizeof(int), s));
     const EnergyArgs ea = energy_args(h, d_pose_in, d_heat, d_frame0, d_mean_bone, wt);
@@ -638,7 +660,8 @@ static int optimize_stage_impl(gem_handle* h, int stage, int B, const float* d_p
 // the second one is captured into a hipGraph and instantiated, every later one is a single hipGraphLaunch: the host cost of a
 // call drops from ~3 ms of launches to one launch (BASELINE configs[4]; several sequences in flight from one host thread).
 static bool same_key(const GraphKey& a, const GraphKey& b) {
-    if (a.kind != b.kind || a.stage != b.stage || a.B != b.B || a.precision != b.precision || a.stream != b.stream) return false;
+    if (a.kind != b.kind || a.stage != b.stage || a.B != b.B || a.precision != b.precision || a.stream != b.stream || a.tex_cache != b.tex_cache)
+        return false;
     for (int i = 0; i < 12; ++i)
         if (a.ptr[i] != b.ptr[i]) return false;
     return std::memcmp(a.w, b.w, sizeof(a.w)) == 0 && std::memcmp(&a.opt, &b.opt, sizeof(a.opt)) == 0;
@@ -740,7 +763,7 @@ int gem_optimize_stage(gem_handle* h, int stage, int B, const float* d_pose_in, 
     if (B == 0) return 0;
     if (!d_pose_in || !d_mean_bone || !wt || !opt || !d_pose_out) { set_error("gem_optimize_stage: null argument"); return 1; }
     GraphKey key;
-    key.kind = 1; key.stage = stage; key.B = B; key.precision = h->precision; key.stream = stream;
+    key.kind = 1; key.stage = stage; key.B = B; key.precision = h->precision; key.stream = stream; key.tex_cache = h->tex_cache;
     const void* ptrs[] = {d_pose_in, d_heat, d_frame0, d_mean_bone, d_eps, d_pose_out, d_stats};
     for (int i = 0; i < 7; ++i) key.ptr[i] = ptrs[i];
     key.w[0] = *wt; key.opt = *opt;
@@ -762,7 +785,7 @@ int gem_optimize_windows(gem_handle* h, int B, const float* d_local_pose, const 
     hipStream_t s = (hipStream_t)stream;
     if (B == 0) return 0;
     GraphKey key;
-    key.kind = 2; key.B = B; key.precision = h->precision; key.stream = stream;
+    key.kind = 2; key.B = B; key.precision = h->precision; key.stream = stream; key.tex_cache = h->tex_cache;
     const void* ptrs[] = {d_local_pose, d_cams, d_heat, d_frame0, d_mean_bone, d_eps_local, d_eps_global, d_mid_local, d_global, d_stats};
     for (int i = 0; i < 10; ++i) key.ptr[i] = ptrs[i];
     key.w[0] = *w_local; key.w[1] = *w_global; key.opt = *opt;
@@ -890,7 +913,7 @@ int gem_profile_read(gem_handle* h, int family, double* total_ms, int64_t* n_lau
             }
             if (h->ws.log_pos - r.log_idx <= N_LOG) r.flops = r.flops_per_window * nlog[r.log_idx % N_LOG];
         }
-        static const char* dump = getenv("GEM_PROFILE_DUMP");          // developer aid: one line per timed launch
+        static const char* dump = dev_env("GEM_PROFILE_DUMP");          // developer aid: one line per timed launch
         if (dump) {
             if (FILE* f = fopen(dump, "a")) {
                 fprintf(f, "%d %d %.3f\n", r.family, r.log_idx >= 0 && !nlog.empty() ? nlog[r.log_idx % N_LOG] : -1, ms * 1e3);

@@ -21,6 +21,9 @@ constexpr int TRACE_ROUNDS = 64;           // evaluation rounds whose closure va
 inline int pad64(int x) { return (x + PAD - 1) / PAD * PAD; }
 
 void set_error(const std::string& msg);
+// Developer switches (A/B runs, sweeps, forcing a kernel path in the tests) are read from the environment ONLY when GEM_DEV=1 is
+// set as well: a stray variable in a production environment cannot change which kernels evaluate the network.
+const char* dev_env(const char* name);
 bool hip_ok(hipError_t e, const char* what);
 #define GEM_HIP(call) do { if (!gem::hip_ok((call), #call)) return 1; } while (0)
 
@@ -52,6 +55,12 @@ struct StageNet {
     Layer front, front_bwd;
     int tail_start = -1;           // decoder convs [tail_start, end) run in the fused tail kernel (-1: none)
     size_t tail_lds = 0;
+    // bf16 multi-window tail (tail_bf16.hip): the same layers' weights as bf16 MFMA fragments in the order each of the 8 waves
+    // consumes them, forward layers then adjoint layers: [8][tb_steps_f + tb_steps_b][64 lanes][8 bf16]; nullptr: not available
+    uint16_t* tb_stream = nullptr;
+    int tb_steps_f = 0, tb_steps_b = 0;
+    size_t tb_lds = 0;
+    std::vector<std::vector<float>> host_fwd, host_bwd;   // [3][N][K] padded fp32 weights of the decoder convs / their adjoints (load time only)
     std::vector<void*> allocs;
 };
 
@@ -187,6 +196,7 @@ namespace gem {
 // kernel arguments -- entry point, batch size, precision, every caller pointer, the energy weights and optimiser options
 struct GraphKey {
     int kind = 0, stage = 0, B = 0, precision = 0;
+    bool tex_cache = true;
     const void* ptr[12] = {};
     gem_energy_weights w[2] = {};
     gem_lbfgs_opts opt = {};
@@ -317,6 +327,29 @@ struct TailArgs {
     EnergyArgs e;
 };
 size_t plan_tail(const std::vector<Layer>& dec, int start, int T, int J, TailArgs* out);
+
+// bf16 multi-window fused tail (tail_bf16.hip): G = min(8, 80 / T) windows = up to 80 rows (five 16-row MFMA tiles) per workgroup
+constexpr int TB_MAX_LAYERS = 6;
+struct TailB16Layer { int K, N; const float* bias; };
+struct TailB16Args {
+    int n, B, G, forward_only, mask_first;
+    SlabSrc in_slab;           // the input still lies in fp32 split-K slabs (+ in_bias, LeakyReLU to apply) when in_slab.base != nullptr
+    const float* in_bias;      // bias of row r, column c: in_bias[(r % T) * in_bias_ld + c]
+    int in_bias_ld;
+    const uint16_t* a_in_b;    // [B*T, K0] bf16 input activation (post-LeakyReLU) when there are no slabs
+    uint16_t* g_out_b;         // [B*T, K0] bf16 gradient w.r.t. the input's pre-activation
+    float* Xp;                 // [B*T, 64] decoded pose (fp32) or nullptr
+    const uint16_t* wstream;   // StageNet::tb_stream
+    int steps_f, steps_total;  // steps (1 KB fragments) per wave: forward part / forward + adjoint
+    TailB16Layer fwd[TB_MAX_LAYERS], bwd[TB_MAX_LAYERS];
+    // LDS plan, byte offsets / row strides in bytes (row stride = 2 * width + 32: conflict-free ds_read_b128 fragment reads)
+    int off_act[TB_MAX_LAYERS + 1], ld_act[TB_MAX_LAYERS + 1];      // act[0] = input (region shared with the energy scratch / output staging)
+    int off_g[2], ld_g[2], off_x, off_escr, escr, off_zero, off_mask, ld_mask;
+    EnergyArgs e;
+};
+size_t plan_tail_bf16(const std::vector<Layer>& dec, int start, int T, int J, TailB16Args* out);
+int build_tail_bf16_stream(gem_handle* h, StageNet& net);
+int launch_tail_bf16(gem_handle* h, const TailB16Args& a, size_t lds_bytes, hipStream_t s);
 int launch_tail(gem_handle* h, const TailArgs& a, size_t lds_bytes, hipStream_t s);
 int launch_mean_bone(gem_handle* h, const float* pose, int n_frames, float* out, hipStream_t s);
 int launch_gather_windows(const float* frames, const int32_t* frame0, float* out, int B, int T, int JC, hipStream_t s);

@@ -321,7 +321,7 @@ static int launch_b(gem_handle* h, const Layer& L, const float* A, int lda, cons
     const int* m_dev = h->ws.dyn ? h->ws.n_active + (TAPS == 3 ? 1 : 0) : nullptr;
     constexpr int BK = 64;
     // 128x128 tiles once they fill the chip (developer override GEM_BF16_TILE=1 / 2 forces 64x64 / 128x128)
-    static const char* force = getenv("GEM_BF16_TILE");
+    static const char* force = dev_env("GEM_BF16_TILE");
     const long big_blocks = (long)((M + 127) / 128) * (L.N / 128);
     if (L.N % 128 == 0 && ((force && force[0] == '2') || (!(force && force[0] == '1') && big_blocks >= 256))) {
         auto kb = gemm_bf16_big_kernel<TAPS, EPI, NPROD>;

@@ -272,7 +272,7 @@ constexpr int LDS_PER_CU = 160 * 1024;
 int pick_splitk(const gem_handle* h, long blocks, int n_tiles, size_t slab_elems) {
     const int N_CU = h->n_cu;             // compute units of this handle's device
     if (!h->ws.splitk || blocks >= 3 * N_CU) return 1;
-    static const int force = getenv("GEM_FORCE_SK") ? atoi(getenv("GEM_FORCE_SK")) : 0;      // developer override (sweeps)
+    static const int force = dev_env("GEM_FORCE_SK") ? atoi(dev_env("GEM_FORCE_SK")) : 0;      // developer override (sweeps)
     if (force > 0 && n_tiles / force >= 4 && (size_t)force * slab_elems <= h->ws.splitk_elems) return force;
     int best = 1;
     double best_score = -1.0;
@@ -405,8 +405,8 @@ static int launch_rows_as(gem_handle* h, const Layer& L, const float* A, int lda
 
 // the cut for a linear layer with M rows, or false when this kernel is not the one for the shape
 static bool rows_plan(const gem_handle* h, const Layer& L, int lda, int ldc, int M, bool slabs, rows::Plan* out, bool* use8) {
-    static const bool off = getenv("GEM_NO_ROWS") != nullptr;                 // developer overrides (A/B runs)
-    static const char* only = getenv("GEM_ROWS_ONLY");                        // "fwd": direct-output launches only
+    static const bool off = dev_env("GEM_NO_ROWS") != nullptr;                 // developer overrides (A/B runs)
+    static const char* only = dev_env("GEM_ROWS_ONLY");                        // "fwd": direct-output launches only
     if (off || M < 48 || L.N % rows::BN != 0 || L.K % rows::BK != 0 || (size_t)h->ws.Bmax * lda * 4 >= ((size_t)1 << 32) ||
         (size_t)L.N * L.K * 4 >= ((size_t)1 << 32))
         return false;
@@ -415,7 +415,7 @@ static bool rows_plan(const gem_handle* h, const Layer& L, int lda, int ldc, int
     const rows::Plan p8 = rows::plan(M, L.N, L.K, 8, h->n_cu, slabs, h->ws.splitk_elems, ldc);
     *use8 = p8.n_rb > 0 && (p5.n_rb == 0 || p8.cost < p5.cost - 1e-9);          // ties: the smaller ring
     *out = *use8 ? p8 : p5;
-    static const char* force = getenv("GEM_ROWS_FORCE");      // developer override: "N:n_rb,n_split" for layers with that N
+    static const char* force = dev_env("GEM_ROWS_FORCE");      // developer override: "N:n_rb,n_split" for layers with that N
     if (force) {
         int fn = 0, frb = 0, fsk = 0;
         if (sscanf(force, "%d:%d,%d", &fn, &frb, &fsk) == 3 && fn == L.N && frb > 0 && fsk > 0 && (fsk == 1 || slabs)) {
@@ -432,7 +432,7 @@ static bool rows_plan(const gem_handle* h, const Layer& L, int lda, int ldc, int
 // Will the decoder_input forward product of a B-window round run in the few-rows kernel, so that it can re-pack the active
 // windows itself (no compact_kernel launch between the rounds)?
 bool rows_can_fuse_compaction(const gem_handle* h, const Layer& L, int lda, int ldc, int B, bool slabs) {
-    static const bool off = getenv("GEM_NO_FUSED_COMPACT") != nullptr;        // developer override (A/B runs)
+    static const bool off = dev_env("GEM_NO_FUSED_COMPACT") != nullptr;        // developer override (A/B runs)
     rows::Plan p;
     bool use8;
     return !off && h->precision == GEM_PRECISION_F32 && B <= rows::FUSE_MAX_WINDOWS &&
@@ -473,13 +473,13 @@ static int launch_tile(gem_handle* h, const Layer& L, const float* A, int lda, c
         const int rc = launch_rows<EPI>(h, L, A, lda, aux, C, ldc, M, s, row_map);
         if (rc >= 0) return rc;
     }
-    static const bool no_glds = getenv("GEM_NO_GLDS_F32") != nullptr;          // developer override (A/B runs)
+    static const bool no_glds = dev_env("GEM_NO_GLDS_F32") != nullptr;          // developer override (A/B runs)
     if (!no_glds && L.N % 128 == 0 && L.K % 32 == 0 && (long)((M + 127) / 128) * (L.N / 128) >= 3L * h->n_cu / 2 && h->ws.zero16 &&
         !h->ws.defer_reduce)
         return launch_glds_f32<TAPS, EPI>(h, L, A, lda, aux, C, ldc, M, T, s, row_map);
     // 128x128 tiles only when they still fill the chip (>= 2 workgroups per CU) and divide N
     const long big_blocks = (long)((M + 127) / 128) * (L.N / 128);
-    static const char* force = getenv("GEM_FORCE_TILE");       // developer override: "1" = 64x64, "2" = 128x128, "3" = 64x64 BK64
+    static const char* force = dev_env("GEM_FORCE_TILE");       // developer override: "1" = 64x64, "2" = 128x128, "3" = 64x64 BK64
     if (force && force[0] == '1') return launch_one<TAPS, EPI, 1, 1, TAG, 32>(h, L, A, lda, aux, C, ldc, M, T, s, row_map);
     if (force && force[0] == '2' && L.N % 128 == 0) return launch_one<TAPS, EPI, 2, 2, TAG, 32>(h, L, A, lda, aux, C, ldc, M, T, s, row_map);
     if (force && force[0] == '3' && L.K % 64 == 0) return launch_one<TAPS, EPI, 1, 1, TAG, 64>(h, L, A, lda, aux, C, ldc, M, T, s, row_map);

@@ -230,7 +230,9 @@ __global__ __launch_bounds__(TAIL_THREADS, 2) void decoder_tail_kernel(TailArgs 
     // behind the first layer -- instead of two global round trips between the last forward layer and the first adjoint layer.
     float pre_x0 = 0.f, pre_mb = 0.f;
     int pre_par = 0, pre_ch = -1;
-    const bool pre_on = a.G == 1 && !a.forward_only;
+    // (one element per thread: windows of more than TAIL_THREADS pose values -- T >= 12 with 15 joints -- read their inputs from
+    // global memory inside energy_window instead)
+    const bool pre_on = a.G == 1 && !a.forward_only && T * a.e.J * 3 <= TAIL_THREADS;
     if (pre_on) {
         const int J = a.e.J, n = T * J * 3, bw = a.e.perm ? a.e.perm[w0] : w0;
         if (tid < n) pre_x0 = a.e.X0[(size_t)bw * n + tid];
@@ -286,7 +288,8 @@ __global__ __launch_bounds__(TAIL_THREADS, 2) void decoder_tail_kernel(TailArgs 
         const int* prei = reinterpret_cast<const int*>(pre + n + J);
         energy_window<true, TAIL_THREADS>(a.e, a.e.perm ? a.e.perm[w0] : w0, tid, lds + a.off_act[NL], a.ld_act[NL], scr,
                                           scr + a.escr, scr + 2 * a.escr, scr + 3 * a.escr, g_cur, a.ld_g, a.fwd[NL - 1].N,
-                                          nullptr, pre, pre + n, prei, prei + J);
+                                          nullptr, pre_on ? pre : nullptr, pre_on ? pre + n : nullptr, pre_on ? prei : nullptr,
+                                          pre_on ? prei + J : nullptr);
     } else if (wave < nwin) {
         float* scr = lds + a.off_escr + wave * 4 * a.escr;
         energy_window<false>(a.e, a.e.perm ? a.e.perm[w0 + wave] : w0 + wave, lane,

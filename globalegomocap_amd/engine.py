@@ -100,6 +100,12 @@ class WindowEngine:
             self._bufs[k] = torch.zeros(shape, device=self.device, dtype=dtype)
         return self._bufs[k]
 
+    def _staged(self, key, t):
+        """Copy of `t` in a persistent engine-owned buffer (graph mode: stable pointers for per-call temporaries)."""
+        buf = self._out(key, tuple(t.shape), t.dtype)
+        buf.copy_(t)
+        return buf
+
     def _call(self, fn):
         """Run fn(stream_ptr) on the caller's current stream, or (graphs on) on the engine's stream, ordered after
         everything already enqueued on the current stream and before everything enqueued on it afterwards."""
@@ -199,6 +205,9 @@ class WindowEngine:
         return E, parts, dz, X
 
     def optimize_stage(self, stage, pose_in, mean_bone, eps, weights, heat=None, frame0=None, opts=None, want_stats=True):
+        """One stage for B windows.  With graphs on, the small inputs (pose, mean bone, eps, frame0) are copied into
+        engine-owned buffers so that the call's signature is stable from call to call (replay needs identical pointers);
+        `heat` is passed through as it is and must be the same device tensor to get replays.  Outputs are kept per stage."""
         p = self._f32(pose_in).reshape(-1, self.T, N_JOINTS, 3)
         B = p.shape[0]
         self._check_B(B)
@@ -207,9 +216,12 @@ class WindowEngine:
         heat_t = self._f32(heat) if heat is not None else None
         f0 = self._i32(frame0) if frame0 is not None else None
         self._check_heat(heat_t, frame0, B)
+        if self._graphs:
+            p, mb, eps_t = (self._staged("stage%d_%s" % (stage, k), t) for k, t in (("pose", p), ("mb", mb), ("eps", eps_t)))
+            f0 = self._staged("stage%d_f0" % stage, f0) if f0 is not None else None
         opts = opts or _capi.default_lbfgs_opts()
-        out = self._out("stage_out", (B, self.T, N_JOINTS, 3), torch.float32)
-        stats = self._out("stage_stats", (B, 4), torch.int32, zero=True) if want_stats else None
+        out = self._out("stage%d_out" % stage, (B, self.T, N_JOINTS, 3), torch.float32)
+        stats = self._out("stage%d_stats" % stage, (B, 4), torch.int32, zero=True) if want_stats else None
         self._call(lambda st: _capi.check(self.lib.gem_optimize_stage(self._h, stage, B, _ptr(p), _ptr(heat_t), _ptr(f0), _ptr(mb),
                                                                       _ptr(eps_t), C.byref(weights), C.byref(opts), _ptr(out),
                                                                       _ptr(stats), st), self.lib))
@@ -330,9 +342,23 @@ class WindowEngine:
 
 
 def stats_to_numpy(stats):
-    """[n,4] int32 tensor (n_iter, func_evals, final_loss bits, status) -> structured numpy."""
+    """[n,4] int32 tensor (n_iter, func_evals, final_loss bits, status) -> structured numpy.
+
+    `status` is a bit field (gem_window_stats): bit 0 = the window's L-BFGS finished, bit 1 = a closure value was NaN (a joint
+    on the optical axis: the reference raises "norm is zero!").  `finished` / `degenerate` are those two bits as booleans;
+    `status == 1` therefore reads "finished and not degenerate"."""
     a = stats.cpu().numpy()
-    out = np.zeros(a.shape[0], dtype=[("n_iter", "i4"), ("func_evals", "i4"), ("final_loss", "f4"), ("status", "i4")])
+    out = np.zeros(a.shape[0], dtype=[("n_iter", "i4"), ("func_evals", "i4"), ("final_loss", "f4"), ("status", "i4"),
+                                      ("finished", "?"), ("degenerate", "?")])
     out["n_iter"], out["func_evals"], out["status"] = a[:, 0], a[:, 1], a[:, 3]
     out["final_loss"] = a[:, 2].copy().view(np.float32)
+    out["finished"], out["degenerate"] = (a[:, 3] & 1) != 0, (a[:, 3] & 2) != 0
     return out
+
+
+def raise_if_degenerate(stats):
+    """The reference's `Exception("norm is zero!")` (FishEyeCalibrated.py:124-127) for users of the engine's own calls: pass the
+    stats tensor (or its stats_to_numpy) of optimize_stage / optimize_windows.  Synchronises on the stats."""
+    st = stats if isinstance(stats, np.ndarray) else stats_to_numpy(stats)
+    if st["degenerate"].any() or not np.isfinite(st["final_loss"]).all():
+        raise Exception("norm is zero!")

@@ -19,7 +19,7 @@ import torch
 
 from . import _capi
 from .camera import FisheyeCamera
-from .engine import WindowEngine, energy_weights, stats_to_numpy, LOCAL_STAGE, GLOBAL_STAGE
+from .engine import WindowEngine, energy_weights, stats_to_numpy, raise_if_degenerate, LOCAL_STAGE, GLOBAL_STAGE
 from .errors import calculate_errors
 from .sequence import (SEQ_LEN, OVERLAP, window_starts, cut_windows, merge_batches, final_smooth,
                        relative_global_numpy, to_global_numpy)
@@ -38,8 +38,8 @@ def _as_state_dict(vae):
 def _raise_if_degenerate(stats):
     # a joint exactly on the optical axis makes the projection undefined; the reference raises
     # Exception("norm is zero!") from FishEyeCalibrated.py:124-127; the device latches it in bit 1 of the window status
-    if stats is not None and ((stats["status"] & 2).any() or not np.isfinite(stats["final_loss"]).all()):
-        raise Exception("norm is zero!")
+    if stats is not None:
+        raise_if_degenerate(stats)
 
 
 class BodyPoseOptimizer:

@@ -58,7 +58,12 @@ def list_chunks(data_dir):
 
 SIDE_CACHE = "test_data.cache"          # raw-array cache of test_data.pkl, written next to it (see _write_sidecar)
 _MAGIC = 0x47454D43414348         # "GEMCACH"
-_HDR = 8                          # int64 words: magic, n_frames, H, W, J, n_joint_coords (J*3), reserved x2
+_HDR = 8                          # int64 words: magic, n_frames, H, W, J, n_joint_coords (J*3), size and mtime_ns of the pickle
+
+
+def _pickle_stamp(path):
+    st = os.stat(os.path.join(path, "test_data.pkl"))
+    return int(st.st_size), int(st.st_mtime_ns)
 
 
 def _sidecar_layout(n, H, W, J):
@@ -72,14 +77,14 @@ def _sidecar_layout(n, H, W, J):
 
 def _read_sidecar(path, small=True):
     """(header (n,H,W,J), small arrays or None, cache file, heat offset) when a valid cache of `<chunk>/test_data.pkl` exists,
-    else None.  Valid = at least as new as the pickle, right magic, exactly as long as its header says."""
+    else None.  Valid = right magic, made from a pickle of EXACTLY this size and modification time (the header records both:
+    a pickle replaced by `cp -p` / `rsync -t` / a restore, i.e. with an older time stamp, invalidates the cache too), exactly
+    as long as its header says."""
     cache = os.path.join(path, SIDE_CACHE)
     try:
-        if os.path.getmtime(cache) < os.path.getmtime(os.path.join(path, "test_data.pkl")):
-            return None
         with open(cache, "rb", buffering=0) as f:
             hdr = np.frombuffer(f.read(_HDR * 8), dtype=np.int64)
-            if hdr.shape[0] != _HDR or hdr[0] != _MAGIC:
+            if hdr.shape[0] != _HDR or hdr[0] != _MAGIC or (int(hdr[6]), int(hdr[7])) != _pickle_stamp(path):
                 return None
             n, H, W, J = (int(v) for v in hdr[1:5])
             o_est, o_gt, o_cam, o_heat, total = _sidecar_layout(n, H, W, J)
@@ -108,7 +113,7 @@ def _write_sidecar(path, c, heat):
         o_est, o_gt, o_cam, o_heat, total = _sidecar_layout(n, H, W, J)
         tmp = cache + ".tmp%d" % os.getpid()
         with open(tmp, "wb") as f:
-            f.write(np.array([_MAGIC, n, H, W, J, J * 3, 0, 0], dtype=np.int64).tobytes())
+            f.write(np.array([_MAGIC, n, H, W, J, J * 3, *_pickle_stamp(path)], dtype=np.int64).tobytes())
             for k in ("est_local", "gt", "cams"):
                 f.write(np.ascontiguousarray(c[k], dtype=np.float64).tobytes())
             f.write(b"\0" * (o_heat - f.tell()))
@@ -158,10 +163,11 @@ def peek_frames(path):
     return None if side is None else side[0][0]
 
 
-def load_chunk(path, device=None, sidecar=True, dest=None):
+def load_chunk(path, device=None, sidecar=False, dest=None):
     """`<chunk>/test_data.pkl` (optimizer.py:315-324) as dense arrays; KeyError on a missing key like the reference.
     With `device`, the heat-maps (99 % of the bytes) go straight to that device from the calling thread.
-    sidecar=True: a raw-array cache of the pickle is used when present and written after the first un-pickling (the pickle
+    sidecar=True (opt-in: it writes a ~25 MB `test_data.cache` next to every pickle, a side effect the reference does not have):
+    a raw-array cache of the pickle is used when present and written after the first un-pickling (the pickle
     holds 100 separate [64,64,15] arrays per chunk: un-pickling them is GIL-bound Python object work, 3 ms per chunk and
     thread; the cache is one 24.6 MB read straight into pinned memory, 70 GB/s over 8 reader threads)."""
     side = _read_sidecar(path) if sidecar else None
@@ -224,7 +230,7 @@ class ChunkStream:
     consumer, and yields them in directory order.  The reads release the GIL (file -> pinned memory), so they overlap with
     each other and with the consumer's device work."""
 
-    def __init__(self, paths, depth=8, workers=8, device=None, sidecar=True, dests=None):
+    def __init__(self, paths, depth=8, workers=8, device=None, sidecar=False, dests=None):
         self._paths = list(paths)
         self._depth = max(1, depth)
         self._device = device
@@ -313,12 +319,15 @@ def _batches(stream, chunks_per_batch):
 def optimize_sequences(data_dirs, camera_model_path, vae_weight=0.0, gmm_weight=0.0, smoothness_weight=0.001,
                        bone_length_weight=0.01, weight_3d=0.01, reproj_weight=0.01, final_smooth=True, merge=True,
                        global_vae_path=GLOBAL_VAE_PATH, local_vae_path=LOCAL_VAE_PATH, chunks_per_batch=None, optimizer=None,
-                       device_metrics=True, verbose=True, seq_len=SEQ_LEN, overlap=OVERLAP, sidecar=True, timings=None):
+                       device_metrics=True, verbose=True, seq_len=SEQ_LEN, overlap=OVERLAP, sidecar=False, timings=None):
     """Several sequences in ONE batched device call (BASELINE configs[2]: all test sequences concurrently on one GPU):
     the chunks of every directory of `data_dirs` go through the optimiser together, the reports are per sequence.
     Returns a list of (summary, per-chunk error dicts, estimated_pose, optimized_pose, gt_pose), one per directory, each
     exactly what `optimize_directory` returns; the noise is drawn sequence by sequence, chunk by chunk.
-    sidecar=True keeps a raw-array cache of every pickle next to it (`load_chunk`); False reads the pickles only."""
+    sidecar=True keeps a raw-array cache of every pickle next to it (`load_chunk`; CLI: --cache true); the default reads the
+    pickles only and leaves the data directory untouched.  The frame / noise buffers and reader threads this module keeps
+    between calls (about 0.5 GB of HBM and pinned host memory per 2000-frame sequence) are shared by all calls of the process
+    without locking -- one call at a time -- and are given back by `release_pools()`."""
     del gmm_weight, merge                       # accepted and unused, as in the reference (SURVEY D4)
     paths, group_of = [], {}
     for gi, d in enumerate(data_dirs):
@@ -501,6 +510,19 @@ def optimize_sequences(data_dirs, camera_model_path, vae_weight=0.0, gmm_weight=
     return out
 
 
+def release_pools():
+    """Give back what this module keeps between calls: the per-device frame buffers the readers fill, the pinned noise blocks
+    and the reader threads (with their pinned staging buffers).  Not to be called while another call is in flight."""
+    global _pool, _pool_workers
+    _heat_pool.clear()
+    _noise_pool.clear()
+    pool, _pool, _pool_workers = _pool, None, 0
+    if pool is not None:
+        pool.shutdown(wait=True)
+    if torch.cuda.is_available():
+        torch.cuda.empty_cache()
+
+
 def optimize_directory(data_dir, camera_model_path, *args, **kwargs):
     """One sequence = the reference's `optimize_whole_sequence.py`.  Returns (summary OrderedDict, per-chunk error
     dicts, estimated_pose, optimized_pose, gt_pose) -- the three pose lists are the concatenations
@@ -525,11 +547,13 @@ def _cli():
     p.add_argument("--final_smooth", default=True, type=truthy)
     p.add_argument("--merge", default=True, type=truthy)
     p.add_argument("--chunks_per_batch", type=int, default=None, help="chunks optimised per device call (default: all)")
+    p.add_argument("--cache", default=False, type=truthy, help="keep a raw-array cache (test_data.cache, ~25 MB) next to every pickle: "
+                   "4x faster reads from the second run on")
     a = p.parse_args()
     if a.save:
         raise NotImplementedError("--save writes open3d meshes (optimizer.py:452-504): outside the hot path")
     optimize_directory(a.data_path, a.camera, a.vae, a.gmm, a.smooth, a.bone_length, a.weight_3d, a.reproj_weight,
-                       final_smooth=a.final_smooth, merge=a.merge, chunks_per_batch=a.chunks_per_batch)
+                       final_smooth=a.final_smooth, merge=a.merge, chunks_per_batch=a.chunks_per_batch, sidecar=a.cache)
 
 
 if __name__ == "__main__":

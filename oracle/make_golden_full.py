@@ -47,13 +47,18 @@ VARIANTS = {"default": dict(cli=CLI, seq_seed=2, eps_seed=4321, name="pipeline_f
             # third fixture: the reference's OTHER fisheye calibration (more polynomial terms, another principal point)
             "altcam": dict(cli=CLI, seq_seed=9, eps_seed=7, name="pipeline_full_altcam.npz", full=False, calibration="alt"),
             "allterms": dict(cli=dict(vae_weight=0.002, gmm_weight=0.0, smoothness_weight=0.003, bone_length_weight=0.02, weight_3d=0.02,
-                                      reproj_weight=0.005), seq_seed=5, eps_seed=99, name="pipeline_full_allterms.npz", full=False)}
+                                      reproj_weight=0.005), seq_seed=5, eps_seed=99, name="pipeline_full_allterms.npz", full=False),
+            # fourth fixture: a NON-LINEAR global VAE (feature_offset_global = 0: its feature channels change sign, so the
+            # LeakyReLU' masks of the global stage's backward pass matter; in the other three the global decoder is affine)
+            "nonlinear_global": dict(cli=CLI, seq_seed=11, eps_seed=21, name="pipeline_full_nlglobal.npz", full=False,
+                                     feature_offset_global=0.0)}
 
 
 def main():
-    global CLI, SEQ_SEED, EPS_SEED
+    global CLI, SEQ_SEED, EPS_SEED, FEATURE_OFFSET_GLOBAL
     variant = VARIANTS[sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else "default"]
     CLI, SEQ_SEED, EPS_SEED = variant["cli"], variant["seq_seed"], variant["eps_seed"]
+    FEATURE_OFFSET_GLOBAL = variant.get("feature_offset_global", FEATURE_OFFSET_GLOBAL)
     os.makedirs(OUT, exist_ok=True)
     work = tempfile.mkdtemp(prefix="gem_golden_full_")
     torch, ref_opt, ConvVAE, FishEye = import_reference(work)

@@ -397,6 +397,7 @@ def test_unfused_layer_path(torch_cuda, monkeypatch, shape, seed, B):
     w = (1e-1, 1e-1, 1.0, 1e-3, 1e-2)
     results = {}
     for tag, no_tail in (("fused", False), ("batched", True)):
+        monkeypatch.setenv("GEM_DEV", "1")       # developer switches are honoured only with GEM_DEV=1
         if no_tail:
             monkeypatch.setenv("GEM_NO_TAIL", "1")
         else:
@@ -418,6 +419,160 @@ def test_unfused_layer_path(torch_cuda, monkeypatch, shape, seed, B):
     # both paths do the same arithmetic up to summation order
     np.testing.assert_allclose(results["fused"][0], E, rtol=1e-5)
     assert np.abs(results["fused"][1] - dz).max() <= 1e-4 * np.abs(dz).max()
+
+
+@pytest.mark.parametrize("T", [12, 16])
+def test_fused_tail_with_windows_longer_than_its_thread_count(torch_cuda, monkeypatch, T):
+    """Windows of T >= 12 frames hold more than 512 pose values (T*15*3 = 540 / 720): the fused tail's one-element-per-thread
+    parking of the energy inputs does not cover them, so it must leave them to energy_window's own global reads.  The fused
+    path against the batched layers + stand-alone energy kernel (GEM_NO_TAIL), and against the oracle."""
+    shape = vae_schema.VAEShape(latent_dim=32, seq_len=T, hidden=(16, 16, 32, 32, 64))
+    sd = vae_schema.synthetic_state_dict(shape, 13)
+    vae = O.fold_vae(sd, seq_len=T)
+    cam = oracle_camera()
+    B = 3
+    seq = synth.make_sequence(n_frames=8 * (B - 1) + T, seed=43)
+    est = np.asarray(seq["estimated_local_skeleton"], dtype=np.float32)
+    heat = np.asarray(seq["heatmap_list"], dtype=np.float32)
+    starts = (8 * np.arange(B)).astype(np.int32)
+    pose = np.stack([est[s:s + T] for s in starts])
+    rng = np.random.default_rng(7)
+    mu, _ = O.encode(vae, pose.reshape(B, T, 45))
+    z = (mu + 0.1 * rng.normal(size=mu.shape)).astype(np.float32)
+    mb = O.mean_bone_length(est)
+    res = {}
+    monkeypatch.setenv("GEM_DEV", "1")
+    for tag, no_tail in (("fused", False), ("batched", True)):
+        if no_tail:
+            monkeypatch.setenv("GEM_NO_TAIL", "1")
+        else:
+            monkeypatch.delenv("GEM_NO_TAIL", raising=False)
+        eng = _engine(shape, max_windows=4)
+        eng.load_vae(0, sd)
+        E, parts, dz, X = eng.energy_grad(0, z, pose, mb, _ew(W_ALL), heat, starts)
+        res[tag] = (E.cpu().numpy(), parts.cpu().numpy(), dz.cpu().numpy(), X.cpu().numpy())
+        eng.close()
+    E, parts, dz, X = res["fused"]
+    for b in range(B):
+        Xo, acts = O.decode(vae, z[b:b + 1], keep=True)
+        f, p, dX = O.energy_and_grad(Xo[0], pose[b], mb, O.Weights(*W_ALL), cam, heat[starts[b]:starts[b] + T])
+        dzo = O.decode_backward(vae, dX[None], acts)[0]
+        np.testing.assert_allclose(X[b], Xo[0], rtol=2e-4, atol=2e-5)
+        assert abs(E[b] - f) <= 2e-4 * abs(f) + 1e-7, (b, E[b], f)
+        assert np.abs(dz[b] - dzo).max() <= 2e-3 * np.abs(dzo).max() + 1e-8
+    np.testing.assert_allclose(E, res["batched"][0], rtol=1e-5)
+    np.testing.assert_allclose(parts, res["batched"][1], rtol=1e-5, atol=1e-9)
+    assert np.abs(dz - res["batched"][2]).max() <= 1e-4 * np.abs(dz).max()
+
+
+def test_graph_cache_is_dropped_when_the_weights_are_reloaded(torch_cuda):
+    """A captured call bakes the weight pointers into its kernel arguments: gem_load_vae on a loaded stage frees and re-allocates
+    them, so it must drop the graph cache (else the next identical call replays kernels on freed / stale weights).  Graphs on,
+    capture + replay with weights A, reload weights B, call again with the same signature: the result must be B's eager
+    result.  optimize_stage stages its small inputs in engine-owned buffers, so plain numpy inputs replay as well."""
+    torch = torch_cuda
+    sd_a, sd_b = vae_schema.synthetic_state_dict(TINY, 11), vae_schema.synthetic_state_dict(TINY, 12)
+    B = 6
+    seq = synth.make_sequence(n_frames=8 * (B - 1) + 10, seed=44)
+    est = np.asarray(seq["estimated_local_skeleton"], dtype=np.float32)
+    heat = torch.as_tensor(np.asarray(seq["heatmap_list"], dtype=np.float32), device="cuda")
+    starts = (8 * np.arange(B)).astype(np.int32)
+    pose = np.stack([est[s:s + 10] for s in starts])
+    mb = O.mean_bone_length(est)
+    eps = np.random.default_rng(9).normal(size=(B, TINY.latent_dim)).astype(np.float32)
+    w = _ew((1e-2, 1e-2, 1e-1, 1e-3, 1e-2))
+    eager = {}
+    for tag, sd in (("a", sd_a), ("b", sd_b)):
+        e = _engine(TINY, max_windows=8)
+        e.load_vae(0, sd)
+        out, st = e.optimize_stage(0, pose, mb, eps, w, heat, starts)
+        eager[tag] = (out.clone(), st.clone())
+        e.close()
+    assert not torch.equal(eager["a"][0], eager["b"][0])
+    eng = _engine(TINY, max_windows=8)
+    eng.load_vae(0, sd_a)
+    eng.enable_graphs(True)
+    for k in range(3):                       # eager, capture, replay
+        out, st = eng.optimize_stage(0, pose, mb, eps, w, heat, starts)
+        torch.cuda.synchronize()
+        assert torch.equal(out, eager["a"][0]) and torch.equal(st, eager["a"][1]), k
+    gs = eng.graph_stats()
+    assert gs["captures"] == 1 and gs["replays"] == 2, gs
+    eng.load_vae(0, sd_b)                    # same signature from here on, other weights behind (possibly) the same pointers
+    for k in range(3):
+        out, st = eng.optimize_stage(0, pose, mb, eps, w, heat, starts)
+        torch.cuda.synchronize()
+        assert torch.equal(out, eager["b"][0]) and torch.equal(st, eager["b"][1]), k
+    gs = eng.graph_stats()
+    assert gs["captures"] == 2 and gs["replays"] == 4, gs
+    eng.set_texel_cache(False)               # part of the signature as well: eager again, same numbers (the cache is bitwise neutral)
+    out, st = eng.optimize_stage(0, pose, mb, eps, w, heat, starts)
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager["b"][0]) and eng.graph_stats()["replays"] == 4
+    eng.close()
+
+
+@pytest.mark.parametrize("net,B", [("tiny", 3), ("tiny", 21), ("full", 8), ("full", 21), ("full", 40), ("structured", 40)])
+def test_bf16_multi_window_tail_against_the_batched_bf16_layers(torch_cuda, monkeypatch, golden, net, B):
+    """bf16 decoder mode: the multi-window fused tail (csrc/tail_bf16.hip: 8 windows = five 16-row MFMA tiles per workgroup,
+    bf16 weights and activations in registers / LDS, fp32 accumulate and fp32 energies) against the SAME layers as batched bf16
+    GEMMs + the stand-alone energy kernel (GEM_BATCHED_NARROW).  Both paths round at the same points (bf16 activations and
+    gradients between layers, the same bf16 weights, the same composed front layer), so they agree up to the fp32 summation order
+    -- i.e. to ~1e-7, except where that order flips one bf16 rounding (rare; one flip moves one activation by 2^-8 of its value).
+    Ragged batches (a last workgroup with 5 of 8 windows, B = 3: one partial workgroup) included; whole stages as well."""
+    from globalegomocap_amd.engine import stats_to_numpy
+    torch = torch_cuda
+    if net == "tiny":
+        g = golden("lbfgs_tiny")
+        shape, sd = TINY, sd_from_npz(g, "local/")
+    elif net == "full":
+        shape, sd = FULL, vae_schema.synthetic_state_dict(FULL, 5)
+    else:
+        shape, sd = FULL, vae_schema.structured_state_dict(FULL, 7, feature_offset=0.0)
+    vae = O.fold_vae(sd)
+    seq = synth.make_sequence(n_frames=200, seed=36)
+    est = np.asarray(seq["estimated_local_skeleton"], dtype=np.float32)
+    heat = torch.as_tensor(np.asarray(seq["heatmap_list"], dtype=np.float32), device="cuda")
+    rng = np.random.default_rng(B)
+    starts = rng.integers(0, 190, B).astype(np.int32)
+    pose = np.stack([est[s:s + 10] for s in starts])
+    mb = O.mean_bone_length(est)
+    mu, _ = O.encode(vae, pose.reshape(B, 10, 45))
+    z = (mu + 0.1 * rng.normal(size=mu.shape)).astype(np.float32)
+    eps = rng.normal(size=(B, shape.latent_dim)).astype(np.float32)
+    res = {}
+    monkeypatch.setenv("GEM_DEV", "1")
+    for tag in ("tail16", "batched"):
+        if tag == "tail16":
+            monkeypatch.setenv("GEM_TAIL16", "1")
+            monkeypatch.delenv("GEM_BATCHED_NARROW", raising=False)
+        else:
+            monkeypatch.setenv("GEM_TAIL16", "0")
+            monkeypatch.setenv("GEM_BATCHED_NARROW", "1")
+        eng = _engine(shape, max_windows=B)
+        eng.load_vae(0, sd)
+        eng.set_precision("bf16")
+        E, parts, dz, X = eng.energy_grad(0, z, pose, mb, _ew(W_ALL), heat, starts)
+        _, _, dz_s, _ = eng.energy_grad(0, z, pose, mb, _ew(W_ALL[:4] + (0.0,)), heat, starts)      # smooth energy (no texel edges)
+        out, stats = eng.optimize_stage(0, pose, mb, eps, _ew((1e-6, 1e-5, 1e-2, 0.0, 1e-2)), heat, starts)
+        torch.cuda.synchronize()
+        res[tag] = (E.cpu().numpy(), dz.cpu().numpy(), X.cpu().numpy(), dz_s.cpu().numpy(), out.cpu().numpy(), stats_to_numpy(stats))
+        eng.close()
+    (Ea, dza, Xa, dsa, outa, sta), (Eb, dzb, Xb, dsb, outb, stb) = res["tail16"], res["batched"]
+    qx = np.quantile(np.abs(Xa - Xb).ravel() / max(1.0, np.abs(Xb).max()), [0.5, 0.99])
+    assert qx[0] <= 1e-6 and qx[1] <= 4e-3, qx                      # (99 %: a flipped rounding of a signal channel is 2^-8 of ~3)
+    np.testing.assert_allclose(Ea, Eb, rtol=2e-2)
+    for a_, b_ in ((dza, dzb), (dsa, dsb)):
+        qg = np.quantile(np.abs(a_ - b_).ravel() / np.abs(b_).max(), [0.5, 0.99])
+        assert qg[0] <= 1e-5 and qg[1] <= 2e-2, qg
+    cos = [float(np.dot(dsa[k], dsb[k]) / (np.linalg.norm(dsa[k]) * np.linalg.norm(dsb[k]) + 1e-30)) for k in range(B)]
+    assert min(cos) > 0.9995, min(cos)
+    assert sta["finished"].all() and stb["finished"].all() and not sta["degenerate"].any()
+    assert abs(sta["func_evals"].mean() - stb["func_evals"].mean()) <= 3.0
+    # fp32 oracle, first windows: decoded pose and energy at bf16 accuracy
+    for k in range(min(B, 3)):
+        Xo = O.decode(vae, z[k:k + 1])[0]
+        assert np.abs(Xa[k] - Xo).max() <= 8e-3 * max(1.0, np.abs(Xo).max()), k
 
 
 def test_projections_outside_the_heatmap_and_error_paths(torch_cuda):
@@ -700,6 +855,7 @@ def test_composed_front_layer_against_the_two_layers_it_replaces(torch_cuda, mon
     mb = O.mean_bone_length(est)
     eps = rng.normal(size=(B, 2048)).astype(np.float32)
     res = {}
+    monkeypatch.setenv("GEM_DEV", "1")           # developer switches are honoured only with GEM_DEV=1
     for tag in ("composed", "separate"):
         if tag == "separate":
             monkeypatch.setenv("GEM_NO_FRONT", "1")
@@ -793,7 +949,7 @@ def test_fused_compaction_is_bitwise_the_compact_kernel(torch_cuda, tmp_path):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for tag, extra in (("fused", {}), ("kernel", {"GEM_NO_FUSED_COMPACT": "1"})):
+    for tag, extra in (("fused", {}), ("kernel", {"GEM_NO_FUSED_COMPACT": "1", "GEM_DEV": "1"})):
         env = dict(os.environ, **extra)
         env.pop("GEM_NO_FUSED_COMPACT", None) if not extra else None
         path = str(tmp_path / ("%s.npz" % tag))

@@ -151,23 +151,27 @@ def test_chunk_listing_and_background_reader(tmp_path):
     (tmp_path / "notes.txt").write_text("not a chunk")
     paths = ws.list_chunks(str(tmp_path))
     assert [os.path.basename(p) for p in paths] == ["chunk_1", "chunk_2", "chunk_10"]
-    got = list(ws.ChunkStream(paths, depth=1))
+    got = list(ws.ChunkStream(paths, depth=1, sidecar=True))
     assert [len(c["est_local"]) for c in got] == [25, 30, 20]
     assert got[0]["heat"].dtype == np.float32 and got[0]["heat"].shape == (25, 64, 64, 15) and got[0]["cams"].shape == (25, 4, 4)
     assert [len(b) for b in ws._batches(iter(got), 2)] == [2, 1] and [len(b) for b in ws._batches(iter(got), None)] == [3]
     # the first read left a raw-array cache next to every pickle; the second read comes from it, bit for bit
     for p_ in paths:
         assert os.path.exists(os.path.join(p_, ws.SIDE_CACHE))
-    again = list(ws.ChunkStream(paths, depth=2))
-    plain = list(ws.ChunkStream(paths, depth=2, sidecar=False))
+    again = list(ws.ChunkStream(paths, depth=2, sidecar=True))
+    plain = list(ws.ChunkStream(paths, depth=2))                    # default: pickles only, nothing written
     for a_, b_, c_ in zip(got, again, plain):
         for k in ("est_local", "gt", "cams", "heat"):
             assert np.array_equal(a_[k], b_[k]) and np.array_equal(a_[k], c_[k]) and a_[k].dtype == b_[k].dtype == c_[k].dtype, k
-    # a cache older than its pickle, or of the wrong length, is ignored and rewritten
-    os.utime(os.path.join(paths[0], ws.SIDE_CACHE), (1, 1))
+    # a cache made from another pickle (size or modification time differ -- also an OLDER time stamp, as cp -p / rsync -t / a
+    # restore leave it), or of the wrong length, is ignored and rewritten
+    pk = os.path.join(paths[0], "test_data.pkl")
+    st = os.stat(pk)
+    os.utime(pk, ns=(st.st_atime_ns, st.st_mtime_ns - 10 ** 9))
     assert ws._read_sidecar(paths[0]) is None
-    ws.load_chunk(paths[0])
+    ws.load_chunk(paths[0], sidecar=True)
     assert ws._read_sidecar(paths[0]) is not None
+    ws.release_pools()
     with open(os.path.join(paths[1], ws.SIDE_CACHE), "ab") as f:
         f.write(b"xx")
     assert ws._read_sidecar(paths[1]) is None

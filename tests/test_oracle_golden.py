@@ -245,7 +245,7 @@ def test_full_size_main_torch_port_matches_reference(golden):
     assert abs(mp - float(g["err_smooth/optimized_global_mpjpe"])) < 0.05e-3
 
 
-@pytest.mark.parametrize("name", ["pipeline_full", "pipeline_full_allterms", "pipeline_full_altcam"])
+@pytest.mark.parametrize("name", ["pipeline_full", "pipeline_full_allterms", "pipeline_full_altcam", "pipeline_full_nlglobal"])
 def test_full_size_stages_numpy_oracle_match_reference(golden, name):
     """Every one of the 24 stage calls of the reference's full-size main(), run in isolation (the reference's own stage input)
     through the numpy oracle -- its own L-BFGS state machine, the one the HIP kernel mirrors.
@@ -288,7 +288,7 @@ def test_full_size_stages_numpy_oracle_match_reference(golden, name):
         if st:      # global stage: smooth energy
             assert stats["func_evals"] == n_ref and stats["n_iter"] == int(g["n_iter"][row]), row
             np.testing.assert_allclose(losses, ref_tr[:n_ref], rtol=1e-3, atol=1e-9)
-            assert abs(stats["loss"] - np.nanmin(ref_tr)) <= 1e-4 * abs(np.nanmin(ref_tr)), row
+            assert abs(stats["loss"] - np.nanmin(ref_tr)) <= lim.get("global_loss", 1e-4) * abs(np.nanmin(ref_tr)), row
             assert d.mean() < 0.05e-3 and d.max() < lim["global_max"], (row, d.mean(), d.max())
         else:
             assert abs(stats["loss"] - np.nanmin(ref_tr)) <= lim["local_loss"] * abs(np.nanmin(ref_tr)), row

@@ -27,7 +27,7 @@ for B in (400, 640, 1000, 1280):
     st, ss = stats_to_numpy(stats), stats_to_numpy(stats_s)
     print("B=%d: X diff %.2e, E rel %.2e, dz rel %.2e, all done %s, evals equal %d/40, loss rel diff %.2e, pose diff %.4f mm" % (
         B, np.abs(X[:40].cpu().numpy() - Xs.cpu().numpy()).max(), np.abs(E[:40].cpu().numpy() / Es.cpu().numpy() - 1).max(),
-        np.abs((dz[:40] - dzs).cpu().numpy()).max() / np.abs(dzs.cpu().numpy()).max(), (st["status"] == 1).all(),
+        np.abs((dz[:40] - dzs).cpu().numpy()).max() / np.abs(dzs.cpu().numpy()).max(), st["finished"].all(),
         (st["func_evals"][:40] == ss["func_evals"]).sum(), np.abs(st["final_loss"][:40] / ss["final_loss"] - 1).max(),
         np.linalg.norm((out[:40] - outs).cpu().numpy(), axis=-1).mean() * 1e3), flush=True)
     big.close(); small.close()
