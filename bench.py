@@ -39,12 +39,19 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=50)
     p.add_argument("--warmup", type=int, default=10)
-    p.add_argument("--workload", default="seq2k", help="seq2k (20 chunks, 240 windows) | w8192 | <number of chunks>")
+    p.add_argument("--workload", default="seq2k", help="seq2k (20 chunks, 240 windows per GPU; the default, weak scaling) | w8192 | <number of "
+                   "chunks> | configs3 (65536 windows sharded over the ranks, bf16, strong scaling) | configs4 (12499 overlapping windows of "
+                   "one 100k-frame stream, block-cyclic shards, hipGraph replay, strong scaling)")
+    p.add_argument("--windows", type=int, default=0, help="configs3 / configs4: total number of windows (default 65536 / 12499)")
+    p.add_argument("--block", type=int, default=64, help="configs4: windows per block of the block-cyclic shards")
+    p.add_argument("--emulate-ranks", type=int, default=0, help="configs3 / configs4 with --gpus 1: run the shards of N ranks one after "
+                   "the other in this process (same shards, same calls, no collective): the reference the multi-rank result must equal bitwise")
+    p.add_argument("--dump", default=None, help="configs3 / configs4: rank 0 saves the gathered poses (and the merged sequence) to this .npz")
     p.add_argument("--fit-steps", type=int, default=2000, help="Adam steps to fit the synthetic VAEs (untimed)")
     p.add_argument("--cpu-windows", type=int, default=12, help="windows of the CPU baseline sample (0 = skip)")
     p.add_argument("--no-extra", action="store_true", help="skip the bf16x3 / bf16 side measurements")
     p.add_argument("--no-profile", action="store_true", help="no HIP-event timing of the dominant kernel")
-    p.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "bf16"],
+    p.add_argument("--precision", default=None, choices=["f32", "bf16x3", "bf16"],
                    help="arithmetic of the wide decoder/encoder products (f32 = BASELINE configs[1])")
     p.add_argument("--vae", default="fit", choices=["fit", "structured"],
                    help="synthetic VAE weights: 'fit' = briefly fitted with Adam on synthetic motion (default, as in round 1); "
@@ -52,7 +59,10 @@ def parse():
                         "reference golden (no fitting kernels: profiling runs)")
     p.add_argument("--weights-cache", default=None, help="torch file to load/store the fitted synthetic VAEs (keeps the "
                    "fitting kernels out of a rocprof trace)")
-    return p.parse_args()
+    a = p.parse_args()
+    if a.precision is None:
+        a.precision = "bf16" if a.workload in ("configs3", "configs4") else "f32"      # BASELINE.json: configs[3] and [4] are bf16
+    return a
 
 
 def fit_weights(shape, seed, device, steps, relative):
@@ -99,6 +109,25 @@ def cpu_baseline(sd_local, sd_global, cam, seqd, starts, mean_bone, eps_l, eps_g
     return np.asarray(out), dt, nthreads
 
 
+def committed_traffic(kernel_names):
+    """HBM bytes per launch of the named kernels from the committed rocprofv3 --pmc summaries (profiles/traffic_r*.json: FETCH_SIZE x 2
+    on gfx950 + WRITE_SIZE, separate passes -- MI355X_MICROARCH.md section HBM), dispatch-weighted over the names; (None, None) when
+    no committed file knows them.  NOT measured in this run: the source file is named next to the number."""
+    import glob
+    names = [n.strip() for n in kernel_names.split(";") if n.strip()]
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json")), reverse=True):
+        try:
+            k = json.load(open(path)).get("kernels", {})
+        except (OSError, ValueError):
+            continue
+        hit = [k[n] for n in names if n in k]
+        if len(hit) == len(names) and hit:
+            disp = sum(h["dispatches"] for h in hit)
+            tot = sum((h["read_bytes_corrected"] + h["write_bytes"]) * h["dispatches"] for h in hit)
+            return int(tot / disp), "profiles/%s (committed rocprofv3 --pmc passes of the matching bench command; not measured in this run)" % os.path.basename(path)
+    return None, None
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start N fresh ranks (one per GPU) under torch.distributed.run and
     relay their exit code.  Runs before this process touches torch.cuda or HIP: the parent only waits."""
@@ -113,6 +142,143 @@ def spawn_ranks(n):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this pool (RCCL needs it)
     return subprocess.run(cmd, env=env).returncode
+
+
+def run_sharded(a, world, rank, device, rehearsal, sd_local, sd_global, vae_note):
+    """BASELINE configs[3] / configs[4]: ONE job of n windows sharded over the ranks (strong scaling).
+
+    configs3: 65 536 independent windows, contiguous shards (`dist.shard_range`), every rank synthesises its own frames on its
+      device from seed + rank (nothing is scattered from a root), bf16 decoder; one `all_gather_windows` of the refined poses.
+    configs4: the 12 499 overlapping windows (stride 8) of ONE 100 000-frame stream, block-cyclic shards
+      (`dist.shard_indices(block=k)`: blocks of k windows = 8k + 2 contiguous frames dealt round-robin, so that stretches whose
+      windows exit early or late are spread over the ranks); a rank holds only the frames of its blocks (stored once, + the 2-frame
+      halo between blocks that went to different ranks); every call after the second is one hipGraph replay;
+      `all_gather_indexed` restores window order, then overlap-merge + final smoothing (optimizer.py:425-450) of the gathered
+      sequence on the device.
+    The timed step = optimise the shard + the collective (+ merge for configs4); value = n windows / step time."""
+    import torch
+    import torch.distributed as dist
+    from globalegomocap_amd import synth, vae as vae_schema
+    from globalegomocap_amd.camera import FisheyeCamera, DEFAULT_CALIBRATION
+    from globalegomocap_amd.dist import shard_indices, frame_runs, all_gather_windows, all_gather_indexed
+    from globalegomocap_amd.engine import WindowEngine, energy_weights, stats_to_numpy, LOCAL_STAGE, GLOBAL_STAGE
+    from globalegomocap_amd.errors import mpjpe
+    stream = a.workload == "configs4"
+    n_total = a.windows or (12499 if stream else 65536)
+    block = a.block if stream else None
+    vworld = a.emulate_ranks if (a.emulate_ranks and world == 1) else world
+    my_ranks = list(range(vworld)) if vworld != world else [rank]
+    shape = vae_schema.VAEShape()
+    cam = FisheyeCamera.from_json(DEFAULT_CALIBRATION)
+    T, stride = shape.seq_len, 8
+    idx_of = {r: shard_indices(n_total, r, vworld, block) for r in range(vworld)}
+    cap = max(len(v) for v in idx_of.values())
+    eng = WindowEngine(shape, cam, max_windows=max(cap, 1))
+    eng.load_vae(LOCAL_STAGE, sd_local)
+    eng.load_vae(GLOBAL_STAGE, sd_global)
+    eng.set_precision(a.precision)
+    eng.enable_graphs(stream)
+    wl = (0.01 / 10000, 0.001 / 100, 0.01, 0.0, 0.01)
+    wg = (0.01, 0.001, 0.01, 0.0, 0.0)
+    w_local, w_global = energy_weights(*wl), energy_weights(*wg)
+    shards = {}
+    gt_all = None
+    if stream:
+        n_frames = stride * (n_total - 1) + T
+        starts = (stride * np.arange(n_total)).astype(np.int64)
+        eps_all = torch.randn(n_total, 2, shape.latent_dim, generator=torch.Generator().manual_seed(654))
+    for r in my_ranks:
+        idx = idx_of[r]
+        nb = len(idx)
+        if stream:
+            runs, local0 = frame_runs(starts, idx, T)
+            d = synth.make_stream_device(n_frames, 6000, device, runs=runs, camera=cam, cam_jitter=CAM_JITTER)
+            gt_all = d["gt_global"]
+            mbv = eng.mean_bone_length(d["est_all_np"].astype(np.float32))       # one sequence: one mean bone length (all ranks: same stream)
+            eps = eps_all[torch.as_tensor(idx, dtype=torch.long)] if nb else eps_all[:0]
+        else:
+            d = synth.make_stream_device(stride * max(nb - 1, 0) + T, 5000 + r, device, camera=cam, cam_jitter=CAM_JITTER)
+            local0 = (stride * np.arange(nb)).astype(np.int32)
+            mbv = eng.mean_bone_length(d["est_local"])
+            eps = torch.randn(nb, 2, shape.latent_dim, generator=torch.Generator().manual_seed(7000 + r))
+        shards[r] = dict(d=d, idx=idx, f0=torch.as_tensor(local0, dtype=torch.int32, device=device),
+                         mb=mbv.reshape(1, 15).expand(nb, 15).contiguous(), el=eps[:, 0].contiguous().to(device),
+                         eg=eps[:, 1].contiguous().to(device), frames_held=int(d["heat"].shape[0]))
+    del eps
+    pose_shape = (T, 15, 3)
+
+    def step():
+        outs = {}
+        for r in my_ranks:
+            sh = shards[r]
+            if len(sh["idx"]) == 0:
+                outs[r] = (torch.zeros((0,) + pose_shape, dtype=torch.float64, device=device), None)
+                continue
+            mid, glob, stats = eng.optimize_windows(sh["d"]["est_local"], sh["d"]["cams"], sh["d"]["heat"], sh["f0"], sh["mb"], sh["el"], sh["eg"],
+                                                    w_local, w_global, want_stats=True)
+            outs[r] = (glob.clone() if len(my_ranks) > 1 else glob, stats.clone() if len(my_ranks) > 1 else stats)
+        if world > 1:          # the one collective of the path
+            full = all_gather_indexed(outs[rank][0], n_total, block) if stream else all_gather_windows(outs[rank][0], n_total)
+        elif vworld > 1:       # emulated ranks: the same placement by index, no collective
+            full = torch.empty((n_total,) + pose_shape, dtype=torch.float64, device=device)
+            for r in my_ranks:
+                if len(idx_of[r]):
+                    full[torch.as_tensor(idx_of[r], dtype=torch.long, device=device)] = outs[r][0]
+        else:
+            full = outs[rank][0]
+        merged = eng.merge_windows(full, 1, overlap=T - stride, smooth=True) if stream else None
+        return full, merged, outs
+
+    for _ in range(max(a.warmup, 3 if stream else 1)):      # (graphs: eager, capture, first replay)
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        full, merged, outs = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    fin = all(bool(stats_to_numpy(o[1])["finished"].all()) for o in outs.values() if o[1] is not None)
+    if rank == 0:
+        mp = None
+        if stream:
+            mp = round(mpjpe(merged.cpu().numpy(), gt_all[:merged.shape[0]]) * 1e3, 3)
+        if a.dump:
+            np.savez(a.dump, glob=full.cpu().numpy(), merged=merged.cpu().numpy() if merged is not None else np.zeros(0))
+        gs = eng.graph_stats() if stream else None
+        held = [shards[r]["frames_held"] for r in my_ranks]
+        line = {
+            "metric": "optimised windows/sec (10-frame, 15-joint)", "value": round(n_total * a.steps / elapsed, 2), "unit": "windows/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": {"f32": "f32", "bf16x3": "f32 via 3x bf16 split MFMA", "bf16": "bf16 decoder products and activations / f32 accumulate, energies, L-BFGS"}[a.precision],
+            "data": "synthetic",
+            "config": {"workload": ("BASELINE configs[4]: %d overlapping windows (stride 8) of ONE %d-frame stream, block-cyclic shards of %d-window "
+                                    "blocks over %d ranks, every rank holds only its blocks' frames (+ halo), hipGraph replay of the whole call, "
+                                    "all-gather by index, overlap-merge + final smoothing of the gathered sequence"
+                                    % (n_total, stride * (n_total - 1) + T, block, vworld)) if stream else
+                                   ("BASELINE configs[3]: %d independent windows in contiguous shards over %d ranks (%d per rank), every rank "
+                                    "synthesises its own frames from seed + rank, one all-gather of the refined poses" % (n_total, vworld, cap)),
+                       "windows_total": n_total, "windows_per_rank_max": cap, "ranks": world, "emulated_ranks": vworld if vworld != world else None,
+                       "backend": dist.get_backend() if world > 1 else None, "rehearsal_on_one_card": bool(rehearsal),
+                       "frames_held_by_rank0_shards": held, "vae": vae_note, "precision": a.precision,
+                       "collective": None if world == 1 else ("all_gather_indexed" if stream else "all_gather_windows")},
+            "all_finished": fin, "mpjpe_optimised_mm": mp, "graph": gs,
+        }
+        print(json.dumps(line), flush=True)
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -153,7 +319,9 @@ def main():
     from globalegomocap_amd.sequence import window_starts, merge_batches, final_smooth
     from globalegomocap_amd.errors import mpjpe
 
-    n_chunks = {"seq2k": 20, "w8192": 683}.get(a.workload) or int(a.workload)
+    n_chunks = {"seq2k": 20, "w8192": 683, "configs3": 0, "configs4": 0}.get(a.workload)
+    if n_chunks is None:
+        n_chunks = int(a.workload)
     shape = vae_schema.VAEShape()
     cam = FisheyeCamera.from_json(DEFAULT_CALIBRATION)
 
@@ -169,6 +337,9 @@ def main():
         sd_global, err_g = fit_weights(shape, 102, device, a.fit_steps, relative=True)
         if a.weights_cache and rank == 0:
             torch.save((sd_local, err_l, sd_global, err_g), a.weights_cache)
+    if a.workload in ("configs3", "configs4"):
+        note = ("synthetic, fitted %d Adam steps (recon %.1f / %.1f mm)" % (a.fit_steps, err_l * 1e3, err_g * 1e3)) if a.vae == "fit" else "synthetic, structured"
+        return run_sharded(a, world, rank, device, rehearsal, sd_local, sd_global, note)
     n_frames = n_chunks * CHUNK
     seqd = synth.make_sequence_device(n_frames, seed=1000 + rank, device=device, camera=cam, cam_jitter=CAM_JITTER)
     starts = np.concatenate([c * CHUNK + window_starts(CHUNK) for c in range(n_chunks)]).astype(np.int32)
@@ -284,20 +455,20 @@ def main():
             e.enable_graphs(False)
         del engines[1:]
 
-    # ---- side record (not `value`): BASELINE configs[2] -- "all 5 test-sequence shapes concurrently on 1 MI355X, bf16 VAE
-    # decoder / fp32 energy": 20 + 27 + 27 + 27 + 27 = 128 chunks = 1536 windows in ONE call, fp32 and bf16, each with the
-    # roofline of its own dominant kernel (decoder_input forward + backward-data, HIP events on the launch stream)
-    configs2 = None
-    if a.precision == "f32" and not a.no_extra and world == 1 and a.workload == "seq2k":
-        configs2 = {}
-        nc2 = 128
+    # ---- side records (not `value`): BASELINE configs[2] -- "all 5 test-sequence shapes concurrently on 1 MI355X, bf16 VAE
+    # decoder / fp32 energy": 20 + 27 + 27 + 27 + 27 = 128 chunks = 1536 windows in ONE call, fp32 and bf16 -- and configs[3]'s
+    # per-GPU shard -- 8192 windows (683 chunks = 8196), bf16 -- each with the roofline of its own dominant kernels (HIP events on
+    # the launch stream; kernel names as recorded by the library at launch time)
+    def side_record(nc2, modes, seed, what):
+        rec_all = {}
         B2 = nc2 * len(window_starts(CHUNK))
-        seq2 = synth.make_sequence_device(nc2 * CHUNK, seed=2000, device=device, camera=cam, cam_jitter=CAM_JITTER)
+        seq2 = synth.make_sequence_device(nc2 * CHUNK, seed=seed, device=device, camera=cam, cam_jitter=CAM_JITTER)
         starts2 = np.concatenate([c * CHUNK + window_starts(CHUNK) for c in range(nc2)]).astype(np.int32)
         e2 = WindowEngine(shape, cam, max_windows=B2)
         e2.load_vae(LOCAL_STAGE, sd_local)
         e2.load_vae(GLOBAL_STAGE, sd_global)
-        mb2 = torch.stack([e2.mean_bone_length(seq2["est_local"][c * CHUNK:(c + 1) * CHUNK]) for c in range(nc2)])
+        est_c = seq2["est_local"].reshape(nc2, CHUNK, 15, 3)
+        mb2 = torch.stack([e2.mean_bone_length(est_c[c]) for c in range(nc2)])
         mb2 = mb2[torch.as_tensor(np.repeat(np.arange(nc2), B2 // nc2), device=device)].contiguous()
         g2 = torch.Generator().manual_seed(987)
         eps2 = torch.randn(B2, 2, shape.latent_dim, generator=g2)
@@ -306,7 +477,7 @@ def main():
         per2 = B2 // nc2
         gt2 = np.concatenate([seq2["gt_global"][c * CHUNK:c * CHUNK + 8 * per2 + 2] for c in range(nc2)])
         n2 = max(3, min(a.steps, 10))
-        for mode in ("f32", "bf16"):
+        for mode in modes:
             e2.set_precision(mode)
 
             def step2():
@@ -320,26 +491,47 @@ def main():
             torch.cuda.synchronize()
             dt = time.perf_counter() - t1
             e2.profile_enable(False)
-            ms_k, n_k, fl_k = e2.profile_read(0) if profile else (0.0, 0, 0.0)
             sn2 = stats_to_numpy(st2)
             ev2 = sn2["func_evals"].reshape(2, B2)
             gl_np = gl2.cpu().numpy()
             opt2 = np.concatenate([final_smooth(merge_batches(gl_np[c * per2:(c + 1) * per2])) for c in range(nc2)])
-            peak2 = PEAK_F32_MATRIX_TFLOPS if mode == "f32" else PEAK_BF16_MATRIX_TFLOPS
-            rec = {"windows": B2, "windows_per_s": round(B2 * n2 / dt, 1), "ms_per_step": round(dt / n2 * 1e3, 3),
+            rec = {"windows": B2, "windows_per_s": round(B2 * n2 / dt, 1), "ms_per_step": round(dt / n2 * 1e3, 3), "steps": n2,
                    "evals_per_stage": {"local_mean": round(float(ev2[0].mean()), 2), "global_mean": round(float(ev2[1].mean()), 2)},
-                   "mpjpe_optimised_mm": round(mpjpe(opt2, gt2) * 1e3, 3), "all_finished": bool(sn2["finished"].all()), "degenerate_windows": int(sn2["degenerate"].sum())}
-            if n_k:
-                ach = fl_k / (ms_k * 1e-3) / 1e12
-                rec["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak2, "unit": "TFLOP/s", "frac": round(ach / peak2, 4),
-                                   "kernel": "decoder_input forward + backward-data (%s)" % ("glds::gemm_glds_kernel<true,1,...>" if mode == "f32" else "glds::gemm_glds_kernel<false,1,...>"),
-                                   "launches": int(n_k), "avg_us": round(ms_k * 1e3 / n_k, 2), "flop_per_launch": fl_k / n_k,
-                                   "traffic": None}
-            configs2[mode] = rec
-        configs2["workload"] = ("BASELINE configs[2]: five sequences of 20+27+27+27+27 chunks = %d windows in one call, local+global "
-                                "stage, bf16 = bf16 decoder activations and products / fp32 accumulate, energies and L-BFGS" % B2)
+                   "mpjpe_optimised_mm": round(mpjpe(opt2, gt2) * 1e3, 3), "all_finished": bool(sn2["finished"].all()),
+                   "degenerate_windows": int(sn2["degenerate"].sum())}
+            if profile:
+                # family 0 = the composed front layer (decoder_input o conv 0), forward + backward-data; family 1 = the fused tail
+                # (fp32: one window per workgroup; bf16: eight windows per workgroup, bf16 MFMA); family 2 = L-BFGS (HBM-bound)
+                for fam, key in ((0, "roofline"), (1, "roofline_tail")):
+                    ms_k, n_k, fl_k = e2.profile_read(fam)
+                    names = e2.profile_kernels(fam)
+                    if not n_k:
+                        continue
+                    pk = PEAK_BF16_MATRIX_TFLOPS if mode == "bf16" else PEAK_F32_MATRIX_TFLOPS
+                    ach = fl_k / (ms_k * 1e-3) / 1e12
+                    tr_b, tr_src = committed_traffic(names)
+                    rec[key] = {"bound": "mfma", "achieved": round(ach, 2), "peak": pk, "unit": "TFLOP/s", "frac": round(ach / pk, 4),
+                                "kernel": names, "launches": int(n_k), "avg_us": round(ms_k * 1e3 / n_k, 2), "flop_per_launch": fl_k / n_k,
+                                "share_of_step": round(ms_k * 1e-3 / (dt / n2), 3), "traffic": tr_b, "traffic_source": tr_src}
+                ms_k, n_k, _ = e2.profile_read(2)
+                if n_k:
+                    rec["lbfgs_advance"] = {"launches": int(n_k), "avg_us": round(ms_k * 1e3 / n_k, 2), "share_of_step": round(ms_k * 1e-3 / (dt / n2), 3)}
+            rec_all[mode] = rec
+        rec_all["workload"] = what % B2
         e2.close()
         del seq2
+        torch.cuda.empty_cache()
+        return rec_all
+
+    configs2 = configs3 = None
+    if a.precision == "f32" and not a.no_extra and world == 1 and a.workload == "seq2k":
+        configs2 = side_record(128, ("f32", "bf16"), 2000,
+                               "BASELINE configs[2]: five sequences of 20+27+27+27+27 chunks = %d windows in one call, local+global "
+                               "stage, bf16 = bf16 decoder activations and products / fp32 accumulate, energies and L-BFGS")
+        configs3 = side_record(683, ("bf16",), 3000,
+                               "BASELINE configs[3] per-GPU shard: 683 chunks = %d windows (>= 8192) in one call, local+global stage, bf16 "
+                               "decoder activations and products / fp32 accumulate, energies and L-BFGS; the 8-GPU leg of this "
+                               "config is `bench.py --gpus 8 --workload configs3`")
 
     # ---- side record (not `value`): BASELINE configs[4] -- "streaming 100k-frame sequence over 8 GPUs, hipGraph-captured":
     # the per-GPU shard, 1563 overlapping windows (stride 8) of ONE continuous 12 506-frame stream, frames stored once, no chunk
@@ -410,43 +602,31 @@ def main():
         other_modes = {m: {"windows_per_s": round(B * world * a.steps / dt, 2), "ms_per_step": round(dt / a.steps * 1e3, 3),
                            "mpjpe_optimised_mm": round(seq_mpjpe(gl) * 1e3, 3)} for m, (dt, gl) in other.items()}
         roof = None
-        traffic = traffic_kernel = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_dominant_kernel.json")
-        if os.path.exists(tpath) and a.workload == "seq2k":
-            # HBM bytes per launch of the dominant kernel from separate rocprofv3 --pmc passes of this same
-            # command (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, MI355X_MICROARCH.md section HBM); see profiles/README.md
-            tj = json.load(open(tpath))
-            traffic, traffic_kernel = tj.get("hbm_bytes_per_launch"), tj.get("dominant_kernel")
         roof_other = None
         if profile:
             # HIP-event timings of the two kernel families that carry the step: family 0 = the matrix products around the latent
             # (decoder_input o conv 0 composed into one layer, forward + backward-data), family 1 = the fused decoder tail.
-            # `roofline` describes whichever took more of the timed region, `roofline_other` the other one.
+            # `roofline` describes whichever took more of the timed region, `roofline_other` the other one.  The kernel names are
+            # the ones the library recorded when it launched them (gem_profile_kernels), i.e. the rows of the rocprofv3 stats.
             fam = {}
             for k in (0, 1):
                 ms, n, fl = eng.profile_read(k)
                 if n:
-                    fam[k] = (ms, n, fl)
+                    fam[k] = (ms, n, fl, eng.profile_kernels(k))
             # bf16x3 issues three bf16 MFMAs per algorithmic product
             peak = {"f32": PEAK_F32_MATRIX_TFLOPS, "bf16x3": PEAK_BF16_MATRIX_TFLOPS / 3, "bf16": PEAK_BF16_MATRIX_TFLOPS}[a.precision]
-            gemm_name = (("rows::gemm_rows_kernel<4,5,*> (one sequence: 48..256 windows)" if 48 <= B <= 256 else
-                          "gemm_f32_kernel<1,*> / glds::gemm_glds_kernel<true,1,...>") if a.precision == "f32" else
-                         "glds::gemm_glds_kernel<false,1,*,128,128>" if a.precision == "bf16" else "gemm_bf16_kernel<1,*,3>")
-            names = {0: gemm_name + " (decoder_input o conv 0 as one layer: forward + backward-data)",
-                     1: "decoder_tail_kernel (convs 256->128->64->64->64->45, energy terms, adjoint convs; fp32 in every precision mode)"}
+            what = {0: "decoder_input o conv 0 as one layer: forward + backward-data",
+                    1: "fused decoder tail: convs 256->128->64->64->64->45, energy terms, adjoint convs"}
 
             def roof_of(k):
-                ms, n, fl = fam[k]
+                ms, n, fl, names = fam[k]
                 achieved = fl / (ms * 1e-3) / 1e12
-                pk = peak if k == 0 else PEAK_F32_MATRIX_TFLOPS
-                r = {"bound": "mfma", "achieved": round(achieved, 3), "peak": round(pk, 1), "unit": "TFLOP/s", "frac": round(achieved / pk, 4),
-                     "traffic": None, "kernel": names[k], "launches": int(n), "avg_us": round(ms * 1e3 / n, 2), "flop_per_launch": fl / n,
-                     "share_of_step": round(ms * 1e-3 / min(PROFILE_STEPS, a.steps) / (elapsed / a.steps), 3)}
-                if traffic and a.precision == "f32" and traffic_kernel and (("tail" in traffic_kernel) == (k == 1)):
-                    r["traffic"] = traffic
-                    r["traffic_source"] = ("profiles/traffic_dominant_kernel.json (separate rocprofv3 --pmc passes of this command, "
-                                           "committed; NOT measured in this run)")
-                return r
+                pk = peak if (k == 0 or "bf16" in names) else PEAK_F32_MATRIX_TFLOPS        # (the one-window tail is fp32 in every mode)
+                tr_b, tr_src = committed_traffic(names)
+                return {"bound": "mfma", "achieved": round(achieved, 3), "peak": round(pk, 1), "unit": "TFLOP/s", "frac": round(achieved / pk, 4),
+                        "traffic": tr_b, "traffic_source": tr_src, "kernel": names, "what": what[k], "launches": int(n),
+                        "avg_us": round(ms * 1e3 / n, 2), "flop_per_launch": fl / n,
+                        "share_of_step": round(ms * 1e-3 / min(PROFILE_STEPS, a.steps) / (elapsed / a.steps), 3)}
             if fam:
                 dom = max(fam, key=lambda k: fam[k][0])
                 roof = roof_of(dom)
@@ -548,6 +728,7 @@ def main():
             "cpu_baseline": cpu,
             "other_precisions": other_modes or None,
             "configs2": configs2,
+            "configs3": configs3,
             "configs4": configs4,
             "sequences_in_flight": in_flight,
         }

@@ -78,6 +78,7 @@ static int launch_k(gem_handle* h, const Args& a, int grid, hipStream_t s) {
     static PerDeviceOnce once;
     if (once.need(h->cfg.device))
         GEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    note_kernel(h, reinterpret_cast<const void*>(k));
     hipLaunchKernelGGL(k, dim3(grid), dim3((BM / 64) * (BN / 64) * 64), smem, s, a);
     GEM_HIP(hipGetLastError());
     return 0;
@@ -163,6 +164,7 @@ static int gemm_bf16a(gem_handle* h, const Layer& L, int epi, const uint16_t* A,
         }
     }
     if (prof) { GEM_HIP(hipEventRecord(rec.b, s)); h->prof.recs.push_back(rec); }
+    commit_kernel_names(h, prof ? family : -1);
     return 0;
 }
 
@@ -214,7 +216,7 @@ int evaluate_bf16(gem_handle* h, int stage, int B, const EnergyArgs& ea_in, hipS
         }
         TailB16Args ta;
         plan_tail_bf16(net.dec, st, T, h->J, &ta);
-        ta.B = B; ta.forward_only = forward_only ? 1 : 0;
+        ta.B = B; ta.forward_only = forward_only ? 1 : 0; ta.dbg_ts = nullptr;
         ta.in_slab = in_slab; ta.in_bias = front ? net.front.bias : net.dec[st - 1].bias;
         ta.in_bias_ld = front ? net.dec[0].N : 0;
         for (int i = 0; i < ta.n; ++i) {

@@ -1,5 +1,5 @@
-// Energy terms + analytic gradient of ONE window, executed by ONE wavefront (64 lanes).
-// Shared by the stand-alone energy kernel (energy.hip) and the fused decoder-tail kernel (tail.hip).
+// Energy terms + analytic gradient of ONE window, executed by ONE wavefront (64 lanes) or by a whole workgroup.
+// Shared by the stand-alone energy kernel (energy.hip) and the fused decoder-tail kernels (tail.hip, tail_bf16.hip).
 // Reference: optimizer.py:139-149,172-177,202-213,226-240; utils/fisheye/FishEyeCalibrated.py:96-129.
 #pragma once
 #include "gem_internal.h"
@@ -26,18 +26,81 @@ __device__ __forceinline__ void energy_sync() {
     }
 }
 
-// xsrc: decoded pose rows [T][ldx] (global or LDS); xs/gs/bs/as: LDS scratch of ENERGY_SCRATCH floats each;
-// gdst: gradient rows [T][ldg], columns [J*3, gcols) are zero-filled.
+// Per-lane inputs of a window's energy terms that do not depend on the decoded pose, fetched AHEAD (the bf16 tail requests
+// them at kernel start and keeps them in registers across its forward layers): the stage-input pose values the lane will
+// meet in its strided passes, and -- per (frame, joint) pair of the lane -- mean bone length, parent index and the cached
+// texel block of the reprojection term.  NE / NP = passes over the T*J*3 values / the T*J pairs with 64 lanes.
+template <int NE, int NP>
+struct EnergyPre {
+    float x0[NE];
+    float mb[NP];
+    int par[NP];
+    int key[NP];
+    f32x4_t val[NP];
+};
+struct NoEnergyPre {};
+
+// strided pass over [0, n): e = lane, lane + NT, ...; f(e, it) with the pass index `it`.  CN > 0: n is the compile-time CN,
+// the pass is unrolled (so `it` is a constant inside f: register arrays indexed by it stay in registers).
+template <int NT, int CN, typename F>
+__device__ __forceinline__ void lane_pass(int lane, int n, F f) {
+    if constexpr (CN > 0) {
+#pragma unroll
+        for (int it = 0; it < (CN + NT - 1) / NT; ++it) {
+            const int e = lane + it * NT;
+            if (e < CN) f(e, it);
+        }
+    } else {
+        int it = 0;
+        for (int e = lane; e < n; e += NT, ++it) f(e, it);
+    }
+}
+
+// the prefetch itself (one wavefront per window): issued early by the caller, consumed by energy_window<..., Pre>
+template <int CT, int CJ>
+__device__ __forceinline__ void energy_prefetch(const EnergyArgs& a, int b, int lane, EnergyPre<(CT * CJ * 3 + 63) / 64, (CT * CJ + 63) / 64>& pre) {
+    constexpr int n = CT * CJ * 3, TJ = CT * CJ;
+#pragma unroll
+    for (int it = 0; it < (n + 63) / 64; ++it) {
+        const int e = lane + it * 64;
+        pre.x0[it] = e < n ? a.X0[(size_t)b * n + e] : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < (TJ + 63) / 64; ++it) {
+        const int p = lane + it * 64;
+        pre.mb[it] = 0.f; pre.par[it] = 0; pre.key[it] = -1; pre.val[it] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (p < TJ) {
+            const int j = p % CJ;
+            pre.mb[it] = a.mean_bone[(size_t)b * CJ + j];
+            pre.par[it] = a.parents[j];
+            if (a.tex_key && a.wr != 0.f) {
+                const size_t ci = (size_t)b * TJ + p;
+                pre.key[it] = a.tex_key[ci];
+                pre.val[it] = *reinterpret_cast<const f32x4_t*>(a.tex_val + ci * 4);
+            }
+        }
+    }
+}
+
+// xsrc: decoded pose rows [T][ldx] (global or LDS); xs/gs/bs/as: LDS scratch of ENERGY_SCRATCH floats each (xs may BE xsrc
+// when that is already the dense [T][J*3] image: XS_IS_SRC); gdst: gradient rows [T][ldg], columns [J*3, gcols) are zero-filled.
 // NT threads work on the window (`lane` = 0..NT-1): 64 = one wavefront; more = the whole workgroup (BLOCK_SYNC), so
 // that the T*J*3 = 450 values are one pass and every global-memory latency (x0, mean bone, heat-map texels) is paid
 // once instead of once per 64-lane pass.
-template <bool BLOCK_SYNC, int NT = 64>
+// CT / CJ: compile-time frames / joints (0: run-time a.T / a.J).  With them the index arithmetic (e / JC, p / J) folds into
+// multiplies and the passes unroll; the arithmetic on the DATA is the same instruction for instruction, so results are
+// bitwise those of the run-time version.  Pre: EnergyPre of this lane (NT == 64, CT and CJ given) or NoEnergyPre.
+template <bool BLOCK_SYNC, int NT = 64, int CT = 0, int CJ = 0, bool XS_IS_SRC = false, typename Pre = NoEnergyPre>
 __device__ __forceinline__ void energy_window(const EnergyArgs& a, int b, int lane, const float* xsrc, int ldx, float* xs,
                                               float* gs, float* bs, float* as, float* gdst, int ldg, int gcols,
                                               uint16_t* gdst_b = nullptr, const float* x0_w = nullptr, const float* mb_w = nullptr,
-                                              const int* par_w = nullptr, const int* ch_w = nullptr) {
+                                              const int* par_w = nullptr, const int* ch_w = nullptr, const Pre* pre = nullptr) {
     static_assert(NT == 64 || BLOCK_SYNC, "more than one wavefront per window needs workgroup barriers");
-    const int T = a.T, J = a.J, JC = J * 3, n = T * JC;
+    static_assert((CT > 0) == (CJ > 0), "give both compile-time dimensions or none");
+    constexpr bool HAS_PRE = !__is_same(Pre, NoEnergyPre);
+    static_assert(!HAS_PRE || (NT == 64 && CT > 0), "prefetched inputs are per lane of ONE wavefront with compile-time dimensions");
+    const int T = CT ? CT : a.T, J = CJ ? CJ : a.J, JC = J * 3, n = T * JC;
+    constexpr int CN = CT * CJ * 3, CP = CT * CJ;
     // x0_w / mb_w / par_w / ch_w: this window's stage-input pose, mean bone lengths and the skeleton tables when the caller has
     // already brought them on chip (the fused tail loads them into LDS while its first layers run); else from global memory
     const float* x0 = x0_w ? x0_w : a.X0 + (size_t)b * n;
@@ -46,18 +109,20 @@ __device__ __forceinline__ void energy_window(const EnergyArgs& a, int b, int la
     const int* children = ch_w ? ch_w : a.children;
 
     double e3d = 0, esm = 0, ebone = 0, evae = 0, erep = 0;
-    for (int e = lane; e < n; e += NT) {
+    lane_pass<NT, CN>(lane, n, [&](int e, int it) {
         const int t = e / JC, c = e - t * JC;
         const float x = xsrc[t * ldx + c];
-        xs[e] = x;
-        const float d = x - x0[e];
+        if (!XS_IS_SRC) xs[e] = x;
+        float x0v;
+        if constexpr (HAS_PRE) x0v = pre->x0[it]; else x0v = x0[e];
+        const float d = x - x0v;
         e3d += (double)(d * d);
         evae += (double)(x * x);
         gs[e] = 2.f * a.w3d * d + 2.f * a.wv * x;
-    }
+    });
     energy_sync<BLOCK_SYNC>();
     // smoothness: acceleration a_t (t = 1..T-2) then gather
-    for (int e = lane; e < n; e += NT) {
+    lane_pass<NT, CN>(lane, n, [&](int e, int) {
         const int t = e / JC;
         float acc = 0.f;
         if (t >= 1 && t <= T - 2) {
@@ -65,23 +130,25 @@ __device__ __forceinline__ void energy_window(const EnergyArgs& a, int b, int la
             esm += (double)(acc * acc);
         }
         as[e] = acc;
-    }
+    });
     // bone length: per (t, joint)
-    for (int p = lane; p < T * J; p += NT) {
+    lane_pass<NT, CP>(lane, T * J, [&](int p, int it) {
         const int t = p / J, j = p - t * J;
-        const int par = parents[j];
+        int par;
+        float mbv;
+        if constexpr (HAS_PRE) { par = pre->par[it]; mbv = pre->mb[it]; } else { par = parents[j]; mbv = mbone[j]; }
         const float* xj = xs + (t * J + j) * 3;
         const float* xp = xs + (t * J + par) * 3;
         const float bx = xj[0] - xp[0], by = xj[1] - xp[1], bz = xj[2] - xp[2];
         const float len = sqrtf(bx * bx + by * by + bz * bz);
-        const float diff = len - mbone[j];
+        const float diff = len - mbv;
         ebone += (double)(diff * diff);
         const float coef = len > 0.f ? 2.f * a.wb * diff / len : 0.f;     // d|v|/dv := 0 at v = 0 (torch)
         float* o = bs + (t * J + j) * 3;
         o[0] = coef * bx; o[1] = coef * by; o[2] = coef * bz;
-    }
+    });
     energy_sync<BLOCK_SYNC>();
-    for (int e = lane; e < n; e += NT) {
+    lane_pass<NT, CN>(lane, n, [&](int e, int) {
         const int t = e / JC;
         float g = gs[e];
         const float w2 = 2.f * a.ws;
@@ -89,9 +156,9 @@ __device__ __forceinline__ void energy_window(const EnergyArgs& a, int b, int la
         if (t >= 2) g += w2 * as[e - JC];
         if (t <= T - 3) g += w2 * as[e + JC];
         gs[e] = g;
-    }
+    });
     energy_sync<BLOCK_SYNC>();
-    for (int p = lane; p < T * J; p += NT) {
+    lane_pass<NT, CP>(lane, T * J, [&](int p, int it) {
         const int t = p / J, j = p - t * J;
         float gx = bs[p * 3 + 0], gy = bs[p * 3 + 1], gz = bs[p * 3 + 2];
         const int* ch = children + j * MAXJ;
@@ -143,10 +210,15 @@ __device__ __forceinline__ void energy_window(const EnergyArgs& a, int b, int la
             const size_t ci = (size_t)b * (T * J) + p;
             bool hit = false;
             if (a.tex_key && in) {
-                hit = a.tex_key[ci] == key;
-                if (hit) {
-                    const f32x4_t c = *reinterpret_cast<const f32x4_t*>(a.tex_val + ci * 4);
-                    nw = c[0]; ne = c[1]; sw = c[2]; se = c[3];
+                if constexpr (HAS_PRE) {
+                    hit = pre->key[it] == key;
+                    if (hit) { nw = pre->val[it][0]; ne = pre->val[it][1]; sw = pre->val[it][2]; se = pre->val[it][3]; }
+                } else {
+                    hit = a.tex_key[ci] == key;
+                    if (hit) {
+                        const f32x4_t c = *reinterpret_cast<const f32x4_t*>(a.tex_val + ci * 4);
+                        nw = c[0]; ne = c[1]; sw = c[2]; se = c[3];
+                    }
                 }
             }
             if (!hit) {
@@ -184,14 +256,23 @@ __device__ __forceinline__ void energy_window(const EnergyArgs& a, int b, int la
             gz += gu * dudz + gv * dvdz;
         }
         gs[p * 3 + 0] += gx; gs[p * 3 + 1] += gy; gs[p * 3 + 2] += gz;
-    }
+    });
     energy_sync<BLOCK_SYNC>();
     // gradient rows, zero-padded
-    for (int i = lane; i < T * gcols; i += NT) {
-        const int t = i / gcols, c = i - t * gcols;
-        const float v = c < JC ? gs[t * JC + c] : 0.f;
-        if (gdst_b) gdst_b[t * ldg + c] = (uint16_t)(__builtin_bit_cast(unsigned int, (float)(__bf16)v) >> 16);
-        else gdst[t * ldg + c] = v;
+    if (CT > 0 && gcols == 64) {
+        lane_pass<NT, CT * 64>(lane, T * 64, [&](int i, int) {
+            const int t = i >> 6, c = i & 63;
+            const float v = c < JC ? gs[t * JC + c] : 0.f;
+            if (gdst_b) gdst_b[t * ldg + c] = (uint16_t)(__builtin_bit_cast(unsigned int, (float)(__bf16)v) >> 16);
+            else gdst[t * ldg + c] = v;
+        });
+    } else {
+        for (int i = lane; i < T * gcols; i += NT) {
+            const int t = i / gcols, c = i - t * gcols;
+            const float v = c < JC ? gs[t * JC + c] : 0.f;
+            if (gdst_b) gdst_b[t * ldg + c] = (uint16_t)(__builtin_bit_cast(unsigned int, (float)(__bf16)v) >> 16);
+            else gdst[t * ldg + c] = v;
+        }
     }
     e3d = wave_sum(e3d); esm = wave_sum(esm); ebone = wave_sum(ebone); evae = wave_sum(evae); erep = wave_sum(erep);
     if (NT > 64) {                   // combine the wavefronts' partial sums in wave order (as[] is free by now)

@@ -1,6 +1,8 @@
 // C-ABI entry points of libgem_hip.so (see include/gem_hip.h) and the host-side orchestration of the
 // evaluation rounds.  Host code only: weight folding / packing, workspace management and kernel
 // sequencing; all arithmetic of the path runs in the HIP kernels of gemm_f32.hip, energy.hip, lbfgs.hip.
+#include <cxxabi.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -24,6 +26,25 @@ const char* dev_env(const char* name) {
     const char* on = getenv("GEM_DEV");
     if (!on || on[0] != '1') return nullptr;
     return getenv(name);
+}
+
+void note_kernel(gem_handle* h, const void* host_fn) {
+    if (!h->prof.on) return;
+    const char* m = hipKernelNameRefByPtr(host_fn, nullptr);
+    if (!m) return;
+    int st = 0;
+    char* d = abi::__cxa_demangle(m, nullptr, nullptr, &st);
+    std::string n = (st == 0 && d) ? d : m;
+    free(d);
+    if (n.rfind("void ", 0) == 0) n = n.substr(5);
+    // drop the parameter list: everything from the '(' that closes the template-argument list
+    int depth = 0;
+    for (size_t i = 0; i < n.size(); ++i) {
+        if (n[i] == '<') ++depth;
+        else if (n[i] == '>') --depth;
+        else if (n[i] == '(' && depth == 0) { n.resize(i); break; }
+    }
+    h->prof.pending.insert(n);
 }
 
 // Every captured call bakes weight and workspace pointers into its kernel arguments: whatever re-allocates them drops the cache.
@@ -893,6 +914,18 @@ int gem_lift_skeleton(gem_handle* h, const float* d_heat, const double* d_depth,
 int gem_profile_enable(gem_handle* h, int on) {
     if (!h) { set_error("gem_profile_enable: null handle"); return 1; }
     h->prof.on = on != 0;
+    return 0;
+}
+
+int gem_profile_kernels(gem_handle* h, int family, char* buf, int buf_len) {
+    if (!h || family < 0 || family > 3 || !buf || buf_len < 1) { set_error("gem_profile_kernels: bad argument"); return 1; }
+    std::string out;
+    for (const auto& n : h->prof.names[family]) {
+        if (!out.empty()) out += "; ";
+        out += n;
+    }
+    h->prof.names[family].clear();
+    snprintf(buf, (size_t)buf_len, "%s", out.c_str());
     return 0;
 }
 

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <atomic>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -154,6 +155,10 @@ struct Profile {
     double total_ms[4] = {0, 0, 0, 0};
     int64_t n[4] = {0, 0, 0, 0};
     double flops[4] = {0, 0, 0, 0};      // family 3 (input lifting) counts algorithmic BYTES here
+    // names (as rocprofv3 prints them) of the kernels launched for each timed family since the last gem_profile_kernels call:
+    // bench.py labels its roofline objects with what actually ran, not with what it expects to run
+    std::set<std::string> names[4];
+    std::set<std::string> pending;       // kernels launched since the current timed launcher began
 };
 
 // Wavefront reductions on the DPP cross-lane path (no LDS traffic): quad swaps, half-row and row mirrors
@@ -230,6 +235,13 @@ struct gem_handle {
 };
 
 namespace gem {
+
+// profiling hook: remember the (demangled) name of a kernel about to be launched; no-op unless event profiling is on
+void note_kernel(gem_handle* h, const void* host_fn);
+inline void commit_kernel_names(gem_handle* h, int family) {
+    if (family >= 0 && family < 4) h->prof.names[family].insert(h->prof.pending.begin(), h->prof.pending.end());
+    h->prof.pending.clear();
+}
 
 // ---- kernel launchers (each enqueues on `s`, returns 0/1) -------------------------------------------
 int launch_gemm(gem_handle* h, const Layer& L, int epi, const float* A, int lda, const float* aux, float* Cout, int ldc,
@@ -339,12 +351,13 @@ struct TailB16Args {
     const uint16_t* a_in_b;    // [B*T, K0] bf16 input activation (post-LeakyReLU) when there are no slabs
     uint16_t* g_out_b;         // [B*T, K0] bf16 gradient w.r.t. the input's pre-activation
     float* Xp;                 // [B*T, 64] decoded pose (fp32) or nullptr
+    long long* dbg_ts;         // developer probe (tools/tail16_bench): {shader clock, 100 MHz wall clock} pairs of workgroup 0, or nullptr
     const uint16_t* wstream;   // StageNet::tb_stream
     int steps_f, steps_total;  // steps (1 KB fragments) per wave: forward part / forward + adjoint
     TailB16Layer fwd[TB_MAX_LAYERS], bwd[TB_MAX_LAYERS];
     // LDS plan, byte offsets / row strides in bytes (row stride = 2 * width + 32: conflict-free ds_read_b128 fragment reads)
     int off_act[TB_MAX_LAYERS + 1], ld_act[TB_MAX_LAYERS + 1];      // act[0] = input (region shared with the energy scratch / output staging)
-    int off_g[2], ld_g[2], off_x, off_escr, escr, off_zero, off_mask, ld_mask;
+    int off_g[2], ld_g[2], off_x, off_escr, escr, off_zero, off_mask, ld_mask, off_tab;
     EnergyArgs e;
 };
 size_t plan_tail_bf16(const std::vector<Layer>& dec, int start, int T, int J, TailB16Args* out);

@@ -330,6 +330,7 @@ static int launch_b(gem_handle* h, const Layer& L, const float* A, int lda, cons
         if (big_once.need(h->cfg.device)) {
             GEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         }
+        note_kernel(h, reinterpret_cast<const void*>(kb));
         hipLaunchKernelGGL(kb, dim3(L.N / 128, (M + 127) / 128, 1), dim3(256), smem, s, A, lda, L.wb_hi, L.wb_lo, L.bias, aux, C, ldc,
                            M, L.N, L.K, T, m_dev, row_map);
         GEM_HIP(hipGetLastError());
@@ -354,6 +355,7 @@ static int launch_b(gem_handle* h, const Layer& L, const float* A, int lda, cons
     }
     float* out = grid.z == 1 ? C : h->ws.splitk;
     const int dyn_W = (m_dev && grid.z > 1 && (size_t)wgs * 64 * 64 <= h->ws.splitk_elems) ? (int)wgs : 0;
+    note_kernel(h, reinterpret_cast<const void*>(k));
     hipLaunchKernelGGL(k, grid, dim3(256), shmem, s, A, lda, L.wb_hi, L.wb_lo, L.bias, aux, out, ldc, M, L.N, L.K, T,
                        grid.z == 1 ? n_tiles : per, grid.z == 1 ? (size_t)0 : slab, m_dev, row_map, dyn_W);
     GEM_HIP(hipGetLastError());

@@ -332,11 +332,13 @@ static int launch_one(gem_handle* h, const Layer& L, const float* A, int lda, co
     // evaluation rounds on small batches: slices re-cut on the device for the rows that are still active
     const bool dyn = m_dev && RM * RN == 1 && grid.z > 1 && (size_t)wgs * 64 * BN <= h->ws.splitk_elems;
     if (grid.z == 1) {
+        note_kernel(h, reinterpret_cast<const void*>(k));
         hipLaunchKernelGGL(k, grid, dim3(256), shmem, s, A, lda, L.w, L.bias, aux, C, ldc, M, L.N, L.K, T, n_tiles, (size_t)0, m_dev,
                            row_map, 0);
         GEM_HIP(hipGetLastError());
         return 0;
     }
+    note_kernel(h, reinterpret_cast<const void*>(k));
     hipLaunchKernelGGL(k, grid, dim3(256), shmem, s, A, lda, L.w, L.bias, aux, h->ws.splitk, ldc, M, L.N, L.K, T, per, slab, m_dev,
                        row_map, dyn ? (int)wgs : 0);
     GEM_HIP(hipGetLastError());
@@ -369,6 +371,7 @@ static int launch_glds_f32(gem_handle* h, const Layer& L, const float* A, int ld
     a.lda = lda; a.ldc = ldc; a.M = M; a.N = L.N; a.K = L.K; a.T = T;
     a.n_split = 1; a.tiles_per_split = TAPS * (L.K / 32); a.slab_stride = 0;
     const int grid = ((M + BM - 1) / BM) * (L.N / BN);
+    note_kernel(h, reinterpret_cast<const void*>(k));
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), smem, s, a);
     GEM_HIP(hipGetLastError());
     return 0;
@@ -398,6 +401,7 @@ static int launch_rows_as(gem_handle* h, const Layer& L, const float* A, int lda
         a.perm_out = w.perm; a.slot_of_out = w.slot_of; a.n_active_out = w.n_active; a.log_slot = w.fuse_log;
     }
     const int grid = p.n_rb * (L.N / rows::BN) * p.n_split;
+    note_kernel(h, reinterpret_cast<const void*>(k));
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), (size_t)S * rows::Geometry<RT>::STAGE_BYTES, s, a);
     GEM_HIP(hipGetLastError());
     return 0;
@@ -533,6 +537,7 @@ int launch_gemm(gem_handle* h, const Layer& L, int epi, const float* A, int lda,
         GEM_HIP(hipEventRecord(rec.b, s));
         h->prof.recs.push_back(rec);
     }
+    commit_kernel_names(h, prof ? family : -1);
     return 0;
 }
 

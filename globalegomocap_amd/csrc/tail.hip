@@ -286,10 +286,16 @@ __global__ __launch_bounds__(TAIL_THREADS, 2) void decoder_tail_kernel(TailArgs 
         const int J = a.e.J, n = T * J * 3;
         const float* pre = lds + a.off_pre;
         const int* prei = reinterpret_cast<const int*>(pre + n + J);
-        energy_window<true, TAIL_THREADS>(a.e, a.e.perm ? a.e.perm[w0] : w0, tid, lds + a.off_act[NL], a.ld_act[NL], scr,
-                                          scr + a.escr, scr + 2 * a.escr, scr + 3 * a.escr, g_cur, a.ld_g, a.fwd[NL - 1].N,
-                                          nullptr, pre_on ? pre : nullptr, pre_on ? pre + n : nullptr, pre_on ? prei : nullptr,
-                                          pre_on ? prei + J : nullptr);
+        if (T == 10 && J == 15)      // the usual window shape: compile-time index arithmetic (same numbers)
+            energy_window<true, TAIL_THREADS, 10, 15>(a.e, a.e.perm ? a.e.perm[w0] : w0, tid, lds + a.off_act[NL], a.ld_act[NL], scr,
+                                                      scr + a.escr, scr + 2 * a.escr, scr + 3 * a.escr, g_cur, a.ld_g, a.fwd[NL - 1].N,
+                                                      nullptr, pre_on ? pre : nullptr, pre_on ? pre + n : nullptr, pre_on ? prei : nullptr,
+                                                      pre_on ? prei + J : nullptr);
+        else
+            energy_window<true, TAIL_THREADS>(a.e, a.e.perm ? a.e.perm[w0] : w0, tid, lds + a.off_act[NL], a.ld_act[NL], scr,
+                                              scr + a.escr, scr + 2 * a.escr, scr + 3 * a.escr, g_cur, a.ld_g, a.fwd[NL - 1].N,
+                                              nullptr, pre_on ? pre : nullptr, pre_on ? pre + n : nullptr, pre_on ? prei : nullptr,
+                                              pre_on ? prei + J : nullptr);
     } else if (wave < nwin) {
         float* scr = lds + a.off_escr + wave * 4 * a.escr;
         energy_window<false>(a.e, a.e.perm ? a.e.perm[w0 + wave] : w0 + wave, lane,
@@ -389,16 +395,17 @@ int launch_tail(gem_handle* h, const TailArgs& a, size_t lds_bytes, hipStream_t 
     }
     const int wgs = (a.B + a.G - 1) / a.G;
     switch (a.n) {
-        case 1: hipLaunchKernelGGL(decoder_tail_kernel<1>, dim3(wgs), dim3(TAIL_THREADS), lds_bytes, s, a); break;
-        case 2: hipLaunchKernelGGL(decoder_tail_kernel<2>, dim3(wgs), dim3(TAIL_THREADS), lds_bytes, s, a); break;
-        case 3: hipLaunchKernelGGL(decoder_tail_kernel<3>, dim3(wgs), dim3(TAIL_THREADS), lds_bytes, s, a); break;
-        case 4: hipLaunchKernelGGL(decoder_tail_kernel<4>, dim3(wgs), dim3(TAIL_THREADS), lds_bytes, s, a); break;
-        case 5: hipLaunchKernelGGL(decoder_tail_kernel<5>, dim3(wgs), dim3(TAIL_THREADS), lds_bytes, s, a); break;
-        case 6: hipLaunchKernelGGL(decoder_tail_kernel<6>, dim3(wgs), dim3(TAIL_THREADS), lds_bytes, s, a); break;
+        case 1: note_kernel(h, reinterpret_cast<const void*>(decoder_tail_kernel<1>)); hipLaunchKernelGGL(decoder_tail_kernel<1>, dim3(wgs), dim3(TAIL_THREADS), lds_bytes, s, a); break;
+        case 2: note_kernel(h, reinterpret_cast<const void*>(decoder_tail_kernel<2>)); hipLaunchKernelGGL(decoder_tail_kernel<2>, dim3(wgs), dim3(TAIL_THREADS), lds_bytes, s, a); break;
+        case 3: note_kernel(h, reinterpret_cast<const void*>(decoder_tail_kernel<3>)); hipLaunchKernelGGL(decoder_tail_kernel<3>, dim3(wgs), dim3(TAIL_THREADS), lds_bytes, s, a); break;
+        case 4: note_kernel(h, reinterpret_cast<const void*>(decoder_tail_kernel<4>)); hipLaunchKernelGGL(decoder_tail_kernel<4>, dim3(wgs), dim3(TAIL_THREADS), lds_bytes, s, a); break;
+        case 5: note_kernel(h, reinterpret_cast<const void*>(decoder_tail_kernel<5>)); hipLaunchKernelGGL(decoder_tail_kernel<5>, dim3(wgs), dim3(TAIL_THREADS), lds_bytes, s, a); break;
+        case 6: note_kernel(h, reinterpret_cast<const void*>(decoder_tail_kernel<6>)); hipLaunchKernelGGL(decoder_tail_kernel<6>, dim3(wgs), dim3(TAIL_THREADS), lds_bytes, s, a); break;
         default: set_error("launch_tail: unsupported number of fused layers"); return 1;
     }
     GEM_HIP(hipGetLastError());
     if (prof) { GEM_HIP(hipEventRecord(rec.b, s)); h->prof.recs.push_back(rec); }
+    commit_kernel_names(h, prof ? 1 : -1);
     return 0;
 }
 

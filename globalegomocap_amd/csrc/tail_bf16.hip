@@ -149,6 +149,13 @@ __global__ __launch_bounds__(THREADS, 2) void decoder_tail_bf16_kernel(TailB16Ar
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, q = lane >> 4;
     const int T = a.e.T;
+    int probe = 0;
+#define TB_PROBE()                                                                                     \
+    if (a.dbg_ts && blockIdx.x == 0 && tid == 0) {                                                     \
+        a.dbg_ts[2 * probe] = clock64();                                                               \
+        a.dbg_ts[2 * probe + 1] = wall_clock64();                                                      \
+        ++probe;                                                                                       \
+    }
     const int w0 = blockIdx.x * a.G;                         // first slot of this workgroup
     const int B = a.e.n_dev ? *a.e.n_dev : a.B;              // active slots this round
     if (w0 >= B) return;
@@ -163,6 +170,14 @@ __global__ __launch_bounds__(THREADS, 2) void decoder_tail_bf16_kernel(TailB16Ar
 #pragma unroll
     for (int i = 0; i < RING; ++i) ring[i] = wp[(size_t)min(i, last_step) * 64];
     int consumed = 0;
+    // ---- what the energy terms need besides the decoded pose (stage-input pose, bone lengths, cached texel blocks of this
+    // wave's window) is requested now and stays in registers across the forward layers: the energy phase then starts without
+    // a global round trip.  (The usual window shape, 10 frames x 15 joints, has compile-time index arithmetic as well.)
+    const bool fast_e = T == 10 && a.e.J == 15;
+    EnergyPre<8, 3> pre;
+    const int bwin = (wave < nwin) ? (a.e.perm ? a.e.perm[w0 + wave] : w0 + wave) : 0;
+    if (fast_e && !a.forward_only && wave < nwin) energy_prefetch<10, 15>(a.e, bwin, lane, pre);
+    TB_PROBE();
 
     // ---- stage the input rows as bf16 (+ one sign bit per element: the LeakyReLU' mask of the last adjoint layer; the region
     // itself is reused by the energy terms and the output staging).  In the rounds the producer GEMM leaves fp32 split-K slabs:
@@ -172,41 +187,69 @@ __global__ __launch_bounds__(THREADS, 2) void decoder_tail_bf16_kernel(TailB16Ar
         int nslab = 0;
         size_t stride = 0;
         if (a.in_slab.base) slab_layout(a.in_slab, nslab, stride);
-        for (int idx = tid; idx < nchunk; idx += THREADS) {
-            const int r = idx / cpr, c8 = (idx - r * cpr) * 8;
-            u32x4 o = {0u, 0u, 0u, 0u};
-            unsigned int bits = 0;
-            if (r < R) {
-                if (a.in_slab.base) {
-                    const float* p = a.in_slab.base + (row0 + r) * K0 + c8;
-                    f32x4 v0 = *reinterpret_cast<const f32x4*>(p), v1 = *reinterpret_cast<const f32x4*>(p + 4);
-                    for (int z = 1; z < nslab; ++z) {
-                        v0 += *reinterpret_cast<const f32x4*>(p + (size_t)z * stride);
-                        v1 += *reinterpret_cast<const f32x4*>(p + (size_t)z * stride + 4);
-                    }
-                    const float* bp = a.in_bias + (r % T) * a.in_bias_ld + c8;
-                    v0 += *reinterpret_cast<const f32x4*>(bp);
-                    v1 += *reinterpret_cast<const f32x4*>(bp + 4);
-                    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        constexpr int UN = 5;                  // chunks (8 values) per thread and trip: all their loads in flight together
+        for (int u0 = 0; u0 < nchunk; u0 += UN * THREADS) {
+            int r[UN], c8[UN];
+            bool ok[UN];
+            u32x4 o[UN];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = lrelu(v[e]);
-                    o = u32x4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
-                } else {
-                    o = *reinterpret_cast<const u32x4*>(a.a_in_b + (row0 + r) * K0 + c8);
+            for (int k = 0; k < UN; ++k) {
+                const int idx = u0 + k * THREADS + tid;
+                r[k] = idx / cpr; c8[k] = (idx - r[k] * cpr) * 8;
+                ok[k] = idx < nchunk && r[k] < R;
+                o[k] = u32x4{0u, 0u, 0u, 0u};
+            }
+            if (a.in_slab.base) {
+                f32x4 v0[UN], v1[UN], b0[UN], b1[UN];
+#pragma unroll
+                for (int k = 0; k < UN; ++k) {
+                    const float* p = a.in_slab.base + (row0 + (ok[k] ? r[k] : 0)) * K0 + (ok[k] ? c8[k] : 0);
+                    const float* bp = a.in_bias + (ok[k] ? (r[k] % T) * a.in_bias_ld + c8[k] : 0);
+                    v0[k] = *reinterpret_cast<const f32x4*>(p); v1[k] = *reinterpret_cast<const f32x4*>(p + 4);
+                    b0[k] = *reinterpret_cast<const f32x4*>(bp); b1[k] = *reinterpret_cast<const f32x4*>(bp + 4);
+                }
+                for (int z = 1; z < nslab; ++z) {
+                    f32x4 t0[UN], t1[UN];
+#pragma unroll
+                    for (int k = 0; k < UN; ++k) {
+                        const float* p = a.in_slab.base + (size_t)z * stride + (row0 + (ok[k] ? r[k] : 0)) * K0 + (ok[k] ? c8[k] : 0);
+                        t0[k] = *reinterpret_cast<const f32x4*>(p); t1[k] = *reinterpret_cast<const f32x4*>(p + 4);
+                    }
+#pragma unroll
+                    for (int k = 0; k < UN; ++k) { v0[k] += t0[k]; v1[k] += t1[k]; }
                 }
 #pragma unroll
+                for (int k = 0; k < UN; ++k) {
+                    v0[k] += b0[k]; v1[k] += b1[k];
+                    float v[8] = {v0[k][0], v0[k][1], v0[k][2], v0[k][3], v1[k][0], v1[k][1], v1[k][2], v1[k][3]};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = lrelu(v[e]);
+                    if (ok[k]) o[k] = u32x4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < UN; ++k)
+                    if (ok[k]) o[k] = *reinterpret_cast<const u32x4*>(a.a_in_b + (row0 + r[k]) * K0 + c8[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < UN; ++k) {
+                if (u0 + k * THREADS + tid >= nchunk) continue;
+                unsigned int bits = 0;
+#pragma unroll
                 for (int e = 0; e < 4; ++e) {          // bf16 > 0: sign bit clear and not zero
-                    const unsigned int lo = o[e] & 0xFFFFu, hi = o[e] >> 16;
+                    const unsigned int lo = o[k][e] & 0xFFFFu, hi = o[k][e] >> 16;
                     bits |= ((lo != 0u && lo < 0x8000u) ? 1u : 0u) << (2 * e);
                     bits |= ((hi != 0u && hi < 0x8000u) ? 1u : 0u) << (2 * e + 1);
                 }
+                *reinterpret_cast<u32x4*>(lds + a.off_act[0] + r[k] * a.ld_act[0] + c8[k] * 2) = o[k];
+                lds[a.off_mask + r[k] * a.ld_mask + (c8[k] >> 3)] = (unsigned char)bits;
             }
-            *reinterpret_cast<u32x4*>(lds + a.off_act[0] + r * a.ld_act[0] + c8 * 2) = o;
-            lds[a.off_mask + r * a.ld_mask + (c8 >> 3)] = (unsigned char)bits;
         }
         for (int i = tid; i < ZERO_BYTES / 4; i += THREADS) reinterpret_cast<unsigned int*>(lds + a.off_zero)[i] = 0u;
+        if (tid < a.e.J * MAXJ) reinterpret_cast<int*>(lds + a.off_tab)[tid] = a.e.children[tid];
     }
     lds_barrier();
+    TB_PROBE();
 
     // ---- forward layers
 #pragma unroll
@@ -239,6 +282,7 @@ __global__ __launch_bounds__(THREADS, 2) void decoder_tail_bf16_kernel(TailB16Ar
                           }
                       });
         lds_barrier();
+        TB_PROBE();
     }
     if (a.forward_only) return;
 
@@ -249,11 +293,18 @@ __global__ __launch_bounds__(THREADS, 2) void decoder_tail_bf16_kernel(TailB16Ar
             float* xs = reinterpret_cast<float*>(lds + a.off_x) + wave * n;
             float* scr = reinterpret_cast<float*>(lds + a.off_escr) + wave * 3 * a.escr;
             const int ldg = a.ld_g[p] / 2;
-            energy_window<false>(a.e, a.e.perm ? a.e.perm[w0 + wave] : w0 + wave, lane, xs, a.e.J * 3, xs, scr, scr + a.escr, scr + 2 * a.escr,
-                                 nullptr, ldg, a.fwd[NL - 1].N, reinterpret_cast<uint16_t*>(lds + a.off_g[p]) + wave * T * ldg);
+            uint16_t* gd = reinterpret_cast<uint16_t*>(lds + a.off_g[p]) + wave * T * ldg;
+            const int* ch = reinterpret_cast<const int*>(lds + a.off_tab);
+            if (fast_e)
+                energy_window<false, 64, 10, 15, true, EnergyPre<8, 3>>(a.e, bwin, lane, xs, 45, xs, scr, scr + a.escr, scr + 2 * a.escr, nullptr, ldg,
+                                                                         a.fwd[NL - 1].N, gd, nullptr, nullptr, nullptr, ch, &pre);
+            else
+                energy_window<false, 64, 0, 0, true>(a.e, bwin, lane, xs, a.e.J * 3, xs, scr, scr + a.escr, scr + 2 * a.escr, nullptr, ldg,
+                                                     a.fwd[NL - 1].N, gd, nullptr, nullptr, nullptr, ch);
         }
     }
     lds_barrier();
+    TB_PROBE();
 
     // ---- backward-data layers (adjoint convs): gradient w.r.t. act[j] into g[j & 1], masked by LeakyReLU'(act[j])
 #pragma unroll
@@ -287,6 +338,7 @@ __global__ __launch_bounds__(THREADS, 2) void decoder_tail_bf16_kernel(TailB16Ar
                           *reinterpret_cast<u32x2*>(lds + out_off + m * out_ld + n0 * 2) = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
                       });
         lds_barrier();
+        TB_PROBE();
     }
     // ---- the staged gradient rows leave as whole rows (16 bytes per lane, 2 * K0 contiguous bytes per row)
     {
@@ -296,6 +348,8 @@ __global__ __launch_bounds__(THREADS, 2) void decoder_tail_bf16_kernel(TailB16Ar
             *reinterpret_cast<u32x4*>(a.g_out_b + (row0 + r) * K0 + c8) = *reinterpret_cast<const u32x4*>(lds + a.off_act[0] + r * a.ld_act[0] + c8 * 2);
         }
     }
+    TB_PROBE();
+#undef TB_PROBE
 }
 
 }  // namespace tb
@@ -347,6 +401,9 @@ size_t plan_tail_bf16(const std::vector<Layer>& dec, int start, int T, int J, Ta
     a.off_mask = off;
     a.ld_mask = dec[start].K / 8;
     off += tb::ROWS * a.ld_mask;
+    off = (off + 15) / 16 * 16;
+    a.off_tab = off;                       // children lists of the skeleton ([J][MAXJ] ints)
+    off += GEM_MAX_JOINTS * GEM_MAX_JOINTS * 4;
     off = (off + 15) / 16 * 16 + 64;       // (+ slack: nothing reads past its row, this keeps it that way under edits)
     if (off > 160 * 1024) return 0;
     if (out) *out = a;
@@ -417,16 +474,17 @@ int launch_tail_bf16(gem_handle* h, const TailB16Args& a, size_t lds_bytes, hipS
     }
     const int wgs = (a.B + a.G - 1) / a.G;
     switch (a.n) {
-        case 1: hipLaunchKernelGGL(tb::decoder_tail_bf16_kernel<1>, dim3(wgs), dim3(tb::THREADS), lds_bytes, s, a); break;
-        case 2: hipLaunchKernelGGL(tb::decoder_tail_bf16_kernel<2>, dim3(wgs), dim3(tb::THREADS), lds_bytes, s, a); break;
-        case 3: hipLaunchKernelGGL(tb::decoder_tail_bf16_kernel<3>, dim3(wgs), dim3(tb::THREADS), lds_bytes, s, a); break;
-        case 4: hipLaunchKernelGGL(tb::decoder_tail_bf16_kernel<4>, dim3(wgs), dim3(tb::THREADS), lds_bytes, s, a); break;
-        case 5: hipLaunchKernelGGL(tb::decoder_tail_bf16_kernel<5>, dim3(wgs), dim3(tb::THREADS), lds_bytes, s, a); break;
-        case 6: hipLaunchKernelGGL(tb::decoder_tail_bf16_kernel<6>, dim3(wgs), dim3(tb::THREADS), lds_bytes, s, a); break;
+        case 1: note_kernel(h, reinterpret_cast<const void*>(tb::decoder_tail_bf16_kernel<1>)); hipLaunchKernelGGL(tb::decoder_tail_bf16_kernel<1>, dim3(wgs), dim3(tb::THREADS), lds_bytes, s, a); break;
+        case 2: note_kernel(h, reinterpret_cast<const void*>(tb::decoder_tail_bf16_kernel<2>)); hipLaunchKernelGGL(tb::decoder_tail_bf16_kernel<2>, dim3(wgs), dim3(tb::THREADS), lds_bytes, s, a); break;
+        case 3: note_kernel(h, reinterpret_cast<const void*>(tb::decoder_tail_bf16_kernel<3>)); hipLaunchKernelGGL(tb::decoder_tail_bf16_kernel<3>, dim3(wgs), dim3(tb::THREADS), lds_bytes, s, a); break;
+        case 4: note_kernel(h, reinterpret_cast<const void*>(tb::decoder_tail_bf16_kernel<4>)); hipLaunchKernelGGL(tb::decoder_tail_bf16_kernel<4>, dim3(wgs), dim3(tb::THREADS), lds_bytes, s, a); break;
+        case 5: note_kernel(h, reinterpret_cast<const void*>(tb::decoder_tail_bf16_kernel<5>)); hipLaunchKernelGGL(tb::decoder_tail_bf16_kernel<5>, dim3(wgs), dim3(tb::THREADS), lds_bytes, s, a); break;
+        case 6: note_kernel(h, reinterpret_cast<const void*>(tb::decoder_tail_bf16_kernel<6>)); hipLaunchKernelGGL(tb::decoder_tail_bf16_kernel<6>, dim3(wgs), dim3(tb::THREADS), lds_bytes, s, a); break;
         default: set_error("launch_tail_bf16: unsupported number of fused layers"); return 1;
     }
     GEM_HIP(hipGetLastError());
     if (prof) { GEM_HIP(hipEventRecord(rec.b, s)); h->prof.recs.push_back(rec); }
+    commit_kernel_names(h, prof ? 1 : -1);
     return 0;
 }
 

@@ -38,6 +38,25 @@ def frame_span(starts, lo, hi, seq_len):
     return int(starts[lo]), int(starts[hi - 1]) + seq_len
 
 
+def frame_runs(starts, idx, seq_len):
+    """Frames the windows `idx` (ascending window indices into `starts`) touch, as the shortest list of contiguous runs
+    [(f0, f1), ...], and every window's first frame re-indexed into the concatenation of those runs -- what a rank holds in HBM
+    for a block-cyclic shard of ONE long sequence: each block of k overlapping windows is 8k + 2 contiguous frames, stored once;
+    only the `seq_len - stride` halo frames between blocks that went to different ranks exist twice, once on each."""
+    runs, local0 = [], np.zeros(len(idx), dtype=np.int32)
+    base = 0
+    for n, i in enumerate(idx):
+        f0, f1 = int(starts[i]), int(starts[i]) + seq_len
+        if runs and f0 <= runs[-1][1]:                       # overlaps / touches the current run: extend it
+            runs[-1][1] = max(runs[-1][1], f1)
+        else:
+            if runs:
+                base += runs[-1][1] - runs[-1][0]
+            runs.append([f0, f1])
+        local0[n] = base + f0 - runs[-1][0]
+    return [tuple(r) for r in runs], local0
+
+
 def all_gather_windows(local, n_windows, group=None):
     """local [n_local, ...] (any float dtype, same trailing shape on every rank) -> [n_windows, ...] on
     every rank, in window order.  Shards may be ragged by one window; they are padded for the collective."""

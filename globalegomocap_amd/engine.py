@@ -335,6 +335,12 @@ class WindowEngine:
     def profile_enable(self, on):
         _capi.check(self.lib.gem_profile_enable(self._h, 1 if on else 0), self.lib)
 
+    def profile_kernels(self, family):
+        """Names (as rocprofv3 prints them) of the kernels launched for `family` while profiling was on, since the last call."""
+        buf = C.create_string_buffer(2048)
+        _capi.check(self.lib.gem_profile_kernels(self._h, family, buf, len(buf)), self.lib)
+        return buf.value.decode()
+
     def profile_read(self, family):
         ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
         _capi.check(self.lib.gem_profile_read(self._h, family, C.byref(ms), C.byref(n), C.byref(fl)), self.lib)

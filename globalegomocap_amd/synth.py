@@ -140,3 +140,27 @@ def make_sequence_device(n_frames, seed, device, camera=None, noise=0.02, sigma=
         "est_local_np": est,
         "cams_np": cams,
     }
+
+
+def make_stream_device(n_frames, seed, device, runs=None, camera=None, noise=0.02, sigma=1.5, block=200, cam_jitter=None):
+    """One long sequence of which this process holds only the frames of `runs` (list of [f0, f1); None = all) in HBM: the small
+    per-frame arrays (poses, cameras, ground truth) are synthesised for the whole stream on the host (they are a function of
+    the seed alone, so every rank sees the same stream), the heat-maps -- 99 % of the bytes -- only for the held frames, on the
+    device.  Returns est_local / cams / heat for the held frames (concatenated runs, device) plus gt_global (host, all frames)."""
+    import torch
+    seq = make_sequence(n_frames, seed, camera, noise, sigma, with_heatmaps=False, cam_jitter=cam_jitter)
+    keep = np.arange(n_frames) if runs is None else np.concatenate([np.arange(f0, f1) for f0, f1 in runs])
+    est = np.asarray(seq["estimated_local_skeleton"])[keep]
+    cams = np.asarray(seq["camera_pose_list"])[keep]
+    cen = torch.as_tensor(seq["heatmap_centres"][keep], dtype=torch.float32, device=device)
+    n = len(keep)
+    heat = torch.empty(n, HEATMAP_SIZE, HEATMAP_SIZE, N_JOINTS, dtype=torch.float32, device=device)
+    ys = torch.arange(HEATMAP_SIZE, dtype=torch.float32, device=device)[None, :, None, None]
+    xs = torch.arange(HEATMAP_SIZE, dtype=torch.float32, device=device)[None, None, :, None]
+    for a in range(0, n, block):
+        c = cen[a:a + block]
+        d2 = (xs - c[:, None, None, :, 0]) ** 2 + (ys - c[:, None, None, :, 1]) ** 2
+        heat[a:a + block] = torch.exp(-d2 / (2.0 * sigma * sigma))
+    return {"est_local": torch.as_tensor(est, dtype=torch.float32, device=device).contiguous(),
+            "cams": torch.as_tensor(cams, dtype=torch.float64, device=device).contiguous(), "heat": heat,
+            "gt_global": np.asarray(seq["gt_global_skeleton"]), "est_all_np": np.asarray(seq["estimated_local_skeleton"]), "frames": keep}

@@ -210,6 +210,10 @@ int gem_lift_skeleton(gem_handle* h, const float* d_heat, const double* d_depth,
  * `gem_profile_enable(h, 1)` turns event recording on (off by default: events cost launches). */
 int gem_profile_enable(gem_handle* h, int on);
 int gem_profile_read(gem_handle* h, int family, double* total_ms, int64_t* n_launches, double* flops);
+/* Names of the kernels launched for `family` while event recording was on, since the last call (a "; "-separated list of
+ * demangled names without parameter lists, i.e. as rocprofv3 --kernel-trace --stats prints them), written to buf (truncated to
+ * buf_len - 1 characters).  bench.py labels its roofline objects with this, so that the label is the kernel that actually ran. */
+int gem_profile_kernels(gem_handle* h, int family, char* buf, int buf_len);
 
 #ifdef __cplusplus
 }

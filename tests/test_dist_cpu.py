@@ -42,6 +42,29 @@ def test_block_cyclic_shards_cover_everything_once():
                     assert max(sizes) - min(sizes) <= block
 
 
+def test_frame_runs_of_block_cyclic_shards():
+    """What a rank holds of ONE long sequence: the frames of its blocks, stored once, windows re-indexed into that buffer."""
+    from globalegomocap_amd.dist import frame_runs
+    n, T = 12499, 10
+    starts = 8 * np.arange(n)
+    for world, block in ((1, 64), (2, 64), (8, 64), (8, 1), (3, 5)):
+        held = 0
+        for r in range(world):
+            idx = shard_indices(n, r, world, block)
+            runs, local0 = frame_runs(starts, idx, T)
+            keep = np.concatenate([np.arange(a, b) for a, b in runs]) if runs else np.zeros(0, dtype=np.int64)
+            assert all(b > a for a, b in runs) and all(runs[k][0] > runs[k - 1][1] for k in range(1, len(runs)))     # disjoint, ascending, maximal
+            for m, i in enumerate(idx[:: max(1, len(idx) // 50)]):
+                k = list(idx).index(i) if len(idx) < 2000 else int(np.searchsorted(idx, i))
+                assert np.array_equal(keep[local0[k]:local0[k] + T], np.arange(starts[i], starts[i] + T))
+            held += len(keep)
+        n_frames = 8 * (n - 1) + T
+        n_blocks = (n + block - 1) // block
+        # every frame once, plus the 2-frame halo at each boundary between blocks of different ranks
+        assert n_frames <= held <= n_frames + 2 * (n_blocks - 1) * (1 if world > 1 else 0)
+    assert frame_runs(starts, np.zeros(0, dtype=np.int64), T)[0] == []
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

@@ -1,0 +1,100 @@
+// Stand-alone timing harness for csrc/tail_bf16.hip (developer tool): per-phase timestamps of workgroup 0 and launch times.
+//   hipcc -w --offload-arch=gfx950 -O3 -std=c++17 -o tools/tail16_bench tools/tail16_bench.hip && ./tools/tail16_bench 1536 [nslab]
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../globalegomocap_amd/csrc/tail_bf16.hip"
+namespace gem {
+void set_error(const std::string& m) { fprintf(stderr, "error: %s\n", m.c_str()); }
+bool hip_ok(hipError_t e, const char* what) { if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", what, hipGetErrorString(e)); return false; } return true; }
+}
+using namespace gem;
+static std::vector<float> host_rand(size_t n, unsigned seed, float scale) {
+    std::vector<float> h(n); srand(seed);
+    for (size_t i = 0; i < n; ++i) h[i] = scale * ((rand() / (float)RAND_MAX) * 2.f - 1.f);
+    return h;
+}
+static float* dev_rand(size_t n, unsigned seed, float scale) {
+    std::vector<float> h = host_rand(n, seed, scale);
+    float* d; hipMalloc(&d, n * 4); hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice); return d;
+}
+int main(int argc, char** argv) {
+    const int B = argc > 1 ? atoi(argv[1]) : 1536, nslab = argc > 2 ? atoi(argv[2]) : 0, iters = 50, T = 10, J = 15;
+    const int dims[6] = {256, 128, 64, 64, 64, 64};
+    gem_handle h; h.prof.on = false; h.T = T; h.J = J; h.cfg.device = 0;
+    StageNet net;
+    net.dec.resize(6); net.dec_bwd.resize(6); net.host_fwd.resize(6); net.host_bwd.resize(6);
+    net.dec[0].K = 512; net.dec[0].N = 256;
+    for (int i = 1; i < 6; ++i) {
+        net.dec[i].K = dims[i - 1]; net.dec[i].N = dims[i]; net.dec[i].taps = 3;
+        net.dec_bwd[i].K = dims[i]; net.dec_bwd[i].N = dims[i - 1]; net.dec_bwd[i].taps = 3;
+        net.host_fwd[i] = host_rand((size_t)3 * dims[i - 1] * dims[i], 10 + i, 0.05f);
+        net.host_bwd[i] = host_rand((size_t)3 * dims[i - 1] * dims[i], 30 + i, 0.05f);
+        net.dec[i].bias = dev_rand(dims[i], 20 + i, 0.05f);
+    }
+    net.tail_start = 1;
+    if (build_tail_bf16_stream(&h, net) || !net.tb_stream) { fprintf(stderr, "no stream\n"); return 1; }
+    TailB16Args a;
+    const size_t lds = plan_tail_bf16(net.dec, 1, T, J, &a);
+    printf("LDS %zu bytes, n=%d, G=%d, steps %d + %d\n", lds, a.n, a.G, net.tb_steps_f, net.tb_steps_b);
+    for (int i = 0; i < a.n; ++i) {
+        a.fwd[i] = TailB16Layer{net.dec[1 + i].K, net.dec[1 + i].N, net.dec[1 + i].bias};
+        a.bwd[i] = TailB16Layer{net.dec_bwd[1 + i].K, net.dec_bwd[1 + i].N, nullptr};
+    }
+    a.B = B; a.dbg_ts = nullptr; a.forward_only = 0;
+    a.wstream = net.tb_stream; a.steps_f = net.tb_steps_f; a.steps_total = net.tb_steps_f + net.tb_steps_b;
+    const size_t rows = (size_t)B * T;
+    hipMalloc((void**)&a.a_in_b, rows * 256 * 2); hipMemset((void*)a.a_in_b, 0x3c, rows * 256 * 2);      // bf16 0x3c3c ~ 0.0115
+    hipMalloc((void**)&a.g_out_b, rows * 256 * 2);
+    a.Xp = nullptr;
+    a.in_slab = SlabSrc{};
+    a.in_bias = dev_rand((size_t)T * 256, 5, 0.05f); a.in_bias_ld = 256;
+    if (nslab > 0) { a.in_slab.base = dev_rand(rows * 256 * nslab, 6, 0.5f); a.in_slab.nslab = nslab; a.in_slab.stride = rows * 256; }
+    EnergyArgs& e = a.e;
+    e = EnergyArgs{};
+    e.X0 = dev_rand((size_t)B * T * 45, 2, 1.f);
+    const int F = 8 * B + 10;
+    hipMalloc((void**)&e.heat, (size_t)F * 64 * 64 * 15 * 4); hipMemset((void*)e.heat, 0, (size_t)F * 64 * 64 * 15 * 4);
+    std::vector<int> f0(B); for (int b = 0; b < B; ++b) f0[b] = 8 * b;
+    hipMalloc((void**)&e.frame0, B * 4); hipMemcpy((void*)e.frame0, f0.data(), B * 4, hipMemcpyHostToDevice);
+    e.mean_bone = dev_rand((size_t)B * 15, 3, 0.3f);
+    hipMalloc(&e.f, B * 8); hipMalloc(&e.parts, B * 40);
+    e.w3d = e.ws = e.wb = 0.01f; e.wv = 0; e.wr = getenv("TAIL_NO_REPROJ") ? 0.f : 0.01f; e.dw3d = e.dws = e.dwb = 0.01; e.dwr = 0.01;
+    e.T = T; e.J = J; e.H = 64; e.W = 64; e.n_poly = 11;
+    const float poly[11] = {478.6f, 350.4f, 79.f, 62.3f, 32.6f, 15.7f, 7.77f, 2.19f, -0.108f, -0.19f, -0.0278f};
+    for (int i = 0; i < 11; ++i) e.poly[i] = poly[i];
+    e.cx = 659.7f; e.cy = 530.f;
+    const int par[15] = {0, 0, 1, 2, 0, 4, 5, 1, 7, 8, 9, 4, 11, 12, 13};
+    std::vector<int> ch(256, -1);
+    for (int j = 0; j < 15; ++j) { int n = 0; for (int c = 0; c < 15; ++c) if (c != j && par[c] == j) ch[j * 16 + n++] = c; }
+    int *dp, *dc; hipMalloc(&dp, 60); hipMemcpy(dp, par, 60, hipMemcpyHostToDevice);
+    hipMalloc(&dc, 1024); hipMemcpy(dc, ch.data(), 1024, hipMemcpyHostToDevice);
+    e.parents = dp; e.children = dc; e.n_dev = nullptr; e.perm = nullptr;
+    if (getenv("TAIL_TEXCACHE")) { hipMalloc(&e.tex_key, rows * J * 4); hipMemset(e.tex_key, 0xFF, rows * J * 4); hipMalloc(&e.tex_val, rows * J * 16); }
+    hipStream_t s; hipStreamCreate(&s);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    {   // phase timestamps of workgroup 0
+        long long* d_ts; hipMalloc(&d_ts, 64 * 8); hipMemset(d_ts, 0, 64 * 8);
+        a.dbg_ts = d_ts;
+        for (int i = 0; i < 20; ++i) launch_tail_bf16(&h, a, lds, s);
+        hipStreamSynchronize(s);
+        long long ts[64]; hipMemcpy(ts, d_ts, sizeof(ts), hipMemcpyDeviceToHost);
+        a.dbg_ts = nullptr;
+        const char* names[14] = {"ring issued", "staged", "fwd 256->128", "fwd 128->64", "fwd 64->64", "fwd 64->64", "fwd 64->45",
+                                 "energy", "bwd 45->64", "bwd 64->64", "bwd 64->64", "bwd 64->128", "bwd 128->256", "rows out"};
+        for (int i = 1; i < 14; ++i)
+            printf("  %-14s %7.2f us  (%6lld shader clocks, %.2f GHz)\n", names[i], (ts[2 * i + 1] - ts[2 * i - 1]) * 0.01,
+                   ts[2 * i] - ts[2 * i - 2], (ts[2 * i] - ts[2 * i - 2]) / ((ts[2 * i + 1] - ts[2 * i - 1]) * 10.0 + 1e-9));
+        printf("  total inside the kernel %.2f us\n", (ts[27] - ts[1]) * 0.01);
+    }
+    for (int fo = 1; fo >= 0; --fo) {
+        a.forward_only = fo;
+        for (int i = 0; i < 3; ++i) launch_tail_bf16(&h, a, lds, s);
+        hipEventRecord(e0, s);
+        for (int i = 0; i < iters; ++i) launch_tail_bf16(&h, a, lds, s);
+        hipEventRecord(e1, s); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("B=%d forward_only=%d: %.1f us\n", B, fo, ms * 1e3 / iters);
+    }
+    return 0;
+}
