@@ -507,6 +507,10 @@ def main():
                     names = e2.profile_kernels(fam)
                     if not n_k:
                         continue
+                    if fl_k <= 0:          # the stand-alone energy kernel (batched narrow layers): no matrix work, latency / gather-bound
+                        rec["energy_kernel"] = {"kernel": names, "launches": int(n_k), "avg_us": round(ms_k * 1e3 / n_k, 2),
+                                                "share_of_step": round(ms_k * 1e-3 / (dt / n2), 3)}
+                        continue
                     pk = PEAK_BF16_MATRIX_TFLOPS if mode == "bf16" else PEAK_F32_MATRIX_TFLOPS
                     ach = fl_k / (ms_k * 1e-3) / 1e12
                     tr_b, tr_src = committed_traffic(names)

@@ -118,9 +118,11 @@ int launch_energy(gem_handle* h, const EnergyArgs& a, int B, hipStream_t s) {
         rec.family = 1; rec.flops = 0;
         GEM_HIP(hipEventRecord(rec.a, s));
     }
+    note_kernel(h, reinterpret_cast<const void*>(energy_kernel));
     hipLaunchKernelGGL(energy_kernel, dim3(B), dim3(64), 0, s, a);
     GEM_HIP(hipGetLastError());
     if (prof) { GEM_HIP(hipEventRecord(rec.b, s)); h->prof.recs.push_back(rec); }
+    commit_kernel_names(h, prof ? rec.family : -1);
     return 0;
 }
 

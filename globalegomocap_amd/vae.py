@@ -147,7 +147,7 @@ def synthetic_state_dict(shape, seed, gain=1.0):
 
 
 def structured_state_dict(shape, seed, latent_gain=8.0, sigma0=0.00125, coupling=0.01, spread=5.0, feature_offset=0.0,
-                          mean_pose=None, pose_scale=0.3):
+                          mean_pose=None, pose_scale=0.3, signal_offset=3.0):
     """A full-size, WELL-CONDITIONED motion VAE built deterministically from a seed -- no training.
 
     Purpose: parity fixtures at the reference's real size (D = 2048).  A random-init VAE decodes far from its input
@@ -171,6 +171,12 @@ def structured_state_dict(shape, seed, latent_gain=8.0, sigma0=0.00125, coupling
         too, the whole network is affine and the energy without reprojection term is SMOOTH: trajectories of two
         implementations then stay together to rounding, instead of parting at the first kink they cross on different sides.
       * logvar = log(sigma0^2) (+ small seeded weights): z0 = mu + eps * sigma0 moves the pose by ~latent_gain*sigma0*pose_scale.
+
+    signal_offset (OFF, default 3: the gauge of the committed reference goldens): bf16 activations resolve a signal channel to
+    2^-8 of its VALUE, i.e. of OFF + u -- with OFF = 3 and pose_scale = 0.3 m that is up to 4.7 mm of pose per rounding, an
+    artefact of the gauge, not of the network.  OFF = 1 keeps the signal on the positive branch for |x - mean_pose| < 0.3 m (the
+    synthetic motion stays within 0.2 m) and brings the rounding down to 0.6-1.2 mm: the "bf16-friendly" variant the bf16 parity
+    tests use against the fp32 oracle.  Same function in exact arithmetic for any OFF.
     """
     from .skeleton import MEAN3D_MM
     C, T, D = shape.channels, shape.seq_len, shape.latent_dim
@@ -181,7 +187,7 @@ def structured_state_dict(shape, seed, latent_gain=8.0, sigma0=0.00125, coupling
     if mean_pose is None:
         mean_pose = (MEAN3D_MM.T / 1000.0).reshape(-1)[:C]
     m = np.asarray(mean_pose, dtype=np.float64)
-    OFF, FOFF, g = 3.0, float(feature_offset), float(latent_gain)
+    OFF, FOFF, g = float(signal_offset), float(feature_offset), float(latent_gain)
 
     def uni(shp, lo, hi):                      # U[lo, hi) from the raw 53-bit uniform stream
         return lo + (hi - lo) * rng.random(size=shp)

@@ -42,6 +42,17 @@ def full_vaes():
     return full_golden_case(g)
 
 
+@pytest.fixture(scope="module")
+def friendly_vaes():
+    """The same two structured full-size VAEs in the bf16-friendly gauge (vae.structured_state_dict(signal_offset=1)): the signal
+    channels carry 1 + u instead of 3 + u, so that bf16's 2^-8 relative resolution is ~1 mm of pose instead of ~5 mm.  Same
+    function in exact arithmetic; regenerated from the seeds like the others.  Used by the BASELINE configs[2..4] tests, whose
+    bf16 runs are pinned to the fp32 CPU oracle."""
+    sd_l = vae_schema.structured_state_dict(FULL, 7, feature_offset=0.0, signal_offset=1.0)
+    sd_g = vae_schema.structured_state_dict(FULL, 8, feature_offset=3.0, signal_offset=1.0)
+    return sd_l, sd_g
+
+
 def _engine(max_windows, sd_l, sd_g, precision="f32", calibration=DEFAULT_CALIBRATION):
     from globalegomocap_amd.engine import WindowEngine, LOCAL_STAGE, GLOBAL_STAGE
     eng = WindowEngine(FULL, FisheyeCamera.from_json(calibration), max_windows=max_windows)
@@ -321,11 +332,16 @@ def _run(eng, p):
 
 def _check_properties(torch, eng, p, sd_l, sd_g, spot, tag, pose_tol_mm, loss_rtol):
     """status, evaluation bounds, Armijo on both stages, determinism, bitwise duplicates; then `spot` windows against the
-    fp32 CPU oracle (both stages chained).  Returns (mid, glob, stats_numpy).
+    fp32 CPU oracle (both stages chained).  Returns (mid, glob, stats_numpy, {window: oracle global pose}).
 
-    Per-window tolerance in bf16: the structured test VAE carries every pose coordinate as 3 + u on its signal channels
-    (u = metres / 0.3), and bf16 resolves values in [2, 4) to 2^-7: about 5 mm per coordinate, far worse than a trained
-    network whose outputs are sums of many small terms.  The acceptance gate of the bf16 mode is the sequence MPJPE (1.5 mm)."""
+    bf16 runs use the bf16-friendly gauge of the structured VAE (fixture friendly_vaes) and are held to the fp32 ORACLE: every
+    spot window within pose_tol_mm and loss_rtol in final energy.  The per-window figure has a FLOOR set by the format, not by
+    the optimiser: this VAE carries every pose coordinate on ONE channel with gain 1 as 1 + u (u = metres / 0.3); each of the
+    five bf16 activations between the decoder layers rounds it to 8 significant bits, i.e. to 1.2 / 2.3 mm steps of pose (values
+    in [0.5, 1) / [1, 2)): 0.54 mm rms per rounding and coordinate, 1.2 mm after five, ~1.9 mm mean 3-D joint distance before
+    anything else happens.  Measured: 2.0-3.2 mm on every window (uniform: noise, not diverged trajectories); the sequence
+    MPJPE -- where that zero-mean noise averages out -- is where north_star's 0.5 mm is asserted (measured 0.01-0.06 mm).
+    A fitted VAE spreads each coordinate over many channels: there bf16 and fp32 agree to 0.001 mm MPJPE (bench.py)."""
     from globalegomocap_amd.engine import stats_to_numpy, LOCAL_STAGE, GLOBAL_STAGE
     B, n_dup = len(p["starts"]), p["n_dup"]
     mid, glob, stats = _run(eng, p)
@@ -366,6 +382,7 @@ def _check_properties(torch, eng, p, sd_l, sd_g, spot, tag, pose_tol_mm, loss_rt
     eps_l, eps_g = p["eps_l"].cpu().numpy(), p["eps_g"].cpu().numpy()
     glob_np = glob.cpu().numpy()
     rep = []
+    refs = {}
     for b in spot:
         s = int(p["starts"][b])
         hs = p["seq"]["heat"][s:s + T].cpu().numpy()
@@ -373,6 +390,7 @@ def _check_properties(torch, eng, p, sd_l, sd_g, spot, tag, pose_tol_mm, loss_rt
         relo = O.relative_global(a, cams_np[s:s + T])
         c, sb = O.optimize_stage(vae_g, cam, O.Weights(*W_GLOBAL), relo.astype(np.float32), hs, mb_np[b], eps_g[b])
         ref = O.to_global(c, cams_np[s:s + T])
+        refs[int(b)] = ref
         d = np.linalg.norm(glob_np[b] - ref, axis=-1).mean()
         rep.append({"window": int(b), "diff_mm": float(d * 1e3), "evals": [int(sn["func_evals"][b]), int(sn["func_evals"][B + b])],
                     "oracle_evals": [int(sa["func_evals"]), int(sb["func_evals"])],
@@ -383,7 +401,7 @@ def _check_properties(torch, eng, p, sd_l, sd_g, spot, tag, pose_tol_mm, loss_rt
             assert abs(int(sn["func_evals"][b]) - sa["func_evals"]) <= 3, (tag, rep[-1])
     print(tag, "oracle spot check:", ["%d: %.3f mm" % (r["window"], r["diff_mm"]) for r in rep])
     _report("spot_%s.json" % tag, rep)
-    return mid, glob, sn
+    return mid, glob, sn, refs
 
 
 def _seq_mpjpe(glob, p, n_chunks, per):
@@ -396,11 +414,14 @@ def _seq_mpjpe(glob, p, n_chunks, per):
     return float(np.linalg.norm(np.concatenate(out) - np.concatenate(gt), axis=-1).mean())
 
 
-def test_config2_all_sequences_in_one_call_bf16(torch_cuda, full_vaes, tmp_path):
+def test_config2_all_sequences_in_one_call_bf16(torch_cuda, friendly_vaes, tmp_path):
     """BASELINE configs[2]: "all 5 test-sequence shapes concurrently on 1 MI355X, bf16 VAE decoder / fp32 energy" -- five
-    sequences of 20 + 27 + 27 + 27 + 27 chunks = 1536 windows, every window in ONE device call."""
+    sequences of 20 + 27 + 27 + 27 + 27 chunks = 1536 windows, every window in ONE device call.
+    bf16 against the fp32 CPU ORACLE (north_star's tolerance): the 12 windows of the first chunk each within the bf16 activation
+    noise floor (see _check_properties), and the MPJPE of that chunk's merged + smoothed sequence within 0.5 mm of the oracle's; over all 126 chunks bf16 vs fp32 HIP (the
+    path pinned to the reference at 0.1 mm by the golden tests) within 0.5 mm as well."""
     torch = torch_cuda
-    data, sd_l, sd_g, w_l, w_g = full_vaes
+    sd_l, sd_g = friendly_vaes
     n_chunks, per = 128, 12
     B = n_chunks * per
     starts = np.concatenate([c * 100 + window_starts(100) for c in range(n_chunks)])
@@ -409,12 +430,21 @@ def test_config2_all_sequences_in_one_call_bf16(torch_cuda, full_vaes, tmp_path)
     _, glob_f32, _ = _run(eng, p)
     mp_f32 = _seq_mpjpe(glob_f32, p, n_chunks - 2, per)          # (the last two chunks hold the duplicated windows)
     eng.set_precision("bf16")
-    mid, glob, sn = _check_properties(torch, eng, p, sd_l, sd_g, spot=(0, 5, 640, 1000, 1511, 1535), tag="configs2_bf16",
-                                      pose_tol_mm=8.0, loss_rtol=5e-2)
+    mid, glob, sn, refs = _check_properties(torch, eng, p, sd_l, sd_g, spot=tuple(range(12)) + (640, 1511), tag="configs2_bf16",
+                                            pose_tol_mm=3.5, loss_rtol=2e-2)
     mp_bf16 = _seq_mpjpe(glob, p, n_chunks - 2, per)
-    print("configs[2]: MPJPE f32 %.3f mm, bf16 %.3f mm over %d frames" % (mp_f32 * 1e3, mp_bf16 * 1e3, (n_chunks - 2) * 98))
-    _report("configs2_mpjpe.json", {"mpjpe_f32_mm": mp_f32 * 1e3, "mpjpe_bf16_mm": mp_bf16 * 1e3})
-    assert abs(mp_bf16 - mp_f32) < 1.5e-3                        # the stated bf16 gate on sequence MPJPE
+    # chunk 0: the oracle's merged + smoothed sequence against the bf16 HIP one, both against the ground truth
+    gt0 = p["seq"]["gt_global"][:98]
+    seq_or = final_smooth(merge_batches(np.stack([refs[b] for b in range(12)])))
+    seq_hip = final_smooth(merge_batches(glob.cpu().numpy()[:12]))
+    mp_or0, mp_hip0 = np.linalg.norm(seq_or - gt0, axis=-1).mean(), np.linalg.norm(seq_hip - gt0, axis=-1).mean()
+    d0 = np.linalg.norm(seq_or - seq_hip, axis=-1).mean()
+    print("configs[2]: MPJPE f32 %.3f mm, bf16 %.3f mm over %d frames; chunk 0: oracle %.3f mm, bf16 HIP %.3f mm, sequence diff %.3f mm"
+          % (mp_f32 * 1e3, mp_bf16 * 1e3, (n_chunks - 2) * 98, mp_or0 * 1e3, mp_hip0 * 1e3, d0 * 1e3))
+    _report("configs2_mpjpe.json", {"mpjpe_f32_mm": mp_f32 * 1e3, "mpjpe_bf16_mm": mp_bf16 * 1e3, "chunk0_mpjpe_oracle_mm": mp_or0 * 1e3,
+                                    "chunk0_mpjpe_bf16_hip_mm": mp_hip0 * 1e3, "chunk0_sequence_diff_mm": d0 * 1e3})
+    assert abs(mp_hip0 - mp_or0) < 0.5e-3, (mp_hip0, mp_or0)      # north_star: MPJPE within 0.5 mm of the reference path
+    assert abs(mp_bf16 - mp_f32) < 0.5e-3, (mp_bf16, mp_f32)
     eng.close()
 
     # and through the reference-shaped entry point: five sequence directories -> optimize_sequences, one device call
@@ -452,38 +482,39 @@ def test_config2_all_sequences_in_one_call_bf16(torch_cuda, full_vaes, tmp_path)
     for (sm_f, per_f, _, opt_f, gt_f), (sm_b, per_b, _, opt_b, _) in zip(res["f32"], res["bf16"]):
         assert len(per_b) == len(per_f) and np.isfinite(list(v for k, v in sm_b.items() if k != "joints_error")).all()
         assert sm_b["optimized_global_mpjpe"] < sm_b["original_global_mpjpe"] - 5e-3          # the optimisation helps (metres)
-        assert abs(sm_b["optimized_global_mpjpe"] - sm_f["optimized_global_mpjpe"]) < 1.5e-3
+        assert abs(sm_b["optimized_global_mpjpe"] - sm_f["optimized_global_mpjpe"]) < 0.5e-3
         assert np.asarray(opt_b).shape == np.asarray(gt_f).shape
     opt.engine.close()
 
 
-def test_config3_shard_8192_windows_bf16(torch_cuda, full_vaes):
-    """BASELINE configs[3]: 64k synthetic windows over 8 GPUs, bf16 -- the per-GPU shard: 8192 windows in one call."""
+def test_config3_shard_8192_windows_bf16(torch_cuda, friendly_vaes):
+    """BASELINE configs[3]: 64k synthetic windows over 8 GPUs, bf16 -- the per-GPU shard: 8192 windows in one call; six windows
+    spread over the batch against the fp32 CPU oracle."""
     torch = torch_cuda
-    data, sd_l, sd_g, w_l, w_g = full_vaes
+    sd_l, sd_g = friendly_vaes
     B, n_frames = 8192, 12000
     rng = np.random.default_rng(303)
     starts = rng.integers(0, n_frames - 10, B)
     eng = _engine(B, sd_l, sd_g, "bf16")
     p = _device_problem(eng, n_frames, starts, seed=303, n_dup=128)
-    _check_properties(torch, eng, p, sd_l, sd_g, spot=(0, 127, 128, 4095, 4096, 8063), tag="configs3_bf16", pose_tol_mm=8.0,
-                      loss_rtol=5e-2)
+    _check_properties(torch, eng, p, sd_l, sd_g, spot=(0, 127, 128, 4095, 4096, 8063), tag="configs3_bf16", pose_tol_mm=3.5,
+                      loss_rtol=2e-2)
     eng.close()
 
 
-@pytest.mark.parametrize("precision,pose_tol_mm,loss_rtol", [("f32", 2.0, 2e-3), ("bf16", 8.0, 5e-2)])
-def test_config4_shard_of_a_continuous_stream(torch_cuda, full_vaes, precision, pose_tol_mm, loss_rtol):
+@pytest.mark.parametrize("precision,pose_tol_mm,loss_rtol", [("f32", 2.0, 2e-3), ("bf16", 3.5, 2e-2)])
+def test_config4_shard_of_a_continuous_stream(torch_cuda, friendly_vaes, precision, pose_tol_mm, loss_rtol):
     """BASELINE configs[4]: a 100k-frame stream over 8 GPUs -- the per-GPU shard: 1563 overlapping windows (stride 8) of ONE
     continuous 12 506-frame sequence, frames stored once, no chunk structure."""
     torch = torch_cuda
-    data, sd_l, sd_g, w_l, w_g = full_vaes
+    sd_l, sd_g = friendly_vaes
     B = 1563
     starts = 8 * np.arange(B)
     n_frames = int(starts[-1]) + 10
     eng = _engine(B, sd_l, sd_g, precision)
     p = _device_problem(eng, n_frames, starts, seed=404, n_dup=0)
-    mid, glob, sn = _check_properties(torch, eng, p, sd_l, sd_g, spot=(0, 1, 700, 701, 1561, 1562), tag="configs4_" + precision,
-                                      pose_tol_mm=pose_tol_mm, loss_rtol=loss_rtol)
+    mid, glob, sn, _ = _check_properties(torch, eng, p, sd_l, sd_g, spot=(0, 1, 700, 701, 1561, 1562), tag="configs4_" + precision,
+                                         pose_tol_mm=pose_tol_mm, loss_rtol=loss_rtol)
     # one continuous sequence: merge ALL windows as one chunk (overlap 2) and smooth -> [8*B+2] frames
     merged = final_smooth(merge_batches(glob.cpu().numpy()))
     assert merged.shape == (8 * B + 2, 15, 3)

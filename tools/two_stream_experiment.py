@@ -12,8 +12,9 @@ dev = torch.device("cuda")
 shape = V.VAEShape(); cam = FisheyeCamera.from_json(DEFAULT_CALIBRATION)
 sd_l, _ = bench.fit_weights(shape, 101, dev, 2000, False)
 sd_g, _ = bench.fit_weights(shape, 102, dev, 2000, True)
-seq = synth.make_sequence_device(2000, 1000, dev, cam, cam_jitter=bench.CAM_JITTER)
-starts = np.concatenate([c * 100 + window_starts(100) for c in range(20)]).astype(np.int32)
+NC = int(os.environ.get("GEM_EXP_CHUNKS", "20"))        # 20 chunks = 240 windows; 128 = 1536; 683 = 8196
+seq = synth.make_sequence_device(100 * NC, 1000, dev, cam, cam_jitter=bench.CAM_JITTER)
+starts = np.concatenate([c * 100 + window_starts(100) for c in range(NC)]).astype(np.int32)
 B = len(starts)
 g = torch.Generator().manual_seed(4321)
 eps = torch.randn(2 * B, 2048, generator=g).reshape(B, 2, -1)
@@ -25,6 +26,7 @@ def make(n_parts):
         lo, hi = p * B // n_parts, (p + 1) * B // n_parts
         e = WindowEngine(shape, cam, max_windows=hi - lo)
         e.load_vae(0, sd_l); e.load_vae(1, sd_g)
+        e.set_precision(os.environ.get("GEM_EXP_PRECISION", "f32"))
         if os.environ.get('GEM_EXP_GRAPHS'): e.enable_graphs(True)
         mb = e.mean_bone_length(seq["est_local"][:100]).reshape(1, 15).expand(hi - lo, 15).contiguous()
         parts.append(dict(e=e, f0=torch.as_tensor(starts[lo:hi], device=dev), mb=mb, el=eps[lo:hi, 0].contiguous().to(dev),
@@ -41,6 +43,8 @@ def run(parts, steps):
     return (time.perf_counter() - t) / steps * 1e3
 
 for n in (1, 2, 3, 4):
+    parts = None
+    torch.cuda.empty_cache()
     parts = make(n)
     run(parts, 3)
     ms = run(parts, 8)
