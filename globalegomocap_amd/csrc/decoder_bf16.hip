@@ -110,8 +110,9 @@ static int gemm_bf16a(gem_handle* h, const Layer& L, int epi, const uint16_t* A,
     a.lda = lda; a.ldc = ldc; a.M = M; a.N = L.N; a.K = L.K; a.T = h->T;
     a.n_split = 1; a.tiles_per_split = k_tiles; a.slab_stride = (size_t)M * ldc;
     if (allow_split && epi != EPI_MASK) {
-        // fill the chip: about three workgroups per CU while every slice keeps >= 4 k-tiles and the slabs fit
-        int sk = (3 * h->n_cu) / tiles;
+        // fill the chip: about two workgroups per CU (the number co-resident with this kernel's 64 KB of LDS; measured at 768 ..
+        // 3072 rows, tools/gemm_glds_bench split: the best cut of every shape) while every slice keeps >= 4 k-tiles and the slabs fit
+        int sk = (2 * h->n_cu) / tiles;
         if (sk > k_tiles / 4) sk = k_tiles / 4;
         if (sk > 8) sk = 8;
         while (sk > 1 && (size_t)sk * a.slab_stride > w.splitk_elems) --sk;

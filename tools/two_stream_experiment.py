@@ -20,6 +20,9 @@ g = torch.Generator().manual_seed(4321)
 eps = torch.randn(2 * B, 2048, generator=g).reshape(B, 2, -1)
 wl, wg = energy_weights(1e-6, 1e-5, 0.01, 0, 0.01), energy_weights(0.01, 0.001, 0.01, 0, 0)
 
+STAGGER = int(os.environ.get("GEM_EXP_STAGGER", "0"))      # shader cycles the k-th stream idles before its call (de-phases the lanes)
+
+
 def make(n_parts):
     parts = []
     for p in range(n_parts):
@@ -36,13 +39,15 @@ def make(n_parts):
 def run(parts, steps):
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(steps):
-        for p in parts:
+        for k, p in enumerate(parts):
             with torch.cuda.stream(p["s"]):
+                if k and STAGGER:
+                    torch.cuda._sleep(STAGGER * k)
                 p["e"].optimize_windows(seq["est_local"], seq["cams"], seq["heat"], p["f0"], p["mb"], p["el"], p["eg"], wl, wg, want_stats=False)
     torch.cuda.synchronize()
     return (time.perf_counter() - t) / steps * 1e3
 
-for n in (1, 2, 3, 4):
+for n in (1, 2, 3):
     parts = None
     torch.cuda.empty_cache()
     parts = make(n)
