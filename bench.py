@@ -42,6 +42,8 @@ def parse():
     p.add_argument("--workload", default="seq2k", help="seq2k (20 chunks, 240 windows per GPU; the default, weak scaling) | w8192 | <number of "
                    "chunks> | configs3 (65536 windows sharded over the ranks, bf16, strong scaling) | configs4 (12499 overlapping windows of "
                    "one 100k-frame stream, block-cyclic shards, hipGraph replay, strong scaling)")
+    p.add_argument("--lanes", type=int, default=None, help="gem_set_lanes: batches of at least this many windows run as two half-batches "
+                   "half a round apart (library default 4352; 0 = one lane always)")
     p.add_argument("--windows", type=int, default=0, help="configs3 / configs4: total number of windows (default 65536 / 12499)")
     p.add_argument("--block", type=int, default=64, help="configs4: windows per block of the block-cyclic shards")
     p.add_argument("--emulate-ranks", type=int, default=0, help="configs3 / configs4 with --gpus 1: run the shards of N ranks one after "
@@ -177,6 +179,8 @@ def run_sharded(a, world, rank, device, rehearsal, sd_local, sd_global, vae_note
     eng.load_vae(LOCAL_STAGE, sd_local)
     eng.load_vae(GLOBAL_STAGE, sd_global)
     eng.set_precision(a.precision)
+    if a.lanes is not None:
+        eng.set_lanes(a.lanes)
     eng.enable_graphs(stream)
     wl = (0.01 / 10000, 0.001 / 100, 0.01, 0.0, 0.01)
     wg = (0.01, 0.001, 0.01, 0.0, 0.0)
@@ -349,6 +353,8 @@ def main():
     eng.load_vae(LOCAL_STAGE, sd_local)
     eng.load_vae(GLOBAL_STAGE, sd_global)
     eng.set_precision(a.precision)
+    if a.lanes is not None:
+        eng.set_lanes(a.lanes)
     mb = torch.stack([eng.mean_bone_length(seqd["est_local"][c * CHUNK:(c + 1) * CHUNK]) for c in range(n_chunks)])
     mb_w = mb[torch.as_tensor(chunk_of, device=device)].contiguous()
     g = torch.Generator().manual_seed(4321 + rank)

@@ -66,6 +66,7 @@ SIGNATURES = {
     "gem_merge_windows": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "gem_calculate_errors": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.POINTER(C.c_double), _P, _P]),
     "gem_lift_skeleton": (C.c_int, [_P, _P, _P, C.c_int, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
+    "gem_set_lanes": (C.c_int, [_P, C.c_int]),
     "gem_profile_enable": (C.c_int, [_P, C.c_int]),
     "gem_profile_read": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "gem_profile_kernels": (C.c_int, [_P, C.c_int, C.c_char_p, C.c_int]),

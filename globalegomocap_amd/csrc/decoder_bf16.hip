@@ -232,6 +232,7 @@ int evaluate_bf16(gem_handle* h, int stage, int B, const EnergyArgs& ea_in, hipS
         ta.e = ea;
         if (launch_tail_bf16(h, ta, net.tb_lds, s)) return 1;
         if (forward_only) return 0;
+        if (record_mid(h, s)) return 1;
         back_from = st - 1;
         gin = w.dec_grad_b[st];
     } else
@@ -271,6 +272,7 @@ int evaluate_bf16(gem_handle* h, int stage, int B, const EnergyArgs& ea_in, hipS
         ta.e = ea;
         if (launch_tail(h, ta, net.tail_lds, s)) return 1;
         if (forward_only) return 0;
+        if (record_mid(h, s)) return 1;
         back_from = st - 1;
         gin = w.dec_grad_b[st];
     } else {
@@ -294,6 +296,7 @@ int evaluate_bf16(gem_handle* h, int stage, int B, const EnergyArgs& ea_in, hipS
         ea.Xp = w.dec_act.back();
         ea.dXp_b = w.dXp_b;
         if (launch_energy(h, ea, B, s)) return 1;
+        if (record_mid(h, s)) return 1;
         back_from = n_dec - 1;
         gin = w.dXp_b;
     }

@@ -332,6 +332,11 @@ void gem_destroy(gem_handle* h) {
     (void)hipDeviceSynchronize();
     for (auto& r : h->prof.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     drop_graphs(h);
+    if (h->lane2) { gem_destroy(h->lane2); h->lane2 = nullptr; }          // (its nets own nothing: the weights are freed below)
+    if (h->lane_stream) (void)hipStreamDestroy(h->lane_stream);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     free_all(h->net[0].allocs);
     free_all(h->net[1].allocs);
     free_all(h->ws.allocs);
@@ -555,7 +560,7 @@ static int evaluate(gem_handle* h, int stage, int B, const float* zp, const Ener
     if (net.tail_start < 0 || (tail_wgs > tail_cap && !force_tail)) {
         if (decoder_forward(h, stage, B, zp, s)) return 1;
         if (forward_only) return 0;
-        if (launch_energy(h, ea, B, s)) return 1;
+        if (launch_energy(h, ea, B, s) || record_mid(h, s)) return 1;
         return decoder_backward(h, stage, B, s, (int)net.dec.size() - 1, w.dXp);
     }
     // wide layers as batched GEMMs, the narrow tail + energy + its adjoints in one kernel
@@ -599,6 +604,7 @@ static int evaluate(gem_handle* h, int stage, int B, const float* zp, const Ener
     ta.e = ea;
     if (launch_tail(h, ta, net.tail_lds, s)) return 1;
     if (forward_only) return 0;
+    if (record_mid(h, s)) return 1;
     if (front) {
         // dE/dz = Wf^T . (gradient w.r.t. the pre-activation of conv 0): replaces the conv adjoint, its reduce pass and the
         // decoder_input backward product; in the rounds lbfgs_advance sums the slabs of this product itself (its bias is zero)
@@ -611,20 +617,37 @@ static int evaluate(gem_handle* h, int stage, int B, const float* zp, const Ener
     return decoder_backward(h, stage, B, s, st - 1, w.dec_grad[st]);
 }
 
-static int optimize_stage_impl(gem_handle* h, int stage, int B, const float* d_pose_in, const float* d_heat,
-                               const int32_t* d_frame0, const float* d_mean_bone, const float* d_eps,
-                               const gem_energy_weights& wt, const gem_lbfgs_opts& opt, float* d_pose_out,
-                               gem_window_stats* d_stats, hipStream_t s) {
+// One stage of B windows as three host steps, so that two half-batches ("lanes", below) can be driven round by round from one
+// loop: begin (encode, initial state), round r (one evaluation + one L-BFGS advance for every window still iterating), finish
+// (decode the result).  optimize_stage_impl runs them back to back.
+struct StageRun {
+    gem_handle* h = nullptr;
+    int stage = 0, B = 0;
+    const float* pose_in = nullptr; const float* heat = nullptr; const int32_t* frame0 = nullptr; const float* mean_bone = nullptr;
+    const float* eps = nullptr;
+    gem_energy_weights wt{}; gem_lbfgs_opts opt{};
+    float* pose_out = nullptr; gem_window_stats* stats = nullptr;
+    hipStream_t s = nullptr;
+    EnergyArgs ea{};
+    bool fuse = false;
+    int rounds = 0;
+};
+
+static int stage_begin(StageRun& r) {
+    gem_handle* h = r.h;
     Workspace& w = h->ws;
-    if (wt.reproj != 0.0 && (!d_heat || !d_frame0)) { set_error("optimize: reproj weight != 0 needs heat-maps and frame indices"); return 1; }
-    if (opt.max_iter < 1 || opt.max_eval < 1 || opt.max_iter - 1 > w.hist_cap || opt.max_iter > MAX_HIST) {
+    const int B = r.B, stage = r.stage;
+    hipStream_t s = r.s;
+    if (r.wt.reproj != 0.0 && (!r.heat || !r.frame0)) { set_error("optimize: reproj weight != 0 needs heat-maps and frame indices"); return 1; }
+    if (r.opt.max_iter < 1 || r.opt.max_eval < 1 || r.opt.max_iter - 1 > w.hist_cap || r.opt.max_iter > MAX_HIST) {
         set_error("optimize: max_iter must be 1.." + std::to_string(w.hist_cap + 1)); return 1;
     }
+    r.rounds = r.opt.max_eval + 1;          // upper bound on evaluations per window (see lbfgs.hip)
     if (B == 0) return 0;
-    if (encoder_forward(h, stage, B, d_pose_in, s)) return 1;
-    if (launch_reparam(w.mulv, d_eps, nullptr, nullptr, nullptr, w.trial, B, h->D, h->Dp, s)) return 1;
+    if (encoder_forward(h, stage, B, r.pose_in, s)) return 1;
+    if (launch_reparam(w.mulv, r.eps, nullptr, nullptr, nullptr, w.trial, B, h->D, h->Dp, s)) return 1;
     if (h->precision == GEM_PRECISION_BF16 && launch_f32_to_bf16(w.trial, w.trial_b, (size_t)B * h->Dp, s)) return 1;
-    if (launch_lbfgs_init(h, B, opt, s)) return 1;
+    if (launch_lbfgs_init(h, B, r.opt, s)) return 1;
     // Rounds run on the windows that are still iterating: after every advance they are re-packed to the front
     // (perm / n_active on the device) and the kernels of the next round read their row count from there.
     static const bool no_compact = dev_env("GEM_NO_COMPACT") != nullptr;
@@ -634,14 +657,12 @@ static int optimize_stage_impl(gem_handle* h, int stage, int B, const float* d_p
     }
     // texel-block cache of the reprojection term: valid for this stage's heat-maps / windows only
     static const bool no_tex = dev_env("GEM_NO_TEXCACHE") != nullptr;
-    w.tex_on = !no_tex && h->tex_cache && w.tex_key && wt.reproj != 0.0;
+    w.tex_on = !no_tex && h->tex_cache && w.tex_key && r.wt.reproj != 0.0;
     if (w.tex_on) GEM_HIP(hipMemsetAsync(w.tex_key, 0xFF, (size_t)B * h->T * h->J * sizeof(int), s));
-    const EnergyArgs ea = energy_args(h, d_pose_in, d_heat, d_frame0, d_mean_bone, wt);
+    r.ea = energy_args(h, r.pose_in, r.heat, r.frame0, r.mean_bone, r.wt);
     w.tex_on = false;
-    const int rounds = opt.max_eval + 1;          // upper bound on evaluations per window (see lbfgs.hip)
     // closure values of this stage, one row per round (0xFF bytes = NaN: "window took no evaluation in this round")
     GEM_HIP(hipMemsetAsync(w.trace, 0xFF, (size_t)TRACE_ROUNDS * w.Bmax * sizeof(double), s));
-    int rc = 0;
     // The active windows are re-packed between the rounds: by compact_kernel, or -- one sequence in fp32 -- inside the
     // decoder_input forward launch of the next round (gemm_rows.h; one launch and its boundary less per round).
     StageNet& net_ = h->net[stage];
@@ -649,29 +670,183 @@ static int optimize_stage_impl(gem_handle* h, int stage, int B, const float* d_p
     const Layer& first_ = front_ ? net_.front : net_.dec_in;
     const int tail_g_ = h->T <= 16 ? 16 / h->T : 1;
     const bool tail_path_ = net_.tail_start >= 0 && (B + tail_g_ - 1) / tail_g_ <= 5 * h->n_cu;
-    const bool fuse = w.dyn && tail_path_ && rows_can_fuse_compaction(h, first_, h->Dp, first_.N, B, /*slabs=*/front_);
-    for (int r = 0; r < rounds && !rc; ++r) {
-        w.round = r;
-        if (r > 0 && w.dyn) {
-            if (fuse) {
-                w.fuse_compact = true;
-                w.fuse_log = w.n_log + (w.log_pos % N_LOG);
-                w.cur_log = w.log_pos++;
-            } else {
-                rc = launch_compact(h, B, 0, s);
-            }
+    r.fuse = w.dyn && tail_path_ && rows_can_fuse_compaction(h, first_, h->Dp, first_.N, B, /*slabs=*/front_);
+    return 0;
+}
+
+static int stage_round(StageRun& r, int k) {
+    gem_handle* h = r.h;
+    Workspace& w = h->ws;
+    if (r.B == 0) return 0;
+    int rc = 0;
+    w.round = k;
+    // (dyn / tex state of THIS lane's workspace: another lane may have run in between)
+    if (k > 0 && w.dyn) {
+        if (r.fuse) {
+            w.fuse_compact = true;
+            w.fuse_log = w.n_log + (w.log_pos % N_LOG);
+            w.cur_log = w.log_pos++;
+        } else {
+            rc = launch_compact(h, r.B, 0, r.s);
         }
-        rc = rc || evaluate(h, stage, B, w.trial, ea, s) || launch_lbfgs_advance(h, B, opt, s);
-        if (w.fuse_compact) { set_error("optimize: the fused compaction was not picked up"); rc = 1; w.fuse_compact = false; }
+    }
+    rc = rc || evaluate(h, r.stage, r.B, w.trial, r.ea, r.s) || launch_lbfgs_advance(h, r.B, r.opt, r.s);
+    if (w.fuse_compact) { set_error("optimize: the fused compaction was not picked up"); rc = 1; w.fuse_compact = false; }
+    if (w.mid_event) {          // (no evaluation path picked the half-round marker up: record it now rather than never)
+        GEM_HIP(hipEventRecord(w.mid_event, r.s));
+        w.mid_event = nullptr;
     }
     w.round = -1;
+    return rc;
+}
+
+static int stage_finish(StageRun& r) {
+    gem_handle* h = r.h;
+    Workspace& w = h->ws;
+    w.round = -1;
     w.dyn = false;
-    if (rc) return 1;
+    if (r.B == 0) return 0;
     // every window is finished now: trial == x*; decode it with the same kernels as the rounds (all windows again)
-    if (evaluate(h, stage, B, w.trial, energy_args(h, d_pose_in, d_heat, d_frame0, d_mean_bone, wt), s, true)) return 1;
-    if (launch_unpack_pose(w.dec_act.back(), d_pose_out, B * h->T, h->C, s)) return 1;
-    if (d_stats && launch_lbfgs_stats(h, B, d_stats, s)) return 1;
+    if (evaluate(h, r.stage, r.B, w.trial, energy_args(h, r.pose_in, r.heat, r.frame0, r.mean_bone, r.wt), r.s, true)) return 1;
+    if (launch_unpack_pose(w.dec_act.back(), r.pose_out, r.B * h->T, h->C, r.s)) return 1;
+    if (r.stats && launch_lbfgs_stats(h, r.B, r.stats, r.s)) return 1;
     return 0;
+}
+
+static int optimize_stage_impl(gem_handle* h, int stage, int B, const float* d_pose_in, const float* d_heat,
+                               const int32_t* d_frame0, const float* d_mean_bone, const float* d_eps,
+                               const gem_energy_weights& wt, const gem_lbfgs_opts& opt, float* d_pose_out,
+                               gem_window_stats* d_stats, hipStream_t s) {
+    StageRun r;
+    r.h = h; r.stage = stage; r.B = B; r.pose_in = d_pose_in; r.heat = d_heat; r.frame0 = d_frame0; r.mean_bone = d_mean_bone; r.eps = d_eps;
+    r.wt = wt; r.opt = opt; r.pose_out = d_pose_out; r.stats = d_stats; r.s = s;
+    if (stage_begin(r)) { h->ws.dyn = false; return 1; }
+    int rc = 0;
+    for (int k = 0; k < r.rounds && !rc; ++k) rc = stage_round(r, k);
+    if (rc) { h->ws.round = -1; h->ws.dyn = false; return 1; }
+    return stage_finish(r);
+}
+
+// ---- both stages of the window loop for one lane (optimizer.py:370-423), as host steps around the stage rounds ---------------
+struct WindowsRun {
+    gem_handle* h = nullptr;
+    int B = 0;
+    const float* local_pose = nullptr; const double* cams = nullptr; const float* heat = nullptr; const int32_t* frame0 = nullptr;
+    const float* mean_bone = nullptr; const float* eps_local = nullptr; const float* eps_global = nullptr;
+    gem_energy_weights w_local{}, w_global{}; gem_lbfgs_opts opt{};
+    float* mid_local = nullptr; double* global = nullptr; gem_window_stats* stats_local = nullptr; gem_window_stats* stats_global = nullptr;
+    hipStream_t s = nullptr;
+    StageRun st;
+    float* mid = nullptr;
+};
+
+static int windows_begin_local(WindowsRun& r) {
+    gem_handle* h = r.h;
+    Workspace& w = h->ws;
+    if (launch_gather_windows(r.local_pose, r.frame0, w.pose_a, r.B, h->T, h->C, r.s)) return 1;
+    r.mid = r.mid_local ? r.mid_local : w.pose_b;
+    StageRun& s = r.st;
+    s = StageRun{};
+    s.h = h; s.stage = GEM_STAGE_LOCAL; s.B = r.B; s.pose_in = w.pose_a; s.heat = r.heat; s.frame0 = r.frame0; s.mean_bone = r.mean_bone;
+    s.eps = r.eps_local; s.wt = r.w_local; s.opt = r.opt; s.pose_out = r.mid; s.stats = r.stats_local; s.s = r.s;
+    return stage_begin(s);
+}
+static int windows_begin_global(WindowsRun& r) {       // local stage -> fp64 relative-global transform -> global stage set up
+    gem_handle* h = r.h;
+    Workspace& w = h->ws;
+    if (stage_finish(r.st)) return 1;
+    if (launch_relative_global(r.mid, r.cams, r.frame0, w.pose_a, r.B, h->T, h->J, r.s)) return 1;
+    StageRun& s = r.st;
+    s = StageRun{};
+    s.h = h; s.stage = GEM_STAGE_GLOBAL; s.B = r.B; s.pose_in = w.pose_a; s.heat = r.heat; s.frame0 = r.frame0; s.mean_bone = r.mean_bone;
+    s.eps = r.eps_global; s.wt = r.w_global; s.opt = r.opt; s.pose_out = w.pose_b;      // (the stage-A result kept there, if any, is dead after the transform)
+    s.stats = r.stats_global; s.s = r.s;
+    return stage_begin(s);
+}
+static int windows_end(WindowsRun& r) {
+    gem_handle* h = r.h;
+    if (stage_finish(r.st)) return 1;
+    return launch_to_global(h->ws.pose_b, r.cams, r.frame0, r.global, r.B, h->T, h->J, r.s);
+}
+static void windows_abort(WindowsRun& r) { r.h->ws.round = -1; r.h->ws.dyn = false; r.h->ws.mid_event = nullptr; }
+
+static int windows_single(WindowsRun& r) {
+    int rc = windows_begin_local(r);
+    for (int k = 0; k < r.st.rounds && !rc; ++k) rc = stage_round(r.st, k);
+    rc = rc || windows_begin_global(r);
+    for (int k = 0; k < r.st.rounds && !rc; ++k) rc = stage_round(r.st, k);
+    rc = rc || windows_end(r);
+    if (rc) windows_abort(r);
+    return rc;
+}
+
+// ---- two lanes --------------------------------------------------------------------------------------------------------------
+// Windows are independent (optimizer.py:370), so a large batch can run as two half-batches on two streams, shifted by HALF an
+// evaluation round: while lane A runs its backward product and its HBM-bound L-BFGS advance, lane B runs its forward product and
+// its fused tail, and vice versa -- the memory-bound kernel of one lane shares the machine with the matrix-bound kernels of the
+// other instead of owning it alone.  The shift is enforced, not hoped for: every round of a lane waits for the event the other
+// lane records behind its tail kernel (B's round r for A's tail of round r, A's round r+1 for B's tail of round r), so the two
+// tails never run together and the lanes cannot drift back into step.  Inside a captured graph the events become edges between
+// the two chains.  Each lane has its own workspace (a second handle that shares the weights); a window's result does not depend
+// on which other windows share its batch as long as no product is cut along K (lanes are used from 4352 windows on, where
+// neither the full batch nor its halves are): bitwise the single-lane result (tests/test_hip_full_size.py).
+static int ensure_lane(gem_handle* h, int B_lane) {
+    if (h->lane2 && h->lane2->ws.Bmax >= B_lane) return 0;
+    if (h->lane2) { GEM_HIP(hipDeviceSynchronize()); gem_destroy(h->lane2); h->lane2 = nullptr; }
+    gem_config cfg = h->cfg;
+    cfg.max_windows = std::max(B_lane, (h->ws.Bmax + 1) / 2 + 8);
+    gem_handle* l = nullptr;
+    if (gem_create(&cfg, &l)) return 1;
+    h->lane2 = l;
+    if (!h->lane_stream) GEM_HIP(hipStreamCreateWithFlags(&h->lane_stream, hipStreamNonBlocking));
+    if (!h->ev_fork) { GEM_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming)); GEM_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming)); }
+    return 0;
+}
+static void sync_lane(gem_handle* h) {          // the lane evaluates the same networks with the same settings (weights are shared, not copied)
+    gem_handle* l = h->lane2;
+    for (int st = 0; st < 2; ++st) {
+        l->net[st] = h->net[st];
+        l->net[st].allocs.clear();              // owned by h
+    }
+    l->precision = h->precision; l->tex_cache = h->tex_cache; l->prof.on = false;
+}
+static hipEvent_t lane_event(gem_handle* h, size_t i) {
+    while (h->ev_pool.size() <= i) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+        h->ev_pool.push_back(e);
+    }
+    return h->ev_pool[i];
+}
+
+static int windows_dual(WindowsRun& a, WindowsRun& b, gem_handle* h) {
+    hipStream_t sa = a.s, sb = b.s;
+    GEM_HIP(hipEventRecord(h->ev_fork, sa));
+    GEM_HIP(hipStreamWaitEvent(sb, h->ev_fork, 0));
+    int rc = windows_begin_local(a) || windows_begin_local(b);
+    size_t ev = 0;
+    hipEvent_t last_b = nullptr;
+    auto rounds = [&]() {
+        for (int k = 0; k < a.st.rounds && !rc; ++k) {
+            hipEvent_t ea = lane_event(h, ev++), eb = lane_event(h, ev++);
+            if (!ea || !eb) { set_error("optimize: hipEventCreate failed"); rc = 1; break; }
+            if (last_b) rc = rc || !hip_ok(hipStreamWaitEvent(sa, last_b, 0), "hipStreamWaitEvent");
+            a.h->ws.mid_event = ea;
+            rc = rc || stage_round(a.st, k);
+            rc = rc || !hip_ok(hipStreamWaitEvent(sb, ea, 0), "hipStreamWaitEvent");
+            b.h->ws.mid_event = eb;
+            rc = rc || stage_round(b.st, k);
+            last_b = eb;
+        }
+    };
+    rounds();
+    rc = rc || windows_begin_global(a) || windows_begin_global(b);
+    rounds();
+    rc = rc || windows_end(a) || windows_end(b);
+    if (rc) { windows_abort(a); windows_abort(b); }
+    // join: the caller's stream continues when lane B is done (also on an error: the capture, if any, must see the join)
+    if (hipEventRecord(h->ev_join, sb) != hipSuccess || hipStreamWaitEvent(sa, h->ev_join, 0) != hipSuccess) rc = 1;
+    return rc;
 }
 
 // ---- hipGraph replay of a whole call ------------------------------------------------------------------------------------
@@ -681,7 +856,8 @@ static int optimize_stage_impl(gem_handle* h, int stage, int B, const float* d_p
 // the second one is captured into a hipGraph and instantiated, every later one is a single hipGraphLaunch: the host cost of a
 // call drops from ~3 ms of launches to one launch (BASELINE configs[4]; several sequences in flight from one host thread).
 static bool same_key(const GraphKey& a, const GraphKey& b) {
-    if (a.kind != b.kind || a.stage != b.stage || a.B != b.B || a.precision != b.precision || a.stream != b.stream || a.tex_cache != b.tex_cache)
+    if (a.kind != b.kind || a.stage != b.stage || a.B != b.B || a.precision != b.precision || a.stream != b.stream || a.tex_cache != b.tex_cache ||
+        a.lanes != b.lanes)
         return false;
     for (int i = 0; i < 12; ++i)
         if (a.ptr[i] != b.ptr[i]) return false;
@@ -785,6 +961,7 @@ int gem_optimize_stage(gem_handle* h, int stage, int B, const float* d_pose_in, 
     if (!d_pose_in || !d_mean_bone || !wt || !opt || !d_pose_out) { set_error("gem_optimize_stage: null argument"); return 1; }
     GraphKey key;
     key.kind = 1; key.stage = stage; key.B = B; key.precision = h->precision; key.stream = stream; key.tex_cache = h->tex_cache;
+    h->last_split = 0;
     const void* ptrs[] = {d_pose_in, d_heat, d_frame0, d_mean_bone, d_eps, d_pose_out, d_stats};
     for (int i = 0; i < 7; ++i) key.ptr[i] = ptrs[i];
     key.w[0] = *wt; key.opt = *opt;
@@ -810,19 +987,29 @@ int gem_optimize_windows(gem_handle* h, int B, const float* d_local_pose, const 
     const void* ptrs[] = {d_local_pose, d_cams, d_heat, d_frame0, d_mean_bone, d_eps_local, d_eps_global, d_mid_local, d_global, d_stats};
     for (int i = 0; i < 10; ++i) key.ptr[i] = ptrs[i];
     key.w[0] = *w_local; key.w[1] = *w_global; key.opt = *opt;
+    // two lanes (windows_dual above) from lanes_min windows on; not while event profiling is on (the per-kernel timings would be
+    // those of kernels sharing the machine)
+    // (bf16 decoder mode only: that is where the products' K cuts were checked to be the same for a batch and its halves)
+    const bool dual = h->lanes_min > 0 && B >= h->lanes_min && !h->prof.on && h->precision == GEM_PRECISION_BF16;
+    const int BA = dual ? ((B + 1) / 2 + 7) / 8 * 8 : B;        // whole tail workgroups (8 windows) in the first lane
+    if (dual) {
+        if (ensure_lane(h, B - BA > BA ? B - BA : BA)) return 1;
+        sync_lane(h);
+    }
+    key.lanes = dual ? 2 : 1;
+    h->last_split = dual ? BA : 0;
     return run_graphed(h, key, s, [&]() -> int {
-        Workspace& w = h->ws;
-        const int T = h->T, J = h->J;
-        // window loop body of main() (optimizer.py:370-423), all windows at once
-        if (launch_gather_windows(d_local_pose, d_frame0, w.pose_a, B, T, h->C, s)) return 1;
-        float* mid = d_mid_local ? d_mid_local : w.pose_b;
-        if (optimize_stage_impl(h, GEM_STAGE_LOCAL, B, w.pose_a, d_heat, d_frame0, d_mean_bone, d_eps_local, *w_local, *opt, mid,
-                                d_stats, s)) return 1;
-        if (launch_relative_global(mid, d_cams, d_frame0, w.pose_a, B, T, J, s)) return 1;
-        float* out_b = w.pose_b;      // the stage-A result kept there (if any) is dead after the transform above
-        if (optimize_stage_impl(h, GEM_STAGE_GLOBAL, B, w.pose_a, d_heat, d_frame0, d_mean_bone, d_eps_global, *w_global, *opt, out_b,
-                                d_stats ? d_stats + B : nullptr, s)) return 1;
-        return launch_to_global(out_b, d_cams, d_frame0, d_global, B, T, J, s);
+        WindowsRun a;
+        a.h = h; a.B = BA; a.local_pose = d_local_pose; a.cams = d_cams; a.heat = d_heat; a.frame0 = d_frame0; a.mean_bone = d_mean_bone;
+        a.eps_local = d_eps_local; a.eps_global = d_eps_global; a.w_local = *w_local; a.w_global = *w_global; a.opt = *opt;
+        a.mid_local = d_mid_local; a.global = d_global; a.stats_local = d_stats; a.stats_global = d_stats ? d_stats + B : nullptr; a.s = s;
+        if (!dual) return windows_single(a);
+        WindowsRun b = a;
+        b.h = h->lane2; b.B = B - BA; b.frame0 = d_frame0 + BA; b.mean_bone = d_mean_bone + (size_t)BA * h->J;
+        b.eps_local = d_eps_local ? d_eps_local + (size_t)BA * h->D : nullptr; b.eps_global = d_eps_global ? d_eps_global + (size_t)BA * h->D : nullptr;
+        b.mid_local = d_mid_local ? d_mid_local + (size_t)BA * h->T * h->C : nullptr; b.global = d_global + (size_t)BA * h->T * h->C;
+        b.stats_local = d_stats ? d_stats + BA : nullptr; b.stats_global = d_stats ? d_stats + B + BA : nullptr; b.s = h->lane_stream;
+        return windows_dual(a, b, h);
     });
 }
 
@@ -832,8 +1019,13 @@ int gem_read_trace(gem_handle* h, int B, int n_rounds, double* d_out, void* stre
     }
     GEM_HIP(hipSetDevice(h->cfg.device));
     if (B == 0 || n_rounds == 0) return 0;
+    // (after a two-lane gem_optimize_windows call the windows [last_split, B) live in the second lane's workspace)
+    const int BA = (h->last_split > 0 && h->lane2 && h->last_split < B) ? h->last_split : B;
     GEM_HIP(hipMemcpy2DAsync(d_out, (size_t)B * sizeof(double), h->ws.trace, (size_t)h->ws.Bmax * sizeof(double),
-                             (size_t)B * sizeof(double), (size_t)n_rounds, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+                             (size_t)BA * sizeof(double), (size_t)n_rounds, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    if (BA < B)
+        GEM_HIP(hipMemcpy2DAsync(d_out + BA, (size_t)B * sizeof(double), h->lane2->ws.trace, (size_t)h->lane2->ws.Bmax * sizeof(double),
+                                 (size_t)(B - BA) * sizeof(double), (size_t)n_rounds, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return 0;
 }
 
@@ -853,6 +1045,12 @@ int gem_graph_stats(gem_handle* h, int64_t* n_captures, int64_t* n_replays) {
     if (!h) { set_error("gem_graph_stats: null handle"); return 1; }
     if (n_captures) *n_captures = h->graph_captures;
     if (n_replays) *n_replays = h->graph_replays;
+    return 0;
+}
+
+int gem_set_lanes(gem_handle* h, int min_windows) {
+    if (!h || min_windows < 0) { set_error("gem_set_lanes: min_windows must be >= 0 (0 = one lane always)"); return 1; }
+    h->lanes_min = min_windows;
     return 0;
 }
 

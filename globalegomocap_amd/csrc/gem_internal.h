@@ -119,6 +119,7 @@ struct Workspace {
     bool tex_on = false;                // energy_args() hands the cache to the kernels (inside a stage only)
     double* trace = nullptr;            // [TRACE_ROUNDS][Bmax] closure value each window consumed in round r of the last stage (NaN: none)
     int round = -1;                     // evaluation round being enqueued (-1: outside the rounds)
+    hipEvent_t mid_event = nullptr;     // two lanes: recorded behind the tail / energy kernel of the round being enqueued (then reset)
     // pipeline scratch
     float* pose_a = nullptr;            // [B,T,J,3] gathered local poses / stage outputs
     float* pose_b = nullptr;
@@ -202,6 +203,7 @@ namespace gem {
 struct GraphKey {
     int kind = 0, stage = 0, B = 0, precision = 0;
     bool tex_cache = true;
+    int lanes = 1;
     const void* ptr[12] = {};
     gem_energy_weights w[2] = {};
     gem_lbfgs_opts opt = {};
@@ -232,9 +234,24 @@ struct gem_handle {
     int64_t graph_replays = 0, graph_captures = 0;
     int* d_parents = nullptr;
     int* d_children = nullptr;     // [J][J] child lists, -1 terminated
+    // two lanes (gem_api.hip windows_dual): a second handle with its own workspace that shares this handle's weights
+    gem_handle* lane2 = nullptr;
+    hipStream_t lane_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    std::vector<hipEvent_t> ev_pool;
+    int lanes_min = 4352;          // gem_set_lanes: batches of at least this many windows run as two lanes (0: never)
+    int last_split = 0;            // windows in the first lane of the last gem_optimize_windows call (0: one lane)
 };
 
 namespace gem {
+
+// two lanes: the half-round marker of the round being enqueued (Workspace::mid_event), recorded behind the tail / energy kernel
+inline int record_mid(gem_handle* h, hipStream_t s) {
+    if (!h->ws.mid_event) return 0;
+    const hipError_t e = hipEventRecord(h->ws.mid_event, s);
+    h->ws.mid_event = nullptr;
+    return gem::hip_ok(e, "hipEventRecord(mid)") ? 0 : 1;
+}
 
 // profiling hook: remember the (demangled) name of a kernel about to be launched; no-op unless event profiling is on
 void note_kernel(gem_handle* h, const void* host_fn);

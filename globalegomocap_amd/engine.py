@@ -118,6 +118,11 @@ class WindowEngine:
         cur.wait_stream(self._gstream)
         return r
 
+    def set_lanes(self, min_windows):
+        """optimize_windows calls of at least `min_windows` windows run as two half-batches on two streams, half a round apart
+        (gem_set_lanes; default 4352; 0 = never).  Same results, bit for bit, from the default threshold on."""
+        _capi.check(self.lib.gem_set_lanes(self._h, int(min_windows)), self.lib)
+
     def set_precision(self, mode):
         """'f32' (default) | 'bf16x3' (split-bf16 MFMA, fp32-grade) | 'bf16' for the wide decoder/encoder products."""
         _capi.check(self.lib.gem_set_precision(self._h, _capi.PRECISION[mode]), self.lib)

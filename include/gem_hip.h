@@ -86,6 +86,13 @@ int gem_version(void);
 int  gem_create(const gem_config* cfg, gem_handle** out);
 void gem_destroy(gem_handle* h);
 
+/* Two lanes: gem_optimize_windows calls of at least `min_windows` windows run as two half-batches on two streams (the caller's
+ * and one owned by the handle), shifted by half an evaluation round so that the HBM-bound L-BFGS advance of one half shares the
+ * device with the matrix-bound kernels of the other (windows are independent: optimizer.py:370).  Results are bitwise those of
+ * one lane wherever no product is cut along K (the default threshold, 4352 windows, guarantees it); outputs, statistics and
+ * gem_read_trace are assembled in window order.  0 = always one lane.  Costs a second workspace (half the size of the first). */
+int gem_set_lanes(gem_handle* h, int min_windows);
+
 /* Arithmetic of the wide decoder / encoder products (the narrow tail layers and every energy term are
  * always fp32):  0 = fp32 MFMA (default, BASELINE configs[1]);
  *                1 = "bf16x3": operands split into bf16 hi+lo, three bf16 MFMAs per product, fp32 accumulate

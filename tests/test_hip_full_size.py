@@ -528,6 +528,36 @@ def test_config4_shard_of_a_continuous_stream(torch_cuda, friendly_vaes, precisi
     eng.close()
 
 
+@pytest.mark.parametrize("B", [4360, 8192])
+def test_two_lanes_are_bitwise_one_lane(torch_cuda, friendly_vaes, B):
+    """Large bf16 batches run as two half-batches on two streams, half an evaluation round apart (gem_set_lanes / windows_dual
+    in csrc/gem_api.hip), so that one half's HBM-bound L-BFGS advance overlaps the other half's matrix-bound kernels.  Windows do
+    not interact and from 4352 windows on no product is cut along K in the full batch or in its halves: mid-local poses, global
+    poses, statistics and closure traces must be bit for bit those of ONE lane -- eagerly and replayed from a hipGraph."""
+    torch = torch_cuda
+    sd_l, sd_g = friendly_vaes
+    rng = np.random.default_rng(B)
+    n_frames = 6000
+    starts = rng.integers(0, n_frames - 10, B)
+    one = _engine(B, sd_l, sd_g, "bf16")
+    one.set_lanes(0)
+    p = _device_problem(one, n_frames, starts, seed=B, n_dup=0)
+    ref = [t.clone() for t in _run(one, p)]
+    tr_ref = one.read_trace(B, 8)
+    one.close()
+    two = _engine(B, sd_l, sd_g, "bf16")                 # default: two lanes from 4352 windows on
+    for graphs in (False, True):
+        two.enable_graphs(graphs)
+        for k in range(3 if graphs else 1):
+            got = _run(two, p)
+            torch.cuda.synchronize()
+            for a_, b_ in zip(got, ref):
+                assert torch.equal(a_, b_), (graphs, k)
+        assert np.array_equal(two.read_trace(B, 8), tr_ref, equal_nan=True)
+    assert two.graph_stats()["replays"] >= 2
+    two.close()
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # hipGraph replay (BASELINE configs[4])
 # ------------------------------------------------------------------------------------------------------------------

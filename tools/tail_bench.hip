@@ -6,6 +6,8 @@
 #include "../globalegomocap_amd/csrc/tail.hip"
 namespace gem {
 void set_error(const std::string& m) { fprintf(stderr, "error: %s\n", m.c_str()); }
+const char* dev_env(const char*) { return nullptr; }
+void note_kernel(gem_handle*, const void*) {}
 bool hip_ok(hipError_t e, const char* what) { if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", what, hipGetErrorString(e)); return false; } return true; }
 }
 using namespace gem;
