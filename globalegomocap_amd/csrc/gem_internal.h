@@ -236,8 +236,11 @@ struct gem_handle {
     int* d_children = nullptr;     // [J][J] child lists, -1 terminated
     // two lanes (gem_api.hip windows_dual): a second handle with its own workspace that shares this handle's weights
     gem_handle* lane2 = nullptr;
-    hipStream_t lane_stream = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t lane_stream = nullptr, lane_stream_a = nullptr;      // both lanes run on streams of their own (non-blocking: the
+                                                                     // caller's may be the legacy default stream, whose implicit
+                                                                     // synchronisation with every blocking stream of the process
+                                                                     // would sit between the lanes' kernels)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join_a = nullptr;
     std::vector<hipEvent_t> ev_pool;
     int lanes_min = 4352;          // gem_set_lanes: batches of at least this many windows run as two lanes (0: never)
     int last_split = 0;            // windows in the first lane of the last gem_optimize_windows call (0: one lane)

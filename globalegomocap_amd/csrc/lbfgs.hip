@@ -207,8 +207,8 @@ __device__ __forceinline__ void lbfgs_advance_body(const AdvArgs& a) {
             }
         }
     };
-    auto store_trial = [&](const float (&v)[EPT]) {       // the next point to evaluate, fp32 and (bf16 decoder mode) bf16
-        store(a.trial, v);
+    auto store_trial = [&](const float (&v)[EPT]) {       // the next point to evaluate: fp32, or bf16 in the bf16 decoder mode (whose
+        if (!a.trial_b) store(a.trial, v);                // products read only the bf16 copy: 8 KB per window and round not written)
         if (a.trial_b) {
             uint16_t* p = a.trial_b + off;
             if constexpr (EPT % 4 == 0) {

@@ -81,9 +81,11 @@ o = traffic("f32", dom, "traffic_%s.json" % tag,
 if o and "dominant_kernel" in o:
     json.dump({k: o.get(k) for k in ("note", "dominant_kernel", "hbm_bytes_per_launch")}, open(os.path.join(dst, "traffic_dominant_kernel.json"), "w"), indent=1)
     print("headline dominant kernel:", o["dominant_kernel"], o["hbm_bytes_per_launch"], "bytes per launch")
-b = traffic("bf16_8192", "gemm_glds_kernel<false, 1, 0", "traffic_%s_bf16_8196_windows.json" % tag,
+b = traffic("bf16_8192", "gemm_glds_kernel<false, 1, ", "traffic_%s_bf16_8196_windows.json" % tag,
             "python bench.py --steps 1 --warmup 1 --workload w8192 --precision bf16 --cpu-windows 0 --no-extra --no-profile")
+c = traffic("bf16_1536", "gemm_glds_kernel<false, 1, ", "traffic_%s_bf16_1536_windows.json" % tag,
+            "python bench.py --steps 2 --warmup 1 --workload 128 --precision bf16 --cpu-windows 0 --no-extra --no-profile")
 if b:
     for k, v in b["kernels"].items():
-        if "glds" in k or "lbfgs" in k or "energy" in k:
+        if "glds" in k or "lbfgs" in k or "energy" in k or "tail" in k:
             print(k, v)
