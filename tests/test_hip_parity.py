@@ -575,6 +575,45 @@ def test_bf16_multi_window_tail_against_the_batched_bf16_layers(torch_cuda, monk
         assert np.abs(Xa[k] - Xo).max() <= 8e-3 * max(1.0, np.abs(Xo).max()), k
 
 
+@pytest.mark.parametrize("T,B", [(12, 13), (16, 7), (5, 19)])
+def test_bf16_multi_window_tail_with_other_window_lengths(torch_cuda, monkeypatch, T, B):
+    """The bf16 tail packs G = min(8, 80 // T) windows into its 80 rows and uses the run-time-shaped energy code for anything but
+    10 x 15: windows of 12 frames (6 per workgroup, 72 rows), 16 (5, 80 rows) and 5 (8, 40 rows) against the batched bf16 layers +
+    stand-alone energy kernel, ragged last workgroups included."""
+    torch = torch_cuda
+    shape = vae_schema.VAEShape(latent_dim=32, seq_len=T, hidden=(16, 16, 32, 32, 64))
+    sd = vae_schema.synthetic_state_dict(shape, 17)
+    seq = synth.make_sequence(n_frames=200, seed=38)
+    est = np.asarray(seq["estimated_local_skeleton"], dtype=np.float32)
+    heat = torch.as_tensor(np.asarray(seq["heatmap_list"], dtype=np.float32), device="cuda")
+    rng = np.random.default_rng(T)
+    starts = rng.integers(0, 200 - T, B).astype(np.int32)
+    pose = np.stack([est[s:s + T] for s in starts])
+    mb = O.mean_bone_length(est)
+    z = rng.normal(size=(B, 32)).astype(np.float32)
+    res = {}
+    monkeypatch.setenv("GEM_DEV", "1")
+    for tag in ("tail16", "batched"):
+        if tag == "tail16":
+            monkeypatch.setenv("GEM_TAIL16", "1")
+            monkeypatch.delenv("GEM_BATCHED_NARROW", raising=False)
+        else:
+            monkeypatch.setenv("GEM_TAIL16", "0")
+            monkeypatch.setenv("GEM_BATCHED_NARROW", "1")
+        eng = _engine(shape, max_windows=B)
+        eng.load_vae(0, sd)
+        eng.set_precision("bf16")
+        E, parts, dz, X = eng.energy_grad(0, z, pose, mb, _ew(W_ALL), heat, starts)
+        torch.cuda.synchronize()
+        res[tag] = (E.cpu().numpy(), parts.cpu().numpy(), dz.cpu().numpy(), X.cpu().numpy())
+        eng.close()
+    (Ea, Pa, dza, Xa), (Eb, Pb, dzb, Xb) = res["tail16"], res["batched"]
+    assert np.abs(Xa - Xb).max() <= 1e-5 * max(1.0, np.abs(Xb).max())
+    np.testing.assert_allclose(Ea, Eb, rtol=1e-5)
+    np.testing.assert_allclose(Pa, Pb, rtol=1e-5, atol=1e-9)
+    assert np.abs(dza - dzb).max() <= 1e-3 * np.abs(dzb).max()
+
+
 def test_projections_outside_the_heatmap_and_error_paths(torch_cuda):
     """Joints that project outside the 64x64 heat-map sample zeros (grid_sample padding); bad calls raise."""
     from globalegomocap_amd import _capi
