@@ -38,6 +38,11 @@ class GemLbfgsOpts(C.Structure):
                 ("c2", C.c_double), ("ls_tol_change", C.c_double)]
 
 
+class GemTrainOpts(C.Structure):
+    _fields_ = [("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("weight_decay", C.c_double),
+                ("kld_weight", C.c_double), ("bn_momentum", C.c_double), ("recon_sum", C.c_int32), ("reserved", C.c_int32)]
+
+
 class GemWindowStats(C.Structure):
     _fields_ = [("n_iter", C.c_int32), ("func_evals", C.c_int32), ("final_loss", C.c_float), ("status", C.c_int32)]
 
@@ -70,6 +75,13 @@ SIGNATURES = {
     "gem_profile_enable": (C.c_int, [_P, C.c_int]),
     "gem_profile_read": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "gem_profile_kernels": (C.c_int, [_P, C.c_int, C.c_char_p, C.c_int]),
+    "gem_trainer_create": (C.c_int, [C.POINTER(GemConfig), C.POINTER(_P)]),
+    "gem_trainer_destroy": (None, [_P]),
+    "gem_trainer_sizes": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "gem_trainer_upload": (C.c_int, [_P, C.c_int, _P, C.c_int64]),
+    "gem_trainer_download": (C.c_int, [_P, C.c_int, _P, C.c_int64]),
+    "gem_trainer_set_step": (C.c_int, [_P, C.c_int64]),
+    "gem_trainer_step": (C.c_int, [_P, C.c_int, _P, _P, C.POINTER(GemTrainOpts), C.c_int, _P, _P]),
 }
 
 _lib = None

@@ -1,0 +1,354 @@
+"""Training / fine-tuning of the motion VAE on the device.
+
+Host-side mirror of the reference's `networks/train.py:36-127` (class `Train`) over `gem_trainer_*` (include/gem_hip.h,
+csrc/train.hip): one `VAETrainer.step` is the loop body `zero_grad -> forward (train mode) -> loss_function -> backward ->
+Adam.step` (train.py:77-83), `fit` the epoch loop with the same shuffling DataLoader semantics (shuffle, drop_last), the same
+M_N = kl_weight * batch_size / len(dataset), the running-loss log every `log_step` steps, the evaluation pass
+(train.py:110-123: eval-mode reconstruction MPJPE) and the per-epoch checkpoint `{'epoch', 'state_dict', 'eval_result', ...}`
+(train.py:102-108) in the reference's own schema, which `optimizer.py:59-60` and `WindowEngine.load_vae` read back.
+
+The arena layout functions at the top are numpy-only (tested on the CPU); everything that computes goes through the HIP library
+and fails loudly without it.
+"""
+import ctypes as C
+import os
+from collections import OrderedDict
+
+import numpy as np
+
+from .vae import VAEShape, check_state_dict, _np
+
+PAD = 64
+
+
+def _pad(x):
+    return (x + PAD - 1) // PAD * PAD
+
+
+def arena_layout(shape):
+    """The packed arena of gem_trainer (include/gem_hip.h): ([(key, kind, offset, (dims...))...], n_params, [(key, offset, N, C)...],
+    n_stats).  kinds: conv / convT (weight [3][N][K]), vec (length N, real C), fc (stacked [2Dp][T*topp]), fc_b, din, din_b."""
+    T, D, Dp = shape.seq_len, shape.latent_dim, _pad(shape.latent_dim)
+    top, topp = shape.hidden[-1], _pad(shape.hidden[-1])
+    enc, dec = shape.conv_layers()
+    items, stats, off, soff = [], [], 0, 0
+
+    def conv(prefix, kind, ci, co, bn):
+        nonlocal off, soff
+        K, N = _pad(ci), _pad(co)
+        wkey = prefix + (".0.weight" if bn else ".weight")
+        items.append((wkey, kind, off, (N, K, co, ci)))
+        off += 3 * N * K
+        items.append((prefix + (".0.bias" if bn else ".bias"), "vec", off, (N, co)))
+        off += N
+        if bn:
+            items.append((prefix + ".1.weight", "vec", off, (N, co)))
+            off += N
+            items.append((prefix + ".1.bias", "vec", off, (N, co)))
+            off += N
+            stats.append((prefix + ".1.running_mean", soff, N, co))
+            stats.append((prefix + ".1.running_var", soff + N, N, co))
+            soff += 2 * N
+
+    for prefix, kind, ci, co, bn in enc:
+        conv(prefix, kind, ci, co, bn)
+    items.append(("fc", "fc", off, (Dp, T, topp, D, top)))
+    off += 2 * Dp * T * topp
+    items.append(("fc.bias", "fc_b", off, (Dp, D)))
+    off += 2 * Dp
+    items.append(("decoder_input.weight", "din", off, (T, topp, Dp, top, D)))
+    off += T * topp * Dp
+    items.append(("decoder_input.bias", "din_b", off, (T, topp, top)))
+    off += T * topp
+    for prefix, kind, ci, co, bn in dec:
+        conv(prefix, kind, ci, co, bn)
+    return items, off, stats, soff
+
+
+def pack_arena(state, shape):
+    """Reference-schema state_dict -> (params arena, statistics arena), fp32."""
+    check_state_dict(state, shape)
+    items, n, stats, ns = arena_layout(shape)
+    P, S = np.zeros(n, np.float32), np.zeros(ns, np.float32)
+    T = shape.seq_len
+    for key, kind, off, dims in items:
+        if kind in ("conv", "convT"):
+            N, K, co, ci = dims
+            w = _np(state[key]).astype(np.float32)
+            taps = np.transpose(w, (2, 0, 1)) if kind == "conv" else np.transpose(w[:, :, ::-1], (2, 1, 0))    # [tap][n][k]
+            blk = np.zeros((3, N, K), np.float32)
+            blk[:, :co, :ci] = taps
+            P[off:off + blk.size] = blk.ravel()
+        elif kind == "vec":
+            N, co = dims
+            P[off:off + co] = _np(state[key]).astype(np.float32)
+        elif kind == "fc":
+            Dp, _, topp, D, top = dims
+            blk = np.zeros((2, Dp, T, topp), np.float32)
+            for i, name in enumerate(("fc_mu", "fc_var")):
+                w = _np(state[name + ".weight"]).astype(np.float32).reshape(D, top, T)
+                blk[i, :D, :, :top] = np.transpose(w, (0, 2, 1))
+            P[off:off + blk.size] = blk.ravel()
+        elif kind == "fc_b":
+            Dp, D = dims
+            P[off:off + D] = _np(state["fc_mu.bias"])
+            P[off + Dp:off + Dp + D] = _np(state["fc_var.bias"])
+        elif kind == "din":
+            _, topp, Dp, top, D = dims
+            w = _np(state[key]).astype(np.float32).reshape(top, T, D)
+            blk = np.zeros((T, topp, Dp), np.float32)
+            blk[:, :top, :D] = np.transpose(w, (1, 0, 2))
+            P[off:off + blk.size] = blk.ravel()
+        elif kind == "din_b":
+            _, topp, top = dims
+            blk = np.zeros((T, topp), np.float32)
+            blk[:, :top] = _np(state[key]).astype(np.float32).reshape(top, T).T
+            P[off:off + blk.size] = blk.ravel()
+    for key, off, N, co in stats:
+        S[off:off + N] = 1.0 if key.endswith("running_var") else 0.0
+        S[off:off + co] = _np(state[key]).astype(np.float32)
+    return P, S
+
+
+def unpack_arena(P, shape, S=None):
+    """Inverse of pack_arena for a parameter-shaped arena (parameters, gradients, Adam moments): OrderedDict in schema order
+    (statistics keys only when `S` is given)."""
+    items, n, stats, ns = arena_layout(shape)
+    P = np.asarray(P, np.float32)
+    if P.size != n:
+        raise ValueError("arena has %d floats, the layout %d" % (P.size, n))
+    T = shape.seq_len
+    out = {}
+    for key, kind, off, dims in items:
+        if kind in ("conv", "convT"):
+            N, K, co, ci = dims
+            taps = P[off:off + 3 * N * K].reshape(3, N, K)[:, :co, :ci]
+            out[key] = np.ascontiguousarray(np.transpose(taps, (1, 2, 0)) if kind == "conv" else np.transpose(taps, (2, 1, 0))[:, :, ::-1])
+        elif kind == "vec":
+            out[key] = P[off:off + dims[1]].copy()
+        elif kind == "fc":
+            Dp, _, topp, D, top = dims
+            blk = P[off:off + 2 * Dp * T * topp].reshape(2, Dp, T, topp)
+            for i, name in enumerate(("fc_mu", "fc_var")):
+                out[name + ".weight"] = np.ascontiguousarray(np.transpose(blk[i, :D, :, :top], (0, 2, 1))).reshape(D, top * T)
+        elif kind == "fc_b":
+            Dp, D = dims
+            out["fc_mu.bias"], out["fc_var.bias"] = P[off:off + D].copy(), P[off + Dp:off + Dp + D].copy()
+        elif kind == "din":
+            _, topp, Dp, top, D = dims
+            blk = P[off:off + T * topp * Dp].reshape(T, topp, Dp)[:, :top, :D]
+            out[key] = np.ascontiguousarray(np.transpose(blk, (1, 0, 2))).reshape(top * T, D)
+        elif kind == "din_b":
+            _, topp, top = dims
+            out[key] = np.ascontiguousarray(P[off:off + T * topp].reshape(T, topp)[:, :top].T).reshape(top * T)
+    if S is not None:
+        S = np.asarray(S, np.float32)
+        if S.size != ns:
+            raise ValueError("statistics arena has %d floats, the layout %d" % (S.size, ns))
+        for key, off, N, co in stats:
+            out[key] = S[off:off + co].copy()
+    return OrderedDict((k, out[k]) for k in shape.schema() if k in out)
+
+
+def initial_state_dict(shape, seed=0):
+    """ConvVAE.__init__ (SeqConvVAE.py:11-92) parameter initialisation -- torch's defaults for Conv1d / ConvTranspose1d / Linear
+    (kaiming_uniform(a=sqrt(5)) = U(+-1/sqrt(fan_in)) for weights and biases), BatchNorm weight 1 / bias 0 / mean 0 / var 1 --
+    drawn from a numpy generator (the values of torch's own RNG stream are not part of the reference's behaviour)."""
+    rng = np.random.default_rng(seed)
+    sd = OrderedDict()
+    for name, shp in shape.schema().items():
+        if name.endswith("running_mean") or (".1." in name and name.endswith(".bias")):
+            sd[name] = np.zeros(shp, np.float32)
+        elif name.endswith("running_var") or (".1." in name and name.endswith(".weight")):
+            sd[name] = np.ones(shp, np.float32)
+        elif name.endswith(".weight"):
+            # torch's fan_in = size(1) * receptive field, also for ConvTranspose1d's [C_in, C_out, k] (i.e. C_out * k there)
+            fan_in = shp[1] * (shp[2] if len(shp) == 3 else 1)
+            b = 1.0 / np.sqrt(fan_in)
+            sd[name] = rng.uniform(-b, b, shp).astype(np.float32)
+            sd["__fan_in__" + name] = fan_in
+        else:
+            w = name[:-len("bias")] + "weight"
+            b = 1.0 / np.sqrt(sd["__fan_in__" + w])
+            sd[name] = rng.uniform(-b, b, shp).astype(np.float32)
+    return OrderedDict((k, v) for k, v in sd.items() if not k.startswith("__fan_in__"))
+
+
+class VAETrainer:
+    """`Train` of networks/train.py over the HIP library: Adam(lr, weight_decay) on ConvVAE.loss_function, BatchNorm in train mode."""
+
+    def __init__(self, shape=None, batch_size=64, lr=1e-4, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8, bn_momentum=0.1,
+                 recon_reduction="mean", device=None, state_dict=None, seed=0):
+        import torch
+        from . import _capi
+        from .engine import N_JOINTS
+        self.lib = _capi.load_library()
+        if not torch.cuda.is_available():
+            raise _capi.GemError("no HIP device visible: the VAE trainer has no CPU path")
+        self.shape = shape or VAEShape()
+        if self.shape.channels != 3 * N_JOINTS:
+            raise ValueError("the trainer is built for %d-joint poses" % N_JOINTS)
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self.batch_size = int(batch_size)
+        cfg = _capi.GemConfig()
+        cfg.seq_len, cfg.n_joints, cfg.latent_dim = self.shape.seq_len, N_JOINTS, self.shape.latent_dim
+        cfg.n_hidden = len(self.shape.hidden)
+        for i, v in enumerate(self.shape.hidden):
+            cfg.hidden[i] = v
+        cfg.heat_h = cfg.heat_w = 64
+        cfg.n_poly, cfg.poly[0] = 1, 1.0
+        cfg.max_windows, cfg.device = self.batch_size, self.device.index
+        self._t = C.c_void_p()
+        _capi.check(self.lib.gem_trainer_create(C.byref(cfg), C.byref(self._t)), self.lib)
+        n, ns = C.c_int64(), C.c_int64()
+        _capi.check(self.lib.gem_trainer_sizes(self._t, C.byref(n), C.byref(ns)), self.lib)
+        self.n_params, self.n_stats = n.value, ns.value
+        lay = arena_layout(self.shape)
+        if (lay[1], lay[3]) != (self.n_params, self.n_stats):
+            raise _capi.GemError("arena layout of the library (%d, %d) and of vae_train.py (%d, %d) differ"
+                                 % (self.n_params, self.n_stats, lay[1], lay[3]))
+        self.opts = _capi.GemTrainOpts(lr=float(lr), beta1=float(betas[0]), beta2=float(betas[1]), eps=float(eps),
+                                       weight_decay=float(weight_decay), kld_weight=0.0, bn_momentum=float(bn_momentum),
+                                       recon_sum=1 if recon_reduction == "sum" else 0, reserved=0)
+        self.steps = 0
+        self._losses = torch.zeros(3, dtype=torch.float64, device=self.device)
+        self._gen = torch.Generator(device=self.device)
+        self._gen.manual_seed(seed)
+        self.load_state_dict(state_dict if state_dict is not None else initial_state_dict(self.shape, seed))
+
+    def close(self):
+        if getattr(self, "_t", None) is not None and self._t.value:
+            self.lib.gem_trainer_destroy(self._t)
+            self._t = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- parameters
+    def _up(self, what, arr):
+        from . import _capi
+        a = np.ascontiguousarray(arr, np.float32)
+        _capi.check(self.lib.gem_trainer_upload(self._t, what, a.ctypes.data_as(C.c_void_p), a.size), self.lib)
+
+    def _down(self, what):
+        from . import _capi
+        a = np.empty(self.n_stats if what == 2 else self.n_params, np.float32)
+        _capi.check(self.lib.gem_trainer_download(self._t, what, a.ctypes.data_as(C.c_void_p), a.size), self.lib)
+        return a
+
+    def load_state_dict(self, state):
+        """network.load_state_dict: parameters and running statistics; Adam's moments and step count start over."""
+        P, S = pack_arena(state, self.shape)
+        self._up(0, P)
+        self._up(2, S)
+        self._up(3, np.zeros_like(P))
+        self._up(4, np.zeros_like(P))
+        self.steps = 0
+
+    def state_dict(self):
+        """network.state_dict() in the reference's schema (numpy arrays; incl. num_batches_tracked like torch's BatchNorm)."""
+        sd = unpack_arena(self._down(0), self.shape, self._down(2))
+        out = OrderedDict()
+        for k, v in sd.items():
+            out[k] = v
+            if k.endswith("running_var"):
+                out[k[:-len("running_var")] + "num_batches_tracked"] = np.array(self.steps, np.int64)
+        return out
+
+    def gradients(self):
+        """The gradients of the last step, keyed like the parameters (p.grad after loss.backward())."""
+        return unpack_arena(self._down(1), self.shape)
+
+    def optimizer_state(self):
+        """Adam's exp_avg / exp_avg_sq per parameter key and the step count (optimizer.state_dict())."""
+        return {"step": self.steps, "exp_avg": unpack_arena(self._down(3), self.shape), "exp_avg_sq": unpack_arena(self._down(4), self.shape)}
+
+    # ---- one step (train.py:77-83)
+    def step(self, poses, kld_weight, eps=None, update=True, sync=True):
+        """poses [B,T,45] (device or host); eps [B,D] or None (drawn on the device like torch.randn_like).  Returns
+        (loss, recon_loss, kld_loss) as floats (sync=True) or the device tensor that will hold them."""
+        import torch
+        from . import _capi
+        x = torch.as_tensor(poses, dtype=torch.float32, device=self.device).contiguous()
+        B = int(x.shape[0])
+        if tuple(x.shape[1:]) != (self.shape.seq_len, self.shape.channels):
+            raise ValueError("poses must be [B,%d,%d]" % (self.shape.seq_len, self.shape.channels))
+        if eps is None:
+            e = torch.randn(B, self.shape.latent_dim, device=self.device, dtype=torch.float32, generator=self._gen)
+        else:
+            e = torch.as_tensor(eps, dtype=torch.float32, device=self.device).contiguous()
+            if tuple(e.shape) != (B, self.shape.latent_dim):
+                raise ValueError("eps must be [B,%d]" % self.shape.latent_dim)
+        self.opts.kld_weight = float(kld_weight)
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        _capi.check(self.lib.gem_trainer_step(self._t, B, x.data_ptr(), e.data_ptr(), C.byref(self.opts), 1 if update else 0,
+                                              self._losses.data_ptr(), C.c_void_p(s)), self.lib)
+        if update:
+            self.steps += 1
+        if not sync:
+            return self._losses
+        return tuple(float(v) for v in self._losses.cpu())
+
+    # ---- the epoch loop (train.py:65-108) and the evaluation pass (train.py:110-127)
+    def evaluate(self, windows, batch_size=None):
+        """Eval-mode reconstruction MPJPE (train.py:110-127): a WindowEngine with the current weights encodes with the random
+        reparameterisation of ConvVAE.forward and decodes; the mean over batches of the per-batch mean joint distance."""
+        import torch
+        from .engine import WindowEngine
+        bs = int(batch_size or self.batch_size)
+        eng = WindowEngine(self.shape, max_windows=bs, device=self.device.index)
+        try:
+            eng.load_vae(0, self.state_dict())
+            data = torch.as_tensor(np.asarray(windows), dtype=torch.float32)
+            errs = []
+            for i in range(0, data.shape[0], bs):
+                x = data[i:i + bs].to(self.device)
+                e = torch.randn(x.shape[0], self.shape.latent_dim, device=self.device, generator=self._gen)
+                z = eng.encode(0, x, eps=e)[2]
+                rec = eng.decode(0, z)
+                d = (rec.reshape(x.shape[0], self.shape.seq_len, -1, 3) - x.reshape(x.shape[0], self.shape.seq_len, -1, 3)).norm(dim=-1)
+                errs.append(float(d.mean()))
+            return float(np.mean(errs))
+        finally:
+            eng.close()
+
+    def fit(self, train_windows, epochs=20, kl_weight=0.25, test_windows=None, log_step=100, checkpoint_dir=None, seed=0, log=print,
+            args=None):
+        """Train.train(): `epochs` passes over a shuffled, drop_last DataLoader of `train_windows` [n,T,45]."""
+        import torch
+        from .vae import save_checkpoint  # noqa: F401  (same schema; the file below carries train.py's extra keys)
+        data = torch.as_tensor(np.asarray(train_windows), dtype=torch.float32, device=self.device)
+        n, bs = int(data.shape[0]), self.batch_size
+        if n < bs:
+            raise ValueError("the dataset (%d windows) is smaller than one batch (%d): drop_last leaves nothing" % (n, bs))
+        m_n = float(kl_weight) * bs / n
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        running = torch.zeros(3, dtype=torch.float64, device=self.device)
+        count, history = 0, []
+        for e in range(int(epochs)):
+            perm = torch.randperm(n, generator=g).to(self.device)
+            for i in range(n // bs):
+                running += self.step(data[perm[i * bs:(i + 1) * bs]], m_n, sync=False)
+                if count % log_step == 0 and count != 0:
+                    r = running.cpu()
+                    log("running loss is: {}".format(float(r[0])))
+                    log("running recon loss is: {}".format(float(r[1])))
+                    history.append((count, float(r[0]), float(r[1])))
+                    running.zero_()
+                count += 1
+            eval_loss = self.evaluate(test_windows if test_windows is not None else train_windows) if test_windows is not False else None
+            if eval_loss is not None:
+                log("eval loss is: {}".format(eval_loss))
+            if checkpoint_dir is not None:
+                os.makedirs(checkpoint_dir, exist_ok=True)
+                sd = OrderedDict((k, torch.from_numpy(np.array(v))) for k, v in self.state_dict().items())
+                opt = self.optimizer_state()
+                torch.save({"epoch": e + 1, "args": dict(args or {}), "state_dict": sd, "eval_result": eval_loss,
+                            "optimizer": {"step": opt["step"],
+                                          "exp_avg": {k: torch.from_numpy(v) for k, v in opt["exp_avg"].items()},
+                                          "exp_avg_sq": {k: torch.from_numpy(v) for k, v in opt["exp_avg_sq"].items()}}},
+                           os.path.join(checkpoint_dir, str(e) + ".pth.tar"))
+        return history

@@ -222,6 +222,45 @@ int gem_profile_read(gem_handle* h, int family, double* total_ms, int64_t* n_lau
  * buf_len - 1 characters).  bench.py labels its roofline objects with this, so that the label is the kernel that actually ran. */
 int gem_profile_kernels(gem_handle* h, int family, char* buf, int buf_len);
 
+/* ---- VAE training on the device: the loop body of networks/train.py:65-108 ----
+ * One gem_trainer_step = model.train() forward (BatchNorm1d batch statistics; running statistics updated with `bn_momentum`,
+ * unbiased variance), ConvVAE.loss_function (networks/models/SeqConvVAE.py:191-219: F.mse_loss(recons, input) + kld_weight *
+ * mean_b(-0.5 * sum_d(1 + logvar - mu^2 - exp(logvar))), `kld_weight` being train.py:89's M_N), loss.backward() and -- when
+ * `update` is non-zero -- one torch.optim.Adam step (train.py:60: lr, betas, eps, L2 weight_decay added to the gradient).
+ *
+ * Parameters, gradients and both Adam moments are fp32 arenas of `n_params` floats in the packed device layout; running
+ * statistics an arena of `n_stats` floats.  Arena order (every width padded to a multiple of 64, padding zero):
+ *   encoder block i:  W [3][N][K] (Conv1d weight[n][k][tap] at [tap][n][k]), bias [N], BN gamma [N], BN beta [N]
+ *   fc_mu | fc_var:   W [2*Dp][T*topp] (row d = fc_mu d, row Dp + d = fc_var d; column t*topp + c = flattened feature c*T + t),
+ *                     bias [2*Dp]
+ *   decoder_input:    W [T*topp][Dp] (row t*topp + c = output feature c*T + t), bias [T*topp]
+ *   decoder block i:  W [3][N][K] = the equivalent Conv1d taps of ConvTranspose1d(k=3,s=1,p=1): weight[k][n][2-tap] at
+ *                     [tap][n][k]; bias, gamma, beta (the final Conv1d has no BatchNorm: W, bias only)
+ *   statistics:       per BatchNorm layer in the same order: running_mean [N], running_var [N]
+ * globalegomocap_amd/vae_train.py converts between this and the checkpoint schema of the reference.
+ *
+ *   d_pose    [B,T,3J] f32 device   the batch (train.py:82 after the float() cast)
+ *   d_eps     [B,D]    f32 device   the reparameterisation noise (torch.randn_like at SeqConvVAE.py:167)
+ *   d_losses  [3]      f64 device   loss, Reconstruction_Loss, KLD (may be NULL)
+ * 2 <= B <= cfg.max_windows.  Everything is enqueued on `stream`; nothing synchronises. */
+typedef struct gem_trainer gem_trainer;
+typedef struct gem_train_opts {
+    double  lr, beta1, beta2, eps, weight_decay;   /* torch.optim.Adam: 1e-3, 0.9, 0.999, 1e-8, train.py's --weight_decay */
+    double  kld_weight;                            /* M_N = kl_weight * batch / len(dataset) (train.py:89) */
+    double  bn_momentum;                           /* 0.1 */
+    int32_t recon_sum;                             /* 0: F.mse_loss mean (the reference); 1: summed squared error */
+    int32_t reserved;
+} gem_train_opts;
+int  gem_trainer_create(const gem_config* cfg, gem_trainer** out);
+void gem_trainer_destroy(gem_trainer* t);
+int  gem_trainer_sizes(gem_trainer* t, int64_t* n_params, int64_t* n_stats);
+/* what: 0 parameters (resets the Adam step count), 1 gradients (download only), 2 running statistics, 3 / 4 Adam moments */
+int  gem_trainer_upload(gem_trainer* t, int what, const float* h_src, int64_t n);
+int  gem_trainer_download(gem_trainer* t, int what, float* h_dst, int64_t n);
+int  gem_trainer_set_step(gem_trainer* t, int64_t step);
+int  gem_trainer_step(gem_trainer* t, int B, const float* d_pose, const float* d_eps, const gem_train_opts* opts, int update,
+                      double* d_losses, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -114,3 +114,35 @@ class WindowOptimizerPort:
             out = self.net.to_pose(z)[0].numpy().astype(np.float32)
         return out, {"n_iter": st["n_iter"], "func_evals": st["func_evals"], "trace": trace,
                      "z0": z0.numpy()[0], "z": z.detach().numpy()[0]}
+
+
+class TrainPort:
+    """The training step of networks/train.py:77-83 with ConvVAE.loss_function (SeqConvVAE.py:191-219) restated on MotionVAE:
+    train-mode forward with the noise handed in, loss (form "M_N": mean-squared error + w * KLD; "kl_weight": summed squared
+    error + w * KLD), backward, torch.optim.Adam(lr, weight_decay).  Pinned to the reference's own run by
+    tests/golden/train_tiny.npz (tests/test_oracle_golden.py)."""
+
+    def __init__(self, sd, lr=1e-4, weight_decay=0.0, seq_len=10):
+        self.net = vae_from_state_dict(sd, seq_len).train()
+        self.opt = torch.optim.Adam(params=self.net.parameters(), lr=lr, weight_decay=weight_decay)
+
+    def step(self, poses, eps, w, form="M_N", update=True):
+        x = torch.as_tensor(np.asarray(poses), dtype=torch.float32)
+        eps = torch.as_tensor(np.asarray(eps), dtype=torch.float32)
+        self.opt.zero_grad()
+        mu, logvar = self.net.moments(x)
+        z = eps * torch.exp(0.5 * logvar) + mu
+        rec = self.net.decode_raw(z).permute(0, 2, 1)
+        recon = F.mse_loss(rec, x) if form == "M_N" else F.mse_loss(rec, x, reduction="sum")
+        kld = torch.mean(-0.5 * torch.sum(1 + logvar - mu ** 2 - logvar.exp(), dim=1), dim=0)
+        loss = recon + w * kld
+        loss.backward()
+        if update:
+            self.opt.step()
+        return loss.item(), recon.item(), kld.item()
+
+    def gradients(self):
+        return OrderedDict((k, p.grad.detach().numpy().copy()) for k, p in self.net.named_parameters())
+
+    def state_dict(self):
+        return OrderedDict((k, v.detach().numpy().copy()) for k, v in self.net.state_dict().items() if not k.endswith("num_batches_tracked"))

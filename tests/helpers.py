@@ -75,3 +75,19 @@ def oracle_stage_losses(vae, cam, w, pose, heat, mean_bone, eps, opt=None):
         return f, O.decode_backward(vae, dX[None], acts)[0]
     z, stats = O.lbfgs_strong_wolfe(fun, z0, opt)
     return O.decode(vae, z[None])[0].astype(np.float32), stats, np.array(losses)
+
+
+def train_golden_case(g, name):
+    """One case of tests/golden/train_tiny.npz (oracle/make_golden_train.py): shape, regenerated initial weights, batches, noise,
+    hyper-parameters and the reference's results."""
+    from globalegomocap_amd.vae_train import initial_state_dict
+    meta = g[name + "/meta"]
+    batch, steps, latent, init_seed = (int(v) for v in meta[:4])
+    shape = vae_schema.VAEShape(latent_dim=latent, hidden=tuple(int(v) for v in meta[5:]))
+    init = initial_state_dict(shape, init_seed)
+    assert vae_schema.state_dict_sha256(init, shape) == str(g[name + "/init_sha256"])
+    lr, wd, w, summed = (float(v) for v in g[name + "/hyper"])
+    return dict(shape=shape, init=init, batch=batch, steps=steps, poses=g[name + "/poses"], eps=g[name + "/eps"], lr=lr, wd=wd, w=w,
+                form="kl_weight" if summed else "M_N", losses=g[name + "/losses"], grad0=sd_from_npz(g, name + "/grad0/"),
+                final=sd_from_npz(g, name + "/final/"), exp_avg=sd_from_npz(g, name + "/exp_avg/"),
+                exp_avg_sq=sd_from_npz(g, name + "/exp_avg_sq/"))

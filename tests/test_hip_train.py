@@ -1,0 +1,136 @@
+"""the VAE training step on the device (gem_trainer_*, csrc/train.hip) against the unmodified
+reference's own steps (tests/golden/train_tiny.npz) and against the CPU port (oracle/torch_port.TrainPort) at full size."""
+import os
+
+import numpy as np
+import pytest
+
+from globalegomocap_amd import synth, vae as vae_schema
+from helpers import FULL, train_golden_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, rtol, scale_atol, msg):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=scale_atol * max(1e-30, float(np.abs(b).max())), err_msg=msg)
+
+
+@pytest.mark.parametrize("case", ["mn", "sum"])
+def test_training_steps_against_the_reference_run(golden, case):
+    from globalegomocap_amd.vae_train import VAETrainer
+    c = train_golden_case(golden("train_tiny"), case)
+    tr = VAETrainer(c["shape"], batch_size=c["batch"], lr=c["lr"], weight_decay=c["wd"], state_dict=c["init"],
+                    recon_reduction="sum" if c["form"] == "kl_weight" else "mean")
+    try:
+        for s in range(c["steps"]):
+            out = tr.step(c["poses"][s], c["w"], eps=c["eps"][s])
+            np.testing.assert_allclose(out, c["losses"][s], rtol=5e-5)
+            if s == 0:
+                g = tr.gradients()
+                assert set(g) == set(c["grad0"])
+                gmax = max(float(np.abs(v).max()) for v in c["grad0"].values())
+                for k, v in g.items():
+                    r = c["grad0"][k]
+                    # (".0.bias": a conv bias in front of a BatchNorm -- its exact gradient is zero, both sides hold rounding noise)
+                    lim = 5e-6 * gmax if k.endswith(".0.bias") else 1e-4 * np.abs(r).max() + 2e-7 * gmax
+                    assert np.abs(np.asarray(v, np.float64) - r).max() <= lim, k
+        sd = tr.state_dict()
+        assert int(sd["encoder.0.1.num_batches_tracked"]) == c["steps"]
+        # The bias of a conv that feeds a BatchNorm has an exactly zero gradient (the batch mean is subtracted): what torch and the
+        # kernels hold there is rounding noise of the size 1e-9, which Adam's normalisation turns into steps of the size lr in either (in opposite
+        # directions at worst, and a step after a sign flip can exceed lr: hence 4 lr per step).
+        # (and the running mean of that BatchNorm follows the bias)
+        noise = lambda k: k.endswith(".0.bias") or k.endswith("running_mean")        # noqa: E731
+        for k, v in c["final"].items():
+            d = np.abs(np.asarray(sd[k], np.float64) - v).max()
+            assert d <= (4 * c["steps"] * c["lr"] if noise(k) else 1e-5 + 0.02 * c["lr"]), (k, d)
+        opt = tr.optimizer_state()
+        assert opt["step"] == c["steps"]
+        for k, v in c["exp_avg"].items():
+            if not noise(k):
+                _close(opt["exp_avg"][k], v, 2e-3, 1e-4, "exp_avg " + k)
+                _close(opt["exp_avg_sq"][k], c["exp_avg_sq"][k], 4e-3, 2e-4, "exp_avg_sq " + k)
+    finally:
+        tr.close()
+
+
+def test_full_size_training_step_against_the_port():
+    import torch
+    from globalegomocap_amd.vae_train import VAETrainer, initial_state_dict
+    from oracle.torch_port import TrainPort
+    B = 24
+    init = initial_state_dict(FULL, 11)
+    poses = synth.make_training_windows(2 * B, FULL.seq_len, 3).reshape(2, B, FULL.seq_len, 45)
+    eps = np.random.default_rng(1).standard_normal((2, B, FULL.latent_dim)).astype(np.float32)
+    port = TrainPort(init, lr=1e-4, weight_decay=1e-5)
+    tr = VAETrainer(FULL, batch_size=64, lr=1e-4, weight_decay=1e-5, state_dict=init)
+    try:
+        for s in range(2):
+            ref = port.step(poses[s], eps[s], 0.25 * B / 1000.0)
+            out = tr.step(poses[s], 0.25 * B / 1000.0, eps=eps[s])
+            np.testing.assert_allclose(out, ref, rtol=1e-4)
+            g, gr = tr.gradients(), port.gradients()
+            gmax = max(float(np.abs(v).max()) for v in gr.values())
+            for k, v in gr.items():
+                d = np.abs(np.asarray(g[k], np.float64) - v).max()
+                assert d <= (5e-6 * gmax if k.endswith(".0.bias") else 1e-3 * np.abs(v).max() + 1e-6 * gmax), (s, k, d, np.abs(v).max())
+        sd, sr = tr.state_dict(), port.state_dict()
+        for k, v in sr.items():
+            d = np.abs(np.asarray(sd[k], np.float64) - v).max()
+            if k.endswith("running_var"):
+                assert d <= 1e-5 * max(1.0, np.abs(v).max()), (k, d)
+            elif k.endswith(".0.bias") or k.endswith("running_mean"):              # zero-gradient biases in front of a BatchNorm: Adam amplifies rounding noise
+                assert d <= 4 * 2 * 1e-4, (k, d)
+            else:
+                # after two Adam steps an entry has moved by at most 2 lr; entries whose gradient is far above rounding agree closely
+                assert d <= 2 * 1e-4 * 1.01 and np.mean(np.abs(np.asarray(sd[k], np.float64) - v) > 0.05 * 1e-4) < 1e-3, (k, d)
+    finally:
+        tr.close()
+
+
+def test_fit_lowers_the_loss_and_writes_the_reference_checkpoint_schema(tmp_path):
+    import torch
+    from globalegomocap_amd.engine import WindowEngine
+    from globalegomocap_amd.vae_train import VAETrainer
+    shape = vae_schema.VAEShape(latent_dim=64, hidden=(32, 64))
+    data = synth.make_training_windows(640, shape.seq_len, 1)
+    tr = VAETrainer(shape, batch_size=64, lr=2e-3, seed=2)
+    try:
+        lines = []
+        first = tr.step(data[:64], 1e-3, update=False)
+        hist = tr.fit(data, epochs=6, kl_weight=0.01, log_step=20, checkpoint_dir=str(tmp_path), log=lines.append)
+        last = tr.step(data[:64], 1e-3, update=False)
+        assert last[1] < 0.5 * first[1], (first, last)
+        assert len(hist) == 2 and hist[1][2] < hist[0][2]           # 60 steps, logged at counts 20 and 40 like train.py:88-95
+        assert any(l.startswith("eval loss is: ") for l in lines)
+        ck = torch.load(os.path.join(str(tmp_path), "5.pth.tar"), map_location="cpu", weights_only=False)
+        assert ck["epoch"] == 6 and ck["eval_result"] > 0
+        keys = [k for k in ck["state_dict"] if not k.endswith("num_batches_tracked")]
+        assert keys == list(shape.schema())
+        # the checkpoint loads into the optimiser's engine (optimizer.py:59-60) and reconstructs like the trainer's eval pass
+        eng = WindowEngine(shape, max_windows=64)
+        eng.load_vae(0, ck["state_dict"])
+        x = torch.as_tensor(data[:64])
+        rec = eng.decode(0, eng.encode(0, x)[0]).cpu()
+        err = (rec - x.reshape(64, shape.seq_len, 15, 3)).norm(dim=-1).mean().item()
+        assert abs(err - ck["eval_result"]) < 0.5 * ck["eval_result"] + 0.02
+        eng.close()
+    finally:
+        tr.close()
+
+
+def test_trainer_rejects_bad_arguments():
+    from globalegomocap_amd import _capi
+    from globalegomocap_amd.vae_train import VAETrainer
+    shape = vae_schema.VAEShape(latent_dim=64, hidden=(32, 64))
+    tr = VAETrainer(shape, batch_size=8)
+    try:
+        with pytest.raises(_capi.GemError, match="max_windows"):
+            tr.step(np.zeros((9, 10, 45), np.float32), 0.1)
+        with pytest.raises(_capi.GemError, match="BatchNorm"):
+            tr.step(np.zeros((1, 10, 45), np.float32), 0.1)
+        with pytest.raises(ValueError):
+            tr.step(np.zeros((4, 10, 44), np.float32), 0.1)
+    finally:
+        tr.close()

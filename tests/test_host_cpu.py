@@ -216,3 +216,33 @@ def test_slam_trajectory_conversion_against_reference_golden(golden):
         np.testing.assert_allclose(mats[i][:3, 3], 1.8 * rt[i], rtol=1e-9, atol=1e-12)
         np.testing.assert_allclose(mats[i][:3, :3], slam.pose_matrix(rt[i], rq[i])[:3, :3], atol=1e-12)
     np.testing.assert_allclose(gt[:, 0] @ R1 / 1.8 + t1, head, atol=1e-9)
+
+
+def test_trainer_arena_layout_roundtrip_and_padding():
+    """vae_train.pack_arena / unpack_arena: the reference's checkpoint schema <-> the packed device arena of gem_trainer."""
+    from globalegomocap_amd import vae as vae_schema
+    from globalegomocap_amd.vae_train import arena_layout, pack_arena, unpack_arena, initial_state_dict
+    shape = vae_schema.VAEShape(latent_dim=40, hidden=(24, 40, 72))
+    sd = vae_schema.synthetic_state_dict(shape, 5)
+    P, S = pack_arena(sd, shape)
+    items, n, stats, ns = arena_layout(shape)
+    assert (P.size, S.size) == (n, ns)
+    back = unpack_arena(P, shape, S)
+    assert list(back) == list(shape.schema())
+    for k in shape.schema():
+        assert np.array_equal(back[k], np.asarray(sd[k], np.float32)), k
+    # everything outside the real entries is zero (statistics: variance 1), so padded channels stay inert
+    real = sum(int(np.prod(s)) for k, s in shape.schema().items() if "running" not in k)
+    assert np.count_nonzero(P) <= real
+    # conv taps: encoder Conv1d weight[n][k][tap] at [tap][n][k]; decoder ConvTranspose1d weight[k][n][2 - tap] at [tap][n][k]
+    key, kind, off, (N, K, co, ci) = items[0]
+    W = P[off:off + 3 * N * K].reshape(3, N, K)
+    assert kind == "conv" and W[2, 5, 7] == np.float32(sd[key][5, 7, 2])
+    key, kind, off, (N, K, co, ci) = [i for i in items if i[1] == "convT"][0]
+    W = P[off:off + 3 * N * K].reshape(3, N, K)
+    assert W[0, 3, 9] == np.float32(sd[key][9, 3, 2])
+    # torch's default initialisation bounds (1/sqrt(fan_in)), BatchNorm at identity
+    init = initial_state_dict(shape, 0)
+    assert np.abs(init["encoder.0.0.weight"]).max() <= 1 / np.sqrt(45 * 3) and np.abs(init["fc_mu.bias"]).max() <= 1 / np.sqrt(72 * 10)
+    assert np.abs(init["decoder.0.0.weight"]).max() <= 1 / np.sqrt(40 * 3)          # ConvTranspose1d [72, 40, 3]: fan_in = 40 * 3
+    assert np.all(init["encoder.1.1.weight"] == 1) and np.all(init["encoder.1.1.running_var"] == 1)

@@ -312,3 +312,22 @@ def test_full_size_main_numpy_oracle_matches_reference(golden):
     assert np.linalg.norm(res["opt"] - g["opt_smooth"], axis=-1).mean() < 0.5e-3
     mp = np.linalg.norm(res["opt"] - res["gt"], axis=-1).mean()
     assert abs(mp - float(g["err_smooth/optimized_global_mpjpe"])) < 0.1e-3
+
+
+@pytest.mark.parametrize("case", ["mn", "sum"])
+def test_training_step_port_against_the_reference_run(golden, case):
+    """oracle/torch_port.TrainPort = networks/train.py:77-83 restated; pinned to the unmodified reference's own steps."""
+    import torch
+    from oracle.torch_port import TrainPort
+    from helpers import train_golden_case
+    torch.set_num_threads(1)
+    c = train_golden_case(golden("train_tiny"), case)
+    port = TrainPort(c["init"], lr=c["lr"], weight_decay=c["wd"])
+    for s in range(c["steps"]):
+        out = port.step(c["poses"][s], c["eps"][s], c["w"], form=c["form"])
+        np.testing.assert_allclose(out, c["losses"][s], rtol=2e-5)
+        if s == 0:
+            for k, v in port.gradients().items():
+                np.testing.assert_allclose(v, c["grad0"][k], rtol=1e-4, atol=1e-6 * max(1.0, float(np.abs(c["grad0"][k]).max())), err_msg=k)
+    for k, v in port.state_dict().items():
+        np.testing.assert_allclose(v, c["final"][k], rtol=1e-4, atol=2e-6, err_msg=k)
