@@ -708,6 +708,46 @@ def main():
             lift = {"frames": int(n_frames), "ms": round(ms, 4), "heatmap_bytes": int(nbytes),
                     "achieved_GBps": round(nbytes / ms / 1e6, 1), "frac_of_hbm_peak": round(nbytes / ms / 1e6 / PEAK_HBM_GBPS, 4),
                     "note": "incl. the f32/f64 output allocation of the Python wrapper; kernel-only time is in profiles/"}
+        train = None
+        if not a.no_extra and world == 1:
+            # one training step of the full-size VAE (networks/train.py:77-83 at the reference's default batch of 64):
+            # train-mode forward, loss, backward incl. weight gradients, Adam -- all on the device, against the torch-CPU port
+            from globalegomocap_amd import synth as synth_mod
+            from globalegomocap_amd.vae_train import VAETrainer, initial_state_dict
+            from oracle.torch_port import TrainPort
+            tb = 64
+            init = initial_state_dict(shape, 0)
+            tw = synth_mod.make_training_windows(tb, shape.seq_len, 0)
+            te = np.random.default_rng(0).standard_normal((tb, shape.latent_dim)).astype(np.float32)
+            trn = VAETrainer(shape, batch_size=tb, lr=1e-4, state_dict=init)
+            tw_d, te_d = torch.as_tensor(tw, device=device), torch.as_tensor(te, device=device)
+            for _ in range(3):
+                trn.step(tw_d, 0.01, eps=te_d, sync=False)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                trn.step(tw_d, 0.01, eps=te_d, sync=False)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 20
+            n_par = trn.n_params
+            trn.close()
+            nthreads = torch.get_num_threads()
+            port = TrainPort(init, lr=1e-4)
+            port.step(tw, te, 0.01)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                port.step(tw, te, 0.01)
+            cpu_ms = (time.perf_counter() - t0) / 3 * 1e3
+            # algorithmic HBM bytes of a step: Adam reads p, g, m, v and writes p, m, v; forward and backward-data read every weight
+            # once each; the weight gradients are written once (activations are small beside the 130 MB arena at this batch)
+            alg_bytes = n_par * 4 * (7 + 2 + 1)
+            train = {"batch": tb, "ms_per_step": round(ms, 4), "windows_per_s": round(tb / ms * 1e3, 1), "parameters_padded": int(n_par),
+                     "algorithmic_bytes_per_step": int(alg_bytes), "achieved_GBps": round(alg_bytes / ms / 1e6, 1),
+                     "frac_of_hbm_peak": round(alg_bytes / ms / 1e6 / PEAK_HBM_GBPS, 4),
+                     "cpu_port_ms_per_step": round(cpu_ms, 1), "cpu_cores": int(nthreads),
+                     "note": "fp32; torch-CPU port = oracle/torch_port.TrainPort (autograd + torch.optim.Adam), 3 steps"}
         total_windows = B * world * a.steps
         line = {
             "metric": "optimised windows/sec (10-frame, 15-joint)",
@@ -733,6 +773,7 @@ def main():
             "mpjpe_mm": {"input": round(mp_in * 1e3, 3), "optimised": round(mp_opt * 1e3, 3)},
             "post": post,
             "lift": lift,
+            "train": train,
             "roofline": roof,
             "roofline_other": roof_other,
             "cpu_baseline": cpu,

@@ -7,11 +7,12 @@
 // Conv1d taps [3][N][K], k contiguous; fc_mu | fc_var stacked; decoder_input time-major), with same-shaped arenas for gradient
 // and the two Adam moments; the reference's checkpoint schema is a permutation of that arena (host side: vae_train.py).  Padded
 // entries are zero and stay zero (their gradients are sums over zero activations).
-//   forward / backward-DATA products: the fp32 MFMA kernels of the optimiser (launch_gemm; adjoint weight images are re-packed
-//     from the arena every step)
+//   forward / backward-DATA products: the fp32 MFMA kernels of the optimiser (launch_gemm); the adjoint weight images of ALL
+//     layers are re-packed from the arena by ONE launch at the start of a step (adjoint_all_kernel, 64x64 tiles through LDS)
 //   weight gradients: gemm_tn_kernel, dW[tap][n][k] = sum_r dC[r][n] * A[r + tap - 1][k] (contraction over the ROWS, both
-//     operands row-major: staged through LDS, v_mfma_f32_16x16x4_f32), row range cut into slabs, summed in slab order
-//   BatchNorm (+ LeakyReLU) forward / backward, bias gradients, the latent / loss gradients, Adam: one small kernel each
+//     operands row-major: staged through LDS, v_mfma_f32_16x16x4_f32), row range cut into slabs of 64 rows (conv layers: small
+//     tensors, many rows) that ONE launch sums in slab order for all layers before Adam (slab_sum_all_kernel)
+//   BatchNorm (+ LeakyReLU) forward / backward (incl. the conv bias gradient), the latent / loss gradients, Adam: one kernel each
 // Everything is enqueued on the caller's stream; no host synchronisation inside a step.
 #include <algorithm>
 #include <cmath>
@@ -30,11 +31,17 @@ struct TrainConv {
     size_t ow = 0, ob = 0, og = 0, obe = 0;     // arena offsets: weight [3][N][K], bias [N], gamma [N], beta [N]
     size_t os = 0;                 // statistics arena: running_mean [N], running_var [N]
     float *Y = nullptr, *out = nullptr, *mean = nullptr, *invstd = nullptr;
+    float *adj = nullptr, *slab = nullptr;      // adjoint image [3][K][N]; weight-gradient slabs [nslab][3][N][K]
 };
 struct TrainLinear {
     int K = 0, N = 0;
     size_t ow = 0, ob = 0;
+    float *adj = nullptr, *slab = nullptr;
 };
+struct AdjDesc { const float* W; float* out; int taps, N, K, tiles; };
+struct SumDesc { const float* slab; float* out; unsigned long long n; };
+constexpr int TN_ROWS_CONV = 64, TN_ROWS_LINEAR = 256;     // rows per weight-gradient slab
+constexpr int LOSS_BLOCK = 1024;
 
 }  // namespace gem
 
@@ -47,36 +54,77 @@ struct gem_trainer {
     size_t n_params = 0, n_stats = 0;
     float *P = nullptr, *G = nullptr, *M1 = nullptr, *M2 = nullptr, *S = nullptr;
     float *pose_p = nullptr, *mulv = nullptr, *z = nullptr, *h0 = nullptr, *Xp = nullptr;
-    float *gA = nullptr, *gB = nullptr, *dmulv = nullptr, *dz = nullptr, *adj = nullptr, *slab = nullptr;
-    double* red = nullptr;         // [8]: recon sum, kld sum, ...
-    size_t slab_elems = 0, adj_elems = 0;
+    float *gA = nullptr, *gB = nullptr, *dmulv = nullptr, *dz = nullptr;
+    double* red = nullptr;         // [8 + partial sums]: [4..6] loss, recon, kld; [8..) per-block partials of the two loss kernels
+    gem::AdjDesc* adj_tab = nullptr; int n_adj = 0, adj_tiles = 0;
+    gem::SumDesc* sum_tab = nullptr; int n_sum = 0; size_t sum_max = 0;
+    int part_recon = 0, part_latent = 0;       // capacity of the partial-sum regions
     long step = 0;
     std::vector<void*> allocs;
 };
 
 namespace gem {
 
-// ---- BatchNorm1d (training mode) + LeakyReLU over [rows, N]: one workgroup per 16 channels, 16 row groups -------------------
-__global__ __launch_bounds__(256) void bn_train_fwd_kernel(const float* __restrict__ Y, int rows, int N, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
-                                                           float* __restrict__ mean_out, float* __restrict__ invstd_out, float* __restrict__ out,
-                                                           float momentum, float eps) {
+// ---- BatchNorm1d (training mode) + LeakyReLU over [rows, N]: one workgroup per 16 channels, BN_GROUPS row groups -------------
+// A thread owns channel c = lane & 15 of the rows g, g + 64, ...; up to BN_REGS of them live in registers, so that the statistics
+// and the normalisation need ONE trip to memory (rows <= 1024, i.e. batches up to 102 windows); longer inputs loop.
+constexpr int BN_GROUPS = 64, BN_THREADS = 16 * BN_GROUPS, BN_REGS = 16;
+// column sums of NV per-thread values over the row groups of a workgroup: lanes of a wave that share a channel first (4 row
+// groups per wave), then the 16 waves through LDS; every thread returns the totals of its channel
+template <int NV>
+__device__ __forceinline__ void bn_reduce(double (&v)[NV], double (*sh)[16][17]) {
+    const int ch = threadIdx.x & 15, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i] += __shfl_xor(v[i], 16);
+        v[i] += __shfl_xor(v[i], 32);
+        if ((threadIdx.x & 48) == 0) sh[i][wave][ch] = v[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s += sh[i][j][ch];
+        v[i] = s;
+    }
+    __syncthreads();
+}
+template <bool IN_REGS>
+__global__ __launch_bounds__(BN_THREADS) void bn_train_fwd_kernel(const float* __restrict__ Y, int rows, int N, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
+                                                                  float* __restrict__ mean_out, float* __restrict__ invstd_out, float* __restrict__ out,
+                                                                  float momentum, float eps) {
     __shared__ double sh[2][16][17];
     const int c = blockIdx.x * 16 + (threadIdx.x & 15), g = threadIdx.x >> 4;
-    double s = 0.0, q = 0.0;
-    for (int r = g; r < rows; r += 16) { const double v = Y[(size_t)r * N + c]; s += v; q += v * v; }
-    sh[0][g][threadIdx.x & 15] = s; sh[1][g][threadIdx.x & 15] = q;
-    __syncthreads();
-    s = 0.0; q = 0.0;
-    for (int i = 0; i < 16; ++i) { s += sh[0][i][threadIdx.x & 15]; q += sh[1][i][threadIdx.x & 15]; }
-    const double mean = s / rows;
-    double var = q / rows - mean * mean;                 // biased (what normalises the batch)
+    float y[BN_REGS];
+    double v[2] = {0.0, 0.0};
+    if (IN_REGS) {
+#pragma unroll
+        for (int j = 0; j < BN_REGS; ++j) { const int r = g + j * BN_GROUPS; y[j] = r < rows ? Y[(size_t)r * N + c] : 0.f; }
+#pragma unroll
+        for (int j = 0; j < BN_REGS; ++j) { v[0] += (double)y[j]; v[1] += (double)y[j] * y[j]; }
+    } else {
+        for (int r = g; r < rows; r += BN_GROUPS) { const double q = Y[(size_t)r * N + c]; v[0] += q; v[1] += q * q; }
+    }
+    bn_reduce<2>(v, sh);
+    const double mean = v[0] / rows;
+    double var = v[1] / rows - mean * mean;                 // biased (what normalises the batch)
     if (var < 0.0) var = 0.0;
     const float invstd = (float)(1.0 / sqrt(var + (double)eps)), mf = (float)mean;
     const float ga = gamma[c], be = beta[c];
-    for (int r = g; r < rows; r += 16) {
-        const float v = ga * ((Y[(size_t)r * N + c] - mf) * invstd) + be;
-        out[(size_t)r * N + c] = v > 0.f ? v : v * LEAKY_SLOPE;
+    if (IN_REGS) {
+#pragma unroll
+        for (int j = 0; j < BN_REGS; ++j) {
+            const int r = g + j * BN_GROUPS;
+            const float o = ga * ((y[j] - mf) * invstd) + be;
+            if (r < rows) out[(size_t)r * N + c] = o > 0.f ? o : o * LEAKY_SLOPE;
+        }
+    } else {
+        for (int r = g; r < rows; r += BN_GROUPS) {
+            const float o = ga * ((Y[(size_t)r * N + c] - mf) * invstd) + be;
+            out[(size_t)r * N + c] = o > 0.f ? o : o * LEAKY_SLOPE;
+        }
     }
     if (g == 0) {
         mean_out[c] = mf; invstd_out[c] = invstd;
@@ -86,46 +134,68 @@ __global__ __launch_bounds__(256) void bn_train_fwd_kernel(const float* __restri
     }
 }
 
-// dOut (w.r.t. the block's output) -> dY (w.r.t. the conv output), dgamma, dbeta.  LeakyReLU' from the sign of the output.
-__global__ __launch_bounds__(256) void bn_train_bwd_kernel(const float* __restrict__ dOut, const float* __restrict__ out, const float* __restrict__ Y,
-                                                           int rows, int N, const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                           const float* __restrict__ invstd, float* __restrict__ dY, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta) {
+// dOut (w.r.t. the block's output) -> dY (w.r.t. the conv output), dgamma, dbeta, and the conv's bias gradient sum_r dY (zero up
+// to rounding -- the batch mean is subtracted --, computed the way autograd does).  LeakyReLU' from the sign of the output.
+template <bool IN_REGS>
+__global__ __launch_bounds__(BN_THREADS) void bn_train_bwd_kernel(const float* __restrict__ dOut, const float* __restrict__ out,
+                                                                  const float* __restrict__ Y, int rows, int N, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                  float* __restrict__ dY, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                  float* __restrict__ dbias) {
     __shared__ double sh[2][16][17];
     const int c = blockIdx.x * 16 + (threadIdx.x & 15), g = threadIdx.x >> 4;
     const float mf = mean[c], is = invstd[c], ga = gamma[c];
-    double sb = 0.0, sg = 0.0;
-    for (int r = g; r < rows; r += 16) {
-        const size_t i = (size_t)r * N + c;
-        const float dzv = dOut[i] * (out[i] > 0.f ? 1.f : LEAKY_SLOPE);
-        sb += dzv; sg += (double)dzv * ((Y[i] - mf) * is);
+    float dzv[BN_REGS], xh[BN_REGS];
+    double v[2] = {0.0, 0.0};
+    if (IN_REGS) {
+#pragma unroll
+        for (int j = 0; j < BN_REGS; ++j) {
+            const int r = g + j * BN_GROUPS;
+            const size_t i = (size_t)r * N + c;
+            const bool ok = r < rows;
+            const float d = ok ? dOut[i] : 0.f, o = ok ? out[i] : 0.f, yy = ok ? Y[i] : mf;
+            dzv[j] = d * (o > 0.f ? 1.f : LEAKY_SLOPE);
+            xh[j] = (yy - mf) * is;
+        }
+#pragma unroll
+        for (int j = 0; j < BN_REGS; ++j) { v[0] += dzv[j]; v[1] += (double)dzv[j] * xh[j]; }
+    } else {
+        for (int r = g; r < rows; r += BN_GROUPS) {
+            const size_t i = (size_t)r * N + c;
+            const float d = dOut[i] * (out[i] > 0.f ? 1.f : LEAKY_SLOPE);
+            v[0] += d; v[1] += (double)d * ((Y[i] - mf) * is);
+        }
     }
-    sh[0][g][threadIdx.x & 15] = sb; sh[1][g][threadIdx.x & 15] = sg;
-    __syncthreads();
-    sb = 0.0; sg = 0.0;
-    for (int i = 0; i < 16; ++i) { sb += sh[0][i][threadIdx.x & 15]; sg += sh[1][i][threadIdx.x & 15]; }
-    const float mb = (float)(sb / rows), mg = (float)(sg / rows);
-    for (int r = g; r < rows; r += 16) {
-        const size_t i = (size_t)r * N + c;
-        const float dzv = dOut[i] * (out[i] > 0.f ? 1.f : LEAKY_SLOPE);
-        const float xh = (Y[i] - mf) * is;
-        dY[i] = ga * is * (dzv - mb - xh * mg);
+    bn_reduce<2>(v, sh);
+    const float mb = (float)(v[0] / rows), mg = (float)(v[1] / rows);
+    double w[1] = {0.0};
+    if (IN_REGS) {
+#pragma unroll
+        for (int j = 0; j < BN_REGS; ++j) {
+            const int r = g + j * BN_GROUPS;
+            const float d = ga * is * (dzv[j] - mb - xh[j] * mg);
+            if (r < rows) { dY[(size_t)r * N + c] = d; w[0] += d; }
+        }
+    } else {
+        for (int r = g; r < rows; r += BN_GROUPS) {
+            const size_t i = (size_t)r * N + c;
+            const float dz0 = dOut[i] * (out[i] > 0.f ? 1.f : LEAKY_SLOPE);
+            const float d = ga * is * (dz0 - mb - ((Y[i] - mf) * is) * mg);
+            dY[i] = d;
+            w[0] += d;
+        }
     }
-    if (g == 0) { dgamma[c] = (float)sg; dbeta[c] = (float)sb; }
+    bn_reduce<1>(w, sh);
+    if (g == 0) { dgamma[c] = (float)v[1]; dbeta[c] = (float)v[0]; dbias[c] = (float)w[0]; }
 }
 
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dC, int rows, int N, float* __restrict__ out) {
-    __shared__ double sh[16][17];
+__global__ __launch_bounds__(BN_THREADS) void colsum_kernel(const float* __restrict__ dC, int rows, int N, float* __restrict__ out) {
+    __shared__ double sh[1][16][17];
     const int c = blockIdx.x * 16 + (threadIdx.x & 15), g = threadIdx.x >> 4;
-    double s = 0.0;
-    for (int r = g; r < rows; r += 16) s += dC[(size_t)r * N + c];
-    sh[g][threadIdx.x & 15] = s;
-    __syncthreads();
-    if (g == 0) {
-        s = 0.0;
-        for (int i = 0; i < 16; ++i) s += sh[i][threadIdx.x & 15];
-        out[c] = (float)s;
-    }
+    double v[1] = {0.0};
+    for (int r = g; r < rows; r += BN_GROUPS) v[0] += dC[(size_t)r * N + c];
+    bn_reduce<1>(v, sh);
+    if (g == 0) out[c] = (float)v[0];
 }
 
 // ---- weight gradient: dW[tap][n][k] = sum_r dC[r][n] * A[r + tap - 1][k], slab z = rows [z * rps, (z + 1) * rps) --------------
@@ -146,23 +216,32 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int r_begin = z * rps, r_end = min(rows, r_begin + rps);
-    for (int r0 = r_begin; r0 < r_end; r0 += 32) {
+    f32x4 vc[2], va[2];
+    auto fetch = [&](int r0) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int i = tid + u * 256, rl = i >> 4, c4 = (i & 15) * 4;
             const int row = r0 + rl;
-            f32x4 vc = {0.f, 0.f, 0.f, 0.f}, va = {0.f, 0.f, 0.f, 0.f};
+            vc[u] = f32x4{0.f, 0.f, 0.f, 0.f}; va[u] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (row < r_end) {
-                vc = *reinterpret_cast<const f32x4*>(dC + (size_t)row * ldc + n0 + c4);
+                vc[u] = *reinterpret_cast<const f32x4*>(dC + (size_t)row * ldc + n0 + c4);
                 int src = row;
                 bool ok = true;
                 if (TAPS == 3) { const int tt = row % T + tap - 1; ok = tt >= 0 && tt < T; src = row + tap - 1; }
-                if (ok) va = *reinterpret_cast<const f32x4*>(A + (size_t)src * lda + k0 + c4);
+                if (ok) va[u] = *reinterpret_cast<const f32x4*>(A + (size_t)src * lda + k0 + c4);
             }
-            *reinterpret_cast<f32x4*>(&Cs[rl][c4]) = vc;
-            *reinterpret_cast<f32x4*>(&As[rl][c4]) = va;
+        }
+    };
+    fetch(r_begin);
+    for (int r0 = r_begin; r0 < r_end; r0 += 32) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + u * 256, rl = i >> 4, c4 = (i & 15) * 4;
+            *reinterpret_cast<f32x4*>(&Cs[rl][c4]) = vc[u];
+            *reinterpret_cast<f32x4*>(&As[rl][c4]) = va[u];
         }
         __syncthreads();
+        if (r0 + 32 < r_end) fetch(r0 + 32);          // the next 32 rows travel while this block's products run
 #pragma unroll
         for (int kk = 0; kk < 32; kk += 4) {
             float a[2], b[2];
@@ -186,67 +265,90 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
                 out[(size_t)n * K + k] = acc[x][y][e];
             }
 }
-__global__ void slab_sum_kernel(const float* __restrict__ slab, int nslab, size_t n, float* __restrict__ out) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float s = slab[i];
-    for (int zz = 1; zz < nslab; ++zz) s += slab[(size_t)zz * n + i];
-    out[i] = s;
+// G = sum over slabs, in slab order; blockIdx.y = layer (table), blockIdx.x = 1024-element chunk
+__global__ __launch_bounds__(256) void slab_sum_all_kernel(const SumDesc* __restrict__ tab, int nslab) {
+    const SumDesc d = tab[blockIdx.y];
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= d.n) return;
+    f32x4 s = *reinterpret_cast<const f32x4*>(d.slab + i);
+    for (int zz = 1; zz < nslab; ++zz) s += *reinterpret_cast<const f32x4*>(d.slab + (size_t)zz * d.n + i);
+    *reinterpret_cast<f32x4*>(d.out + i) = s;
 }
 
-// adjoint images for the backward-data products: conv [3][N][K] -> [3][K][N] with flipped taps; linear [N][K] -> [K][N]
-__global__ void adjoint_kernel(const float* __restrict__ W, float* __restrict__ out, int taps, int N, int K) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (size_t)taps * N * K) return;
-    const int tap = (int)(i / ((size_t)N * K));
-    const size_t r = i - (size_t)tap * N * K;
-    const int kin = (int)(r / N), o = (int)(r - (size_t)kin * N);      // out[tap][kin][o]
-    out[i] = W[((size_t)(taps - 1 - tap) * N + o) * K + kin];
+// adjoint images for the backward-data products of every layer in one launch: conv [3][N][K] -> [3][K][N] with flipped taps,
+// linear [N][K] -> [K][N]; blockIdx.y = layer (table), blockIdx.x = (tap, 64x64 tile), transposed through LDS
+__global__ __launch_bounds__(256) void adjoint_all_kernel(const AdjDesc* __restrict__ tab) {
+    __shared__ float tile[64][65];
+    const AdjDesc d = tab[blockIdx.y];
+    if ((int)blockIdx.x >= d.tiles) return;
+    const int tk = d.K / 64, per = (d.N / 64) * tk;
+    const int tap = blockIdx.x / per, r = blockIdx.x - tap * per;
+    const int n0 = (r / tk) * 64, k0 = (r - (r / tk) * tk) * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const float* src = d.W + ((size_t)tap * d.N + n0) * d.K + k0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) tile[ty + 4 * j][tx] = src[(size_t)(ty + 4 * j) * d.K + tx];
+    __syncthreads();
+    float* dst = d.out + ((size_t)(d.taps - 1 - tap) * d.K + k0) * d.N + n0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) dst[(size_t)(ty + 4 * j) * d.N + tx] = tile[tx][ty + 4 * j];
 }
 
-// reconstruction loss and its gradient: X, pose-packed [rows, 64]; columns >= C carry nothing
-__global__ __launch_bounds__(1024) void recon_loss_kernel(const float* __restrict__ Xp, const float* __restrict__ pose_p, int rows, int C, float scale,
-                                                          float* __restrict__ dXp, double* __restrict__ red) {
-    __shared__ double sh[16];
-    double s = 0.0;
-    for (size_t i = threadIdx.x; i < (size_t)rows * PAD; i += 1024) {
-        const int c = (int)(i % PAD);
-        float d = 0.f;
-        if (c < C) { d = Xp[i] - pose_p[i]; s += (double)d * d; }
-        dXp[i] = 2.f * scale * d;
-    }
+__device__ __forceinline__ void block_partial(double s, double* out) {
+    __shared__ double sh[LOSS_BLOCK / 64];
     s = wave_sum_dpp(s);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) { double t = 0.0; for (int i = 0; i < 16; ++i) t += sh[i]; red[0] = t; }
+    if (threadIdx.x == 0) { double t = 0.0; for (int i = 0; i < LOSS_BLOCK / 64; ++i) t += sh[i]; *out = t; }
+}
+// reconstruction loss and its gradient: X, pose-packed [rows, 64]; columns >= C carry nothing.  part[blockIdx.x] = this block's sum
+__global__ __launch_bounds__(LOSS_BLOCK) void recon_loss_kernel(const float* __restrict__ Xp, const float* __restrict__ pose_p, int rows, int C,
+                                                                float scale, float* __restrict__ dXp, double* __restrict__ part) {
+    const size_t i = (size_t)blockIdx.x * LOSS_BLOCK + threadIdx.x;
+    double s = 0.0;
+    if (i < (size_t)rows * PAD) {
+        float d = 0.f;
+        if ((int)(i % PAD) < C) { d = Xp[i] - pose_p[i]; s = (double)d * d; }
+        dXp[i] = 2.f * scale * d;
+    }
+    block_partial(s, part + blockIdx.x);
 }
 
 // latent: KL term and the gradient w.r.t. [mu | logvar] from dz (decoder side) + the KL term (SeqConvVAE.py:159-169, 206-213)
-__global__ __launch_bounds__(1024) void latent_bwd_kernel(const float* __restrict__ mulv, const float* __restrict__ eps, const float* __restrict__ dz,
-                                                          int B, int D, int Dp, float kw_over_B, float* __restrict__ dmulv, double* __restrict__ red) {
-    __shared__ double sh[16];
+__global__ __launch_bounds__(LOSS_BLOCK) void latent_bwd_kernel(const float* __restrict__ mulv, const float* __restrict__ eps, const float* __restrict__ dz,
+                                                                int B, int D, int Dp, float kw_over_B, float* __restrict__ dmulv, double* __restrict__ part) {
+    const size_t i = (size_t)blockIdx.x * LOSS_BLOCK + threadIdx.x;
     double s = 0.0;
-    for (size_t i = threadIdx.x; i < (size_t)B * Dp; i += 1024) {
+    if (i < (size_t)B * Dp) {
         const int b = (int)(i / Dp), d = (int)(i - (size_t)b * Dp);
         float dmu = 0.f, dlv = 0.f;
         if (d < D) {
             const float mu = mulv[(size_t)b * 2 * Dp + d], lv = mulv[(size_t)b * 2 * Dp + Dp + d];
             const float ev = expf(lv), g = dz[i];
-            s += (double)(1.f + lv - mu * mu - ev);
+            s = (double)(1.f + lv - mu * mu - ev);
             dmu = g + kw_over_B * mu;
             dlv = g * eps[(size_t)b * D + d] * 0.5f * expf(0.5f * lv) + kw_over_B * 0.5f * (ev - 1.f);
         }
         dmulv[(size_t)b * 2 * Dp + d] = dmu;
         dmulv[(size_t)b * 2 * Dp + Dp + d] = dlv;
     }
-    s = wave_sum_dpp(s);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) { double t = 0.0; for (int i = 0; i < 16; ++i) t += sh[i]; red[1] = -0.5 * t / B; }
+    block_partial(s, part + blockIdx.x);
 }
-__global__ void finish_loss_kernel(double* red, double n_recon, double kld_weight, double* out) {
-    const double recon = red[0] / n_recon;
-    out[0] = recon + kld_weight * red[1]; out[1] = recon; out[2] = red[1];
+// sums the per-block partials in block order: out = [loss, recon, kld]
+__global__ __launch_bounds__(256) void finish_loss_kernel(const double* __restrict__ part_recon, int n_recon_parts, const double* __restrict__ part_latent,
+                                                          int n_latent_parts, double n_recon, double kld_weight, int B, double* __restrict__ out) {
+    __shared__ double sh[2][256];
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < n_recon_parts; i += 256) a += part_recon[i];
+    for (int i = threadIdx.x; i < n_latent_parts; i += 256) b += part_latent[i];
+    sh[0][threadIdx.x] = a; sh[1][threadIdx.x] = b;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a = 0.0; b = 0.0;
+        for (int i = 0; i < 256; ++i) { a += sh[0][i]; b += sh[1][i]; }
+        const double recon = a / n_recon, kld = -0.5 * b / B;
+        out[0] = recon + kld_weight * kld; out[1] = recon; out[2] = kld;
+    }
 }
 
 // torch.optim.Adam (amsgrad off): g += wd * p; m, v moments; p -= lr / bc1 * m / (sqrt(v) / sqrt(bc2) + eps)
@@ -271,27 +373,15 @@ static int talloc(gem_trainer* t, T** p, size_t n) {
     return 0;
 }
 
-static Layer conv_layer(gem_trainer* t, const TrainConv& c) {
-    Layer L; L.taps = 3; L.K = c.K; L.N = c.N; L.w = t->P + c.ow; L.bias = t->P + c.ob; return L;
-}
-
-// weight gradient of a layer (TAPS taps) into G at `og`: slabs over the row range, summed in order
+// weight gradient of a layer (TAPS taps): slabs of `rps` rows into the layer's slab region (summed into G later by
+// slab_sum_all_kernel), or -- a single slab -- straight into G at `og`
 template <int TAPS>
-static int weight_grad(gem_trainer* t, const float* dC, int ldc, const float* A, int lda, int rows, int N, int K, size_t og, hipStream_t s) {
-    const int rps = 256, nslab = (rows + rps - 1) / rps;
-    const size_t n = (size_t)TAPS * N * K;
-    if (nslab > 1 && n * nslab > t->slab_elems) { set_error("train: weight-gradient scratch too small"); return 1; }
+static int weight_grad(gem_trainer* t, const float* dC, int ldc, const float* A, int lda, int rows, int N, int K, size_t og, float* slab, int rps,
+                       hipStream_t s) {
+    const int nslab = (rows + rps - 1) / rps;
+    if (nslab > 1 && !slab) { set_error("train: weight-gradient slabs missing"); return 1; }
     hipLaunchKernelGGL(gemm_tn_kernel<TAPS>, dim3((N / 64) * (K / 64), TAPS, nslab), dim3(256), 0, s, dC, ldc, A, lda,
-                       nslab > 1 ? t->slab : t->G + og, rows, N, K, t->T, rps);
-    if (nslab > 1)
-        hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)t->slab, nslab, n, t->G + og);
-    GEM_HIP(hipGetLastError());
-    return 0;
-}
-static int adjoint(gem_trainer* t, const float* W, int taps, int N, int K, hipStream_t s) {
-    const size_t n = (size_t)taps * N * K;
-    if (n > t->adj_elems) { set_error("train: adjoint scratch too small"); return 1; }
-    hipLaunchKernelGGL(adjoint_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, t->adj, taps, N, K);
+                       nslab > 1 ? slab : t->G + og, rows, N, K, t->T, rps);
     GEM_HIP(hipGetLastError());
     return 0;
 }
@@ -328,26 +418,46 @@ int gem_trainer_create(const gem_config* cfg, gem_trainer** out) {
     t->n_params = off; t->n_stats = soff;
     gem_trainer* p = t.get();
     if (talloc(p, &p->P, off) || talloc(p, &p->G, off) || talloc(p, &p->M1, off) || talloc(p, &p->M2, off) || talloc(p, &p->S, soff)) return 1;
-    size_t max_w = 0, max_width = PAD;
+    size_t max_width = PAD;
+    const size_t conv_slabs = (rows + TN_ROWS_CONV - 1) / TN_ROWS_CONV, lin_slabs = ((size_t)p->Bmax + TN_ROWS_LINEAR - 1) / TN_ROWS_LINEAR;
+    std::vector<AdjDesc> adj;
+    std::vector<SumDesc> sums;          // conv layers first, then (only when they need slabs) the two linear layers
     for (auto* v : {&p->enc, &p->dec})
         for (auto& c : *v) {
+            const size_t nw = (size_t)3 * c.N * c.K;
             if (talloc(p, &c.Y, rows * c.N) || talloc(p, &c.out, rows * c.N) || talloc(p, &c.mean, (size_t)c.N) || talloc(p, &c.invstd, (size_t)c.N)) return 1;
-            max_w = std::max(max_w, (size_t)3 * c.N * c.K);
+            if (&c != &p->enc.front()) {          // (nothing flows back through the first encoder conv)
+                if (talloc(p, &c.adj, nw)) return 1;
+                adj.push_back(AdjDesc{p->P + c.ow, c.adj, 3, c.N, c.K, 3 * (c.N / 64) * (c.K / 64)});
+            }
+            if (conv_slabs > 1) {
+                if (talloc(p, &c.slab, nw * conv_slabs)) return 1;
+                sums.push_back(SumDesc{c.slab, p->G + c.ow, nw});
+            }
             max_width = std::max(max_width, (size_t)std::max(c.N, c.K));
         }
-    max_w = std::max(max_w, std::max((size_t)p->fc.N * p->fc.K, (size_t)p->dec_in.N * p->dec_in.K));
-    p->adj_elems = max_w;
-    // weight-gradient slabs of 256 rows (a single slab goes straight to the gradient arena): the conv layers contract over B*T
-    // rows of small tensors, the linear layers over B rows of large ones
-    size_t conv_w = 0;
-    for (auto* v : {&p->enc, &p->dec}) for (auto& c : *v) conv_w = std::max(conv_w, (size_t)3 * c.N * c.K);
-    const size_t conv_slabs = (rows + 255) / 256, lin_slabs = ((size_t)p->Bmax + 255) / 256;
-    p->slab_elems = std::max(conv_slabs > 1 ? conv_w * conv_slabs : 0,
-                             lin_slabs > 1 ? std::max((size_t)p->fc.N * p->fc.K, (size_t)p->dec_in.N * p->dec_in.K) * lin_slabs : 0);
+    p->n_sum = (int)sums.size();
+    for (TrainLinear* l : {&p->fc, &p->dec_in}) {
+        const size_t nw = (size_t)l->N * l->K;
+        if (talloc(p, &l->adj, nw)) return 1;
+        adj.push_back(AdjDesc{p->P + l->ow, l->adj, 1, l->N, l->K, (l->N / 64) * (l->K / 64)});
+        if (lin_slabs > 1) {
+            if (talloc(p, &l->slab, nw * lin_slabs)) return 1;
+            sums.push_back(SumDesc{l->slab, p->G + l->ow, nw});
+        }
+    }
+    for (const auto& d : adj) p->adj_tiles = std::max(p->adj_tiles, d.tiles);
+    for (const auto& d : sums) p->sum_max = std::max(p->sum_max, (size_t)d.n);
+    p->n_adj = (int)adj.size();
+    if (talloc(p, &p->adj_tab, adj.size()) || talloc(p, &p->sum_tab, sums.size())) return 1;
+    GEM_HIP(hipMemcpy(p->adj_tab, adj.data(), adj.size() * sizeof(AdjDesc), hipMemcpyHostToDevice));
+    if (!sums.empty()) GEM_HIP(hipMemcpy(p->sum_tab, sums.data(), sums.size() * sizeof(SumDesc), hipMemcpyHostToDevice));
+    p->part_recon = (int)((rows * PAD + LOSS_BLOCK - 1) / LOSS_BLOCK);
+    p->part_latent = (int)(((size_t)p->Bmax * p->Dp + LOSS_BLOCK - 1) / LOSS_BLOCK);
     if (talloc(p, &p->pose_p, rows * PAD) || talloc(p, &p->mulv, (size_t)p->Bmax * 2 * p->Dp) || talloc(p, &p->z, (size_t)p->Bmax * p->Dp) ||
         talloc(p, &p->h0, rows * p->topp) || talloc(p, &p->Xp, rows * PAD) || talloc(p, &p->gA, rows * max_width) || talloc(p, &p->gB, rows * max_width) ||
-        talloc(p, &p->dmulv, (size_t)p->Bmax * 2 * p->Dp) || talloc(p, &p->dz, (size_t)p->Bmax * p->Dp) || talloc(p, &p->adj, p->adj_elems) ||
-        talloc(p, &p->slab, p->slab_elems) || talloc(p, &p->red, (size_t)8))
+        talloc(p, &p->dmulv, (size_t)p->Bmax * 2 * p->Dp) || talloc(p, &p->dz, (size_t)p->Bmax * p->Dp) ||
+        talloc(p, &p->red, (size_t)8 + p->part_recon + p->part_latent))
         return 1;
     *out = t.release();
     return 0;
@@ -375,6 +485,7 @@ int gem_trainer_upload(gem_trainer* t, int what, const float* src, int64_t n) {
     const size_t want = what == 2 ? t->n_stats : t->n_params;
     if (!dst || (size_t)n != want) { set_error("gem_trainer_upload: bad selector or size"); return 1; }
     GEM_HIP(hipSetDevice(t->h->cfg.device));
+    GEM_HIP(hipDeviceSynchronize());
     GEM_HIP(hipMemcpy(dst, src, want * sizeof(float), hipMemcpyHostToDevice));
     if (what == 0) t->step = 0;
     return 0;
@@ -404,12 +515,17 @@ int gem_trainer_step(gem_trainer* t, int B, const float* d_pose, const float* d_
     hipStream_t s = (hipStream_t)stream;
     const int T = t->T, rows = B * T;
     h->precision = GEM_PRECISION_F32;
+    // ---- the adjoint weight images of this step's parameters (one launch for all layers)
+    hipLaunchKernelGGL(adjoint_all_kernel, dim3(t->adj_tiles, t->n_adj), dim3(256), 0, s, (const AdjDesc*)t->adj_tab);
+    GEM_HIP(hipGetLastError());
     // ---- forward (train mode)
     if (launch_pack_pose(d_pose, t->pose_p, rows, t->C, s)) return 1;
     auto conv_fwd = [&](TrainConv& c, const float* in) -> int {
-        if (launch_gemm(h, conv_layer(t, c), EPI_BIAS, in, c.K, nullptr, c.bn ? c.Y : c.out, c.N, rows, T, s, -1)) return 1;
+        Layer L; L.taps = 3; L.K = c.K; L.N = c.N; L.w = t->P + c.ow; L.bias = t->P + c.ob;
+        if (launch_gemm(h, L, EPI_BIAS, in, c.K, nullptr, c.bn ? c.Y : c.out, c.N, rows, T, s, -1)) return 1;
         if (c.bn) {
-            hipLaunchKernelGGL(bn_train_fwd_kernel, dim3(c.N / 16), dim3(256), 0, s, (const float*)c.Y, rows, c.N, (const float*)(t->P + c.og),
+            auto k = rows <= BN_REGS * BN_GROUPS ? bn_train_fwd_kernel<true> : bn_train_fwd_kernel<false>;
+            hipLaunchKernelGGL(k, dim3(c.N / 16), dim3(BN_THREADS), 0, s, (const float*)c.Y, rows, c.N, (const float*)(t->P + c.og),
                                (const float*)(t->P + c.obe), t->S + c.os, t->S + c.os + c.N, c.mean, c.invstd, c.out, (float)o->bn_momentum, (float)BN_EPS);
             GEM_HIP(hipGetLastError());
         }
@@ -427,63 +543,71 @@ int gem_trainer_step(gem_trainer* t, int B, const float* d_pose, const float* d_
     const float* X = t->dec.back().out;
     // ---- loss + its gradient w.r.t. the decoded pose
     const double n_recon = o->recon_sum ? 1.0 : (double)rows * t->C;
-    hipLaunchKernelGGL(recon_loss_kernel, dim3(1), dim3(1024), 0, s, X, (const float*)t->pose_p, rows, t->C, (float)(1.0 / n_recon), t->gA, t->red);
+    double* part_recon = t->red + 8;
+    double* part_latent = part_recon + t->part_recon;
+    const int n_pr = (int)(((size_t)rows * PAD + LOSS_BLOCK - 1) / LOSS_BLOCK), n_pl = (int)(((size_t)B * t->Dp + LOSS_BLOCK - 1) / LOSS_BLOCK);
+    hipLaunchKernelGGL(recon_loss_kernel, dim3(n_pr), dim3(LOSS_BLOCK), 0, s, X, (const float*)t->pose_p, rows, t->C, (float)(1.0 / n_recon), t->gA, part_recon);
     GEM_HIP(hipGetLastError());
     // ---- backward: decoder
+    auto bn_bwd = rows <= BN_REGS * BN_GROUPS ? bn_train_bwd_kernel<true> : bn_train_bwd_kernel<false>;
     float *g = t->gA, *g2 = t->gB;
     for (int i = (int)t->dec.size() - 1; i >= 0; --i) {
         TrainConv& c = t->dec[i];
         const float* a_in = i > 0 ? t->dec[i - 1].out : t->h0;
         const float* dY = g;
         if (c.bn) {
-            hipLaunchKernelGGL(bn_train_bwd_kernel, dim3(c.N / 16), dim3(256), 0, s, (const float*)g, (const float*)c.out, (const float*)c.Y, rows, c.N,
-                               (const float*)(t->P + c.og), (const float*)c.mean, (const float*)c.invstd, g2, t->G + c.og, t->G + c.obe);
-            GEM_HIP(hipGetLastError());
+            hipLaunchKernelGGL(bn_bwd, dim3(c.N / 16), dim3(BN_THREADS), 0, s, (const float*)g, (const float*)c.out, (const float*)c.Y, rows, c.N,
+                               (const float*)(t->P + c.og), (const float*)c.mean, (const float*)c.invstd, g2, t->G + c.og, t->G + c.obe, t->G + c.ob);
             dY = g2;
+        } else {
+            hipLaunchKernelGGL(colsum_kernel, dim3(c.N / 16), dim3(BN_THREADS), 0, s, dY, rows, c.N, t->G + c.ob);
         }
-        hipLaunchKernelGGL(colsum_kernel, dim3(c.N / 16), dim3(256), 0, s, dY, rows, c.N, t->G + c.ob);
-        if (weight_grad<3>(t, dY, c.N, a_in, c.K, rows, c.N, c.K, c.ow, s)) return 1;
-        if (adjoint(t, t->P + c.ow, 3, c.N, c.K, s)) return 1;
-        Layer L; L.taps = 3; L.K = c.N; L.N = c.K; L.w = t->adj; L.bias = nullptr;
+        GEM_HIP(hipGetLastError());
+        if (weight_grad<3>(t, dY, c.N, a_in, c.K, rows, c.N, c.K, c.ow, c.slab, TN_ROWS_CONV, s)) return 1;
+        Layer L; L.taps = 3; L.K = c.N; L.N = c.K; L.w = c.adj; L.bias = nullptr;
         float* dA = (dY == g) ? g2 : g;          // the buffer that does not hold dY
         if (launch_gemm(h, L, EPI_NONE, dY, c.N, nullptr, dA, c.K, rows, T, s, -1)) return 1;
         if (dA != g) { float* tmp = g; g = dA; g2 = tmp; }
     }
     // g = dh0 [B, T*topp]: decoder_input
     { const TrainLinear& l = t->dec_in;
-      hipLaunchKernelGGL(colsum_kernel, dim3(l.N / 16), dim3(256), 0, s, (const float*)g, B, l.N, t->G + l.ob);
-      if (weight_grad<1>(t, g, l.N, t->z, l.K, B, l.N, l.K, l.ow, s)) return 1;
-      if (adjoint(t, t->P + l.ow, 1, l.N, l.K, s)) return 1;
-      Layer L; L.taps = 1; L.K = l.N; L.N = l.K; L.w = t->adj; L.bias = nullptr;
+      hipLaunchKernelGGL(colsum_kernel, dim3(l.N / 16), dim3(BN_THREADS), 0, s, (const float*)g, B, l.N, t->G + l.ob);
+      if (weight_grad<1>(t, g, l.N, t->z, l.K, B, l.N, l.K, l.ow, l.slab, TN_ROWS_LINEAR, s)) return 1;
+      Layer L; L.taps = 1; L.K = l.N; L.N = l.K; L.w = l.adj; L.bias = nullptr;
       if (launch_gemm(h, L, EPI_NONE, g, l.N, nullptr, t->dz, l.K, B, T, s, -1)) return 1; }
-    hipLaunchKernelGGL(latent_bwd_kernel, dim3(1), dim3(1024), 0, s, (const float*)t->mulv, d_eps, (const float*)t->dz, B, t->D, t->Dp,
-                       (float)(o->kld_weight / B), t->dmulv, t->red);
-    hipLaunchKernelGGL(finish_loss_kernel, dim3(1), dim3(1), 0, s, t->red, n_recon, o->kld_weight, t->red + 4);
+    hipLaunchKernelGGL(latent_bwd_kernel, dim3(n_pl), dim3(LOSS_BLOCK), 0, s, (const float*)t->mulv, d_eps, (const float*)t->dz, B, t->D, t->Dp,
+                       (float)(o->kld_weight / B), t->dmulv, part_latent);
+    hipLaunchKernelGGL(finish_loss_kernel, dim3(1), dim3(256), 0, s, (const double*)part_recon, n_pr, (const double*)part_latent, n_pl, n_recon,
+                       o->kld_weight, B, t->red + 4);
     GEM_HIP(hipGetLastError());
     // fc_mu | fc_var
     { const TrainLinear& l = t->fc;
       const float* flat = t->enc.back().out;
-      hipLaunchKernelGGL(colsum_kernel, dim3(l.N / 16), dim3(256), 0, s, (const float*)t->dmulv, B, l.N, t->G + l.ob);
-      if (weight_grad<1>(t, t->dmulv, l.N, flat, l.K, B, l.N, l.K, l.ow, s)) return 1;
-      if (adjoint(t, t->P + l.ow, 1, l.N, l.K, s)) return 1;
-      Layer L; L.taps = 1; L.K = l.N; L.N = l.K; L.w = t->adj; L.bias = nullptr;
+      hipLaunchKernelGGL(colsum_kernel, dim3(l.N / 16), dim3(BN_THREADS), 0, s, (const float*)t->dmulv, B, l.N, t->G + l.ob);
+      if (weight_grad<1>(t, t->dmulv, l.N, flat, l.K, B, l.N, l.K, l.ow, l.slab, TN_ROWS_LINEAR, s)) return 1;
+      Layer L; L.taps = 1; L.K = l.N; L.N = l.K; L.w = l.adj; L.bias = nullptr;
       g = t->gA; g2 = t->gB;
       if (launch_gemm(h, L, EPI_NONE, t->dmulv, l.N, nullptr, g, l.K, B, T, s, -1)) return 1; }
     // encoder
     for (int i = (int)t->enc.size() - 1; i >= 0; --i) {
         TrainConv& c = t->enc[i];
         const float* a_in = i > 0 ? t->enc[i - 1].out : t->pose_p;
-        hipLaunchKernelGGL(bn_train_bwd_kernel, dim3(c.N / 16), dim3(256), 0, s, (const float*)g, (const float*)c.out, (const float*)c.Y, rows, c.N,
-                           (const float*)(t->P + c.og), (const float*)c.mean, (const float*)c.invstd, g2, t->G + c.og, t->G + c.obe);
-        hipLaunchKernelGGL(colsum_kernel, dim3(c.N / 16), dim3(256), 0, s, (const float*)g2, rows, c.N, t->G + c.ob);
+        hipLaunchKernelGGL(bn_bwd, dim3(c.N / 16), dim3(BN_THREADS), 0, s, (const float*)g, (const float*)c.out, (const float*)c.Y, rows, c.N,
+                           (const float*)(t->P + c.og), (const float*)c.mean, (const float*)c.invstd, g2, t->G + c.og, t->G + c.obe, t->G + c.ob);
         GEM_HIP(hipGetLastError());
-        if (weight_grad<3>(t, g2, c.N, a_in, c.K, rows, c.N, c.K, c.ow, s)) return 1;
+        if (weight_grad<3>(t, g2, c.N, a_in, c.K, rows, c.N, c.K, c.ow, c.slab, TN_ROWS_CONV, s)) return 1;
         if (i > 0) {
-            if (adjoint(t, t->P + c.ow, 3, c.N, c.K, s)) return 1;
-            Layer L; L.taps = 3; L.K = c.N; L.N = c.K; L.w = t->adj; L.bias = nullptr;
+            Layer L; L.taps = 3; L.K = c.N; L.N = c.K; L.w = c.adj; L.bias = nullptr;
             if (launch_gemm(h, L, EPI_NONE, g2, c.N, nullptr, g, c.K, rows, T, s, -1)) return 1;
         }
     }
+    // the weight-gradient slabs -> the gradient arena (slab order: deterministic)
+    { const int ns_conv = (rows + TN_ROWS_CONV - 1) / TN_ROWS_CONV, ns_lin = (B + TN_ROWS_LINEAR - 1) / TN_ROWS_LINEAR;
+      if (ns_conv > 1 && t->n_sum > 0)
+          hipLaunchKernelGGL(slab_sum_all_kernel, dim3((unsigned)((t->sum_max / 4 + 255) / 256), t->n_sum), dim3(256), 0, s, (const SumDesc*)t->sum_tab, ns_conv);
+      if (ns_lin > 1)
+          hipLaunchKernelGGL(slab_sum_all_kernel, dim3((unsigned)((t->sum_max / 4 + 255) / 256), 2), dim3(256), 0, s, (const SumDesc*)t->sum_tab + t->n_sum, ns_lin);
+      GEM_HIP(hipGetLastError()); }
     if (d_losses) GEM_HIP(hipMemcpyAsync(d_losses, t->red + 4, 3 * sizeof(double), hipMemcpyDeviceToDevice, s));
     // ---- Adam
     if (update) {

@@ -44,6 +44,9 @@ def test_training_steps_against_the_reference_run(golden, case):
         noise = lambda k: k.endswith(".0.bias") or k.endswith("running_mean")        # noqa: E731
         for k, v in c["final"].items():
             d = np.abs(np.asarray(sd[k], np.float64) - v).max()
+            if k.endswith("running_var"):
+                assert d <= 1e-4 * max(1.0, float(np.abs(v).max())), (k, d)
+                continue
             assert d <= (4 * c["steps"] * c["lr"] if noise(k) else 1e-5 + 0.02 * c["lr"]), (k, d)
         opt = tr.optimizer_state()
         assert opt["step"] == c["steps"]
