@@ -352,3 +352,51 @@ class VAETrainer:
                                           "exp_avg_sq": {k: torch.from_numpy(v) for k, v in opt["exp_avg_sq"].items()}}},
                            os.path.join(checkpoint_dir, str(e) + ".pth.tar"))
         return history
+
+
+def _cli():
+    """`python -m globalegomocap_amd.vae_train`: the flags of networks/config.py:5-49 that `Train` reads, over a window file.
+
+    --train_data_path takes a .npy / .npz ('windows') of [n, seq_length, 45] relative-global pose windows (what AMASSDataset's
+    __getitem__ yields, networks/dataset/global_dataset.py:34-38; building them from AMASS pickles is data preparation and stays
+    with the reference) or `synthetic:<n>` for synthetic motion.  Checkpoints go to logs/<log_dir>/checkpoints/<e>.pth.tar
+    (train.py:19-33,102-108)."""
+    import argparse
+    import datetime
+    from . import synth
+    p = argparse.ArgumentParser(description="Train the motion VAE on MI355X (mirror of networks/train.py)")
+    p.add_argument("--train_data_path", required=True)
+    p.add_argument("--test_data_path", default=None)
+    p.add_argument("--latent_dim", type=int, required=True)
+    p.add_argument("--seq_length", type=int, required=True)
+    p.add_argument("--kl_weight", type=float, required=True)
+    p.add_argument("--epoch", type=int, default=20)
+    p.add_argument("--batch_size", type=int, default=64)
+    p.add_argument("--learning_rate", type=float, default=1e-4)
+    p.add_argument("--weight_decay", type=float, default=0.0)
+    p.add_argument("--log_dir", default=None)
+    p.add_argument("--log_step", type=int, default=100)
+    p.add_argument("--seed", type=int, default=0)
+    a = p.parse_args()
+
+    def load(path, seed):
+        if path.startswith("synthetic:"):
+            return synth.make_training_windows(int(path.split(":", 1)[1]), a.seq_length, seed)
+        d = np.load(path)
+        return np.asarray(d["windows"] if hasattr(d, "files") else d, np.float32).reshape(-1, a.seq_length, 45)
+    train = load(a.train_data_path, a.seed)
+    test = load(a.test_data_path, a.seed + 1) if a.test_data_path else train[-min(len(train), 10 * a.batch_size):]
+    log_dir = os.path.join("logs", a.log_dir or datetime.datetime.now().strftime("%m.%d-%H:%M:%S"))
+    print("making save dir at: {}".format(log_dir))
+    shape = VAEShape(latent_dim=a.latent_dim, seq_len=a.seq_length)
+    tr = VAETrainer(shape, batch_size=a.batch_size, lr=a.learning_rate, weight_decay=a.weight_decay, seed=a.seed)
+    try:
+        print("---------------------Start Training-----------------------")
+        tr.fit(train, epochs=a.epoch, kl_weight=a.kl_weight, test_windows=test, log_step=a.log_step,
+               checkpoint_dir=os.path.join(log_dir, "checkpoints"), seed=a.seed, args=vars(a))
+    finally:
+        tr.close()
+
+
+if __name__ == "__main__":
+    _cli()

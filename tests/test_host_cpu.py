@@ -35,6 +35,7 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(_capi.GemLbfgsOpts) == 8 + 16 + 5 * 8
     # int32 x4, int32[8], int32 x2, int32 (+pad), double[16], double x2, int32[16], int32 x2
     assert C.sizeof(_capi.GemConfig) == 16 + 32 + 8 + 8 + 128 + 16 + 64 + 8
+    assert C.sizeof(_capi.GemTrainOpts) == 7 * 8 + 8          # struct gem_train_opts: 7 doubles, 2 int32
 
 
 def test_missing_library_fails_loudly(tmp_path):
