@@ -82,6 +82,8 @@ SIGNATURES = {
     "gem_trainer_download": (C.c_int, [_P, C.c_int, _P, C.c_int64]),
     "gem_trainer_set_step": (C.c_int, [_P, C.c_int64]),
     "gem_trainer_step": (C.c_int, [_P, C.c_int, _P, _P, C.POINTER(GemTrainOpts), C.c_int, _P, _P]),
+    "gem_trainer_arena": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(C.c_int64)]),
+    "gem_trainer_apply": (C.c_int, [_P, C.POINTER(GemTrainOpts), C.c_double, _P]),
 }
 
 _lib = None

@@ -353,10 +353,10 @@ __global__ __launch_bounds__(256) void finish_loss_kernel(const double* __restri
 
 // torch.optim.Adam (amsgrad off): g += wd * p; m, v moments; p -= lr / bc1 * m / (sqrt(v) / sqrt(bc2) + eps)
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n, float lr,
-                            float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+                            float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const float gg = g[i] + wd * p[i];
+    const float gg = g[i] * gscale + wd * p[i];
     const float mm = b1 * m[i] + (1.f - b1) * gg;
     const float vv = b2 * v[i] + (1.f - b2) * gg * gg;
     m[i] = mm; v[i] = vv;
@@ -609,14 +609,29 @@ int gem_trainer_step(gem_trainer* t, int B, const float* d_pose, const float* d_
           hipLaunchKernelGGL(slab_sum_all_kernel, dim3((unsigned)((t->sum_max / 4 + 255) / 256), 2), dim3(256), 0, s, (const SumDesc*)t->sum_tab + t->n_sum, ns_lin);
       GEM_HIP(hipGetLastError()); }
     if (d_losses) GEM_HIP(hipMemcpyAsync(d_losses, t->red + 4, 3 * sizeof(double), hipMemcpyDeviceToDevice, s));
-    // ---- Adam
-    if (update) {
-        ++t->step;
-        const double bc1 = 1.0 - std::pow(o->beta1, (double)t->step), bc2 = 1.0 - std::pow(o->beta2, (double)t->step);
-        hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((t->n_params + 255) / 256)), dim3(256), 0, s, t->P, (const float*)t->G, t->M1, t->M2, t->n_params,
-                           (float)o->lr, (float)o->beta1, (float)o->beta2, (float)o->eps, (float)o->weight_decay, (float)bc1, (float)std::sqrt(bc2));
-        GEM_HIP(hipGetLastError());
-    }
+    if (update) return gem_trainer_apply(t, o, 1.0, stream);
+    return 0;
+}
+
+int gem_trainer_apply(gem_trainer* t, const gem_train_opts* o, double grad_scale, void* stream) {
+    if (!t || !o) { set_error("gem_trainer_apply: null argument"); return 1; }
+    GEM_HIP(hipSetDevice(t->h->cfg.device));
+    hipStream_t s = (hipStream_t)stream;
+    ++t->step;
+    const double bc1 = 1.0 - std::pow(o->beta1, (double)t->step), bc2 = 1.0 - std::pow(o->beta2, (double)t->step);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((t->n_params + 255) / 256)), dim3(256), 0, s, t->P, (const float*)t->G, t->M1, t->M2, t->n_params,
+                       (float)o->lr, (float)o->beta1, (float)o->beta2, (float)o->eps, (float)o->weight_decay, (float)bc1, (float)std::sqrt(bc2),
+                       (float)grad_scale);
+    GEM_HIP(hipGetLastError());
+    return 0;
+}
+
+int gem_trainer_arena(gem_trainer* t, int what, void** d_ptr, int64_t* n) {
+    if (!t || !d_ptr) { set_error("gem_trainer_arena: null argument"); return 1; }
+    float* p = what == 0 ? t->P : what == 1 ? t->G : what == 2 ? t->S : what == 3 ? t->M1 : what == 4 ? t->M2 : nullptr;
+    if (!p) { set_error("gem_trainer_arena: bad selector"); return 1; }
+    *d_ptr = p;
+    if (n) *n = (int64_t)(what == 2 ? t->n_stats : t->n_params);
     return 0;
 }
 

@@ -211,6 +211,7 @@ class VAETrainer:
                                        weight_decay=float(weight_decay), kld_weight=0.0, bn_momentum=float(bn_momentum),
                                        recon_sum=1 if recon_reduction == "sum" else 0, reserved=0)
         self.steps = 0
+        self._grad = None
         self._losses = torch.zeros(3, dtype=torch.float64, device=self.device)
         self._gen = torch.Generator(device=self.device)
         self._gen.manual_seed(seed)
@@ -292,6 +293,45 @@ class VAETrainer:
             return self._losses
         return tuple(float(v) for v in self._losses.cpu())
 
+    # ---- data parallel (one process per GPU; the reference itself trains on one device)
+    def arena_tensor(self, what=1):
+        """Arena `what` (0 parameters, 1 gradients, 2 statistics, 3 / 4 Adam moments) as a torch tensor over the library's memory."""
+        import torch
+        from . import _capi
+        ptr, n = C.c_void_p(), C.c_int64()
+        _capi.check(self.lib.gem_trainer_arena(self._t, what, C.byref(ptr), C.byref(n)), self.lib)
+
+        class _View:
+            __cuda_array_interface__ = {"shape": (n.value,), "typestr": "<f4", "data": (ptr.value, False), "version": 2}
+        return torch.as_tensor(_View(), device=self.device)
+
+    def step_data_parallel(self, poses, kld_weight, eps=None, group=None, sync=True):
+        """One step of DistributedDataParallel-style training: this rank's batch -> gradients (gem_trainer_step, update = 0),
+        ONE all-reduce of the flat gradient arena (RCCL through torch.distributed; `group` = None: the default group), Adam on
+        the mean gradient (gem_trainer_apply with grad_scale = 1 / world size).  BatchNorm statistics stay per rank (DDP without
+        SyncBatchNorm).  Returns the losses averaged over the ranks."""
+        import torch
+        import torch.distributed as dist
+        from . import _capi
+        world = dist.get_world_size(group)
+        losses = self.step(poses, kld_weight, eps=eps, update=False, sync=False)
+        if getattr(self, "_grad", None) is None:
+            self._grad = self.arena_tensor(1)
+        dist.all_reduce(self._grad, group=group)
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        _capi.check(self.lib.gem_trainer_apply(self._t, C.byref(self.opts), 1.0 / world, C.c_void_p(s)), self.lib)
+        self.steps += 1
+        mean = losses.clone()
+        dist.all_reduce(mean, group=group)
+        mean /= world
+        return tuple(float(v) for v in mean.cpu()) if sync else mean
+
+    def broadcast_parameters(self, src=0, group=None):
+        """Every rank starts from rank `src`'s parameters, statistics and Adam state (DDP's initial broadcast)."""
+        import torch.distributed as dist
+        for what in (0, 2, 3, 4):
+            dist.broadcast(self.arena_tensor(what), src=src, group=group)
+
     # ---- the epoch loop (train.py:65-108) and the evaluation pass (train.py:110-127)
     def evaluate(self, windows, batch_size=None):
         """Eval-mode reconstruction MPJPE (train.py:110-127): a WindowEngine with the current weights encodes with the random
@@ -316,8 +356,12 @@ class VAETrainer:
             eng.close()
 
     def fit(self, train_windows, epochs=20, kl_weight=0.25, test_windows=None, log_step=100, checkpoint_dir=None, seed=0, log=print,
-            args=None):
-        """Train.train(): `epochs` passes over a shuffled, drop_last DataLoader of `train_windows` [n,T,45]."""
+            args=None, group=None, data_parallel=False):
+        """Train.train(): `epochs` passes over a shuffled, drop_last DataLoader of `train_windows` [n,T,45].
+
+        data_parallel=True (torch.distributed initialised, one process per GPU): every rank walks the same permutation (same
+        seed) and takes the batches rank, rank + world, ... (a DistributedSampler's split); gradients are averaged over the
+        ranks every step; rank 0 logs, evaluates and writes the checkpoints."""
         import torch
         from .vae import save_checkpoint  # noqa: F401  (same schema; the file below carries train.py's extra keys)
         data = torch.as_tensor(np.asarray(train_windows), dtype=torch.float32, device=self.device)
@@ -328,10 +372,20 @@ class VAETrainer:
         g = torch.Generator(device="cpu").manual_seed(seed)
         running = torch.zeros(3, dtype=torch.float64, device=self.device)
         count, history = 0, []
+        rank, world = 0, 1
+        if data_parallel:
+            import torch.distributed as dist
+            rank, world = dist.get_rank(group), dist.get_world_size(group)
+            self.broadcast_parameters(0, group)
+            if rank != 0:
+                log = lambda *a, **k: None          # noqa: E731  (rank 0 reports, like a DDP training script)
         for e in range(int(epochs)):
             perm = torch.randperm(n, generator=g).to(self.device)
-            for i in range(n // bs):
-                running += self.step(data[perm[i * bs:(i + 1) * bs]], m_n, sync=False)
+            for i in range(rank, (n // bs) // world * world, world):
+                if data_parallel:
+                    running += self.step_data_parallel(data[perm[i * bs:(i + 1) * bs]], m_n, group=group, sync=False)
+                else:
+                    running += self.step(data[perm[i * bs:(i + 1) * bs]], m_n, sync=False)
                 if count % log_step == 0 and count != 0:
                     r = running.cpu()
                     log("running loss is: {}".format(float(r[0])))
@@ -339,6 +393,8 @@ class VAETrainer:
                     history.append((count, float(r[0]), float(r[1])))
                     running.zero_()
                 count += 1
+            if rank != 0:
+                continue
             eval_loss = self.evaluate(test_windows if test_windows is not None else train_windows) if test_windows is not False else None
             if eval_loss is not None:
                 log("eval loss is: {}".format(eval_loss))

@@ -260,6 +260,13 @@ int  gem_trainer_download(gem_trainer* t, int what, float* h_dst, int64_t n);
 int  gem_trainer_set_step(gem_trainer* t, int64_t step);
 int  gem_trainer_step(gem_trainer* t, int B, const float* d_pose, const float* d_eps, const gem_train_opts* opts, int update,
                       double* d_losses, void* stream);
+/* Data-parallel training (one process per GPU, every rank its own batch; the reference trains on one device, networks/train.py:58):
+ * gem_trainer_step(..., update = 0, ...) leaves the rank's gradients in the gradient arena; the caller all-reduces that ONE flat
+ * buffer (gem_trainer_arena returns the device address of arena `what` and its length in floats; RCCL through torch.distributed
+ * in vae_train.py) and applies the Adam step with gem_trainer_apply, which scales the gradients by grad_scale (1 / world size)
+ * on the fly.  BatchNorm statistics stay per rank, as under torch's DistributedDataParallel without SyncBatchNorm. */
+int  gem_trainer_arena(gem_trainer* t, int what, void** d_ptr, int64_t* n);
+int  gem_trainer_apply(gem_trainer* t, const gem_train_opts* opts, double grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -137,3 +137,82 @@ def test_trainer_rejects_bad_arguments():
             tr.step(np.zeros((4, 10, 44), np.float32), 0.1)
     finally:
         tr.close()
+
+
+DP_SCRIPT = """
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+from globalegomocap_amd import synth, vae as vae_schema
+from globalegomocap_amd.vae_train import VAETrainer, initial_state_dict
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo")
+shape = vae_schema.VAEShape(latent_dim=64, hidden=(32, 64))
+data = synth.make_training_windows(4 * 16, shape.seq_len, 3).reshape(4, 16, shape.seq_len, 45)     # [step*world + rank]
+eps = np.random.default_rng(5).standard_normal((4, 16, shape.latent_dim)).astype(np.float32)
+# rank 1 starts from OTHER weights: the initial broadcast must bring rank 0's
+tr = VAETrainer(shape, batch_size=16, lr=1e-3, weight_decay=1e-4, state_dict=initial_state_dict(shape, 7 + rank))
+tr.broadcast_parameters(0)
+out = []
+for s in range(2):
+    out.append(tr.step_data_parallel(data[s * world + rank], 0.01, eps=eps[s * world + rank]))
+sd = tr.state_dict()
+np.savez(sys.argv[1] + ".rank%%d.npz" %% rank, losses=np.array(out), **{k: v for k, v in sd.items()})
+tr.close()
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_two_rank_data_parallel_steps_equal_the_mean_gradient_step(tmp_path):
+    """step_data_parallel on two REAL ranks (torch.distributed.run, gloo, both on the one card of the test box) against one
+    process doing what DDP defines: the two ranks' gradients from their own batches (own BatchNorm statistics), their mean,
+    one Adam step on it.  The parameters must come out bitwise equal on both ranks and bitwise equal to the emulation."""
+    import subprocess
+    import sys
+    import torch
+    from globalegomocap_amd.vae_train import VAETrainer, initial_state_dict, pack_arena
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "dp.py"
+    script.write_text(DP_SCRIPT % root)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29631", str(script), str(tmp_path / "dp")], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    a, b = np.load(str(tmp_path / "dp.rank0.npz")), np.load(str(tmp_path / "dp.rank1.npz"))
+    shape = vae_schema.VAEShape(latent_dim=64, hidden=(32, 64))
+    data = synth.make_training_windows(4 * 16, shape.seq_len, 3).reshape(4, 16, shape.seq_len, 45)
+    eps = np.random.default_rng(5).standard_normal((4, 16, shape.latent_dim)).astype(np.float32)
+    # emulation: two trainers = the two ranks; gradients exchanged through the arena views
+    t0 = VAETrainer(shape, batch_size=16, lr=1e-3, weight_decay=1e-4, state_dict=initial_state_dict(shape, 7))
+    t1 = VAETrainer(shape, batch_size=16, lr=1e-3, weight_decay=1e-4, state_dict=initial_state_dict(shape, 7))
+    try:
+        import ctypes as C
+        from globalegomocap_amd import _capi
+        losses = []
+        for s in range(2):
+            l0 = t0.step(data[2 * s], 0.01, eps=eps[2 * s], update=False)
+            l1 = t1.step(data[2 * s + 1], 0.01, eps=eps[2 * s + 1], update=False)
+            g0, g1 = t0.arena_tensor(1), t1.arena_tensor(1)
+            tot = g0 + g1
+            g0.copy_(tot)
+            g1.copy_(tot)
+            for t in (t0, t1):
+                _capi.check(t.lib.gem_trainer_apply(t._t, C.byref(t.opts), 0.5, None), t.lib)
+                t.steps += 1
+            losses.append([(x + y) / 2 for x, y in zip(l0, l1)])
+        torch.cuda.synchronize()
+        s0, s1 = t0.state_dict(), t1.state_dict()
+        np.testing.assert_allclose(a["losses"], np.array(losses), rtol=1e-12)
+        np.testing.assert_array_equal(a["losses"], b["losses"])
+        for k in shape.schema():
+            if "running" in k:                       # BatchNorm statistics are per rank
+                assert np.array_equal(a[k], s0[k]) and np.array_equal(b[k], s1[k]), k
+            else:
+                assert np.array_equal(a[k], b[k]), k
+                assert np.array_equal(a[k], s0[k]), k
+        assert not np.array_equal(a["encoder.0.1.running_mean"], b["encoder.0.1.running_mean"])
+    finally:
+        t0.close()
+        t1.close()
