@@ -216,3 +216,34 @@ def test_two_rank_data_parallel_steps_equal_the_mean_gradient_step(tmp_path):
     finally:
         t0.close()
         t1.close()
+
+
+@pytest.mark.parametrize("batch", [4, 130, 300])
+def test_training_step_against_the_port_at_other_batch_sizes(batch):
+    """The code paths the golden batches (9, 12) do not reach: 4 windows = 40 rows, a single weight-gradient slab written
+    straight into the gradient arena; 130 windows = 1300 rows, the BatchNorm kernels' looping variant (more rows than a
+    thread keeps in registers); 300 windows, the linear layers' weight gradients in two slabs."""
+    from globalegomocap_amd.vae_train import VAETrainer, initial_state_dict
+    from oracle.torch_port import TrainPort
+    shape = vae_schema.VAEShape(latent_dim=72, hidden=(24, 40, 96))
+    init = initial_state_dict(shape, 21)
+    poses = synth.make_training_windows(2 * batch, shape.seq_len, 8).reshape(2, batch, shape.seq_len, 45)
+    eps = np.random.default_rng(2).standard_normal((2, batch, shape.latent_dim)).astype(np.float32)
+    port = TrainPort(init, lr=1e-3, weight_decay=1e-4)
+    tr = VAETrainer(shape, batch_size=batch, lr=1e-3, weight_decay=1e-4, state_dict=init)
+    try:
+        for s in range(2):
+            ref = port.step(poses[s], eps[s], 0.02)
+            out = tr.step(poses[s], 0.02, eps=eps[s])
+            np.testing.assert_allclose(out, ref, rtol=5e-5)
+            g, gr = tr.gradients(), port.gradients()
+            gmax = max(float(np.abs(v).max()) for v in gr.values())
+            for k, v in gr.items():
+                d = np.abs(np.asarray(g[k], np.float64) - v).max()
+                assert d <= (5e-6 * gmax if k.endswith(".0.bias") else 2e-4 * np.abs(v).max() + 5e-7 * gmax), (s, k, d, np.abs(v).max())
+        sd, sr = tr.state_dict(), port.state_dict()
+        for k, v in sr.items():
+            if k.endswith("running_var"):
+                assert np.abs(np.asarray(sd[k], np.float64) - v).max() <= 1e-4 * max(1.0, float(np.abs(v).max())), k
+    finally:
+        tr.close()
