@@ -111,7 +111,7 @@ static double run(const char* name, int M, int N, int K, int T, int n_split, int
     return tf;
 }
 
-template <int EPI, bool OUT_BF16, int S>
+template <int EPI, bool OUT_BF16, int S, int ABL = 0>
 static double run_ring(const char* name, int M, int N, int K, int n_split, int reps) {
     std::vector<uint16_t> hA((size_t)M * K), hW((size_t)N * K);
     std::vector<float> hb(N);
@@ -130,7 +130,7 @@ static double run_ring(const char* name, int M, int N, int K, int n_split, int r
     a.lda = K; a.ldc = N; a.M = M; a.N = N; a.K = K; a.T = 10;
     const int nTiles = K / gem::ring::BK;
     a.n_split = n_split; a.tiles_per_split = (nTiles + n_split - 1) / n_split; a.slab_stride = (size_t)M * N;
-    auto k = gem::ring::gemm_ring_kernel<EPI, OUT_BF16, S>;
+    auto k = gem::ring::gemm_ring_kernel<EPI, OUT_BF16, S, ABL>;
     const size_t smem = (size_t)S * gem::ring::STAGE;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const int grid = ((M + gem::ring::BM - 1) / gem::ring::BM) * (N / gem::ring::BN) * n_split;
@@ -217,6 +217,16 @@ int main(int argc, char** argv) {
         run_ring<EPI_BIAS_LRELU, true, 5>("front fwd S5", 8192, 2560, 2048, 1, reps);
         run_ring<EPI_BIAS_LRELU, false, 6>("front fwd 1536 split 1", 1536, 2560, 2048, 1, reps);
         run_ring<EPI_BIAS_LRELU, false, 6>("front fwd 1536 split 4", 1536, 2560, 2048, 4, reps);
+    }
+    if (!strcmp(which, "ablate")) {      // what bounds the ring kernel: drop one activity at a time (results wrong, timing only)
+        run_ring<EPI_BIAS_LRELU, true, 6, 0>("full", 8192, 2560, 2048, 1, reps);
+        run_ring<EPI_BIAS_LRELU, true, 6, 1>("no DMA in the loop", 8192, 2560, 2048, 1, reps);
+        run_ring<EPI_BIAS_LRELU, true, 6, 2>("no fragment reads", 8192, 2560, 2048, 1, reps);
+        run_ring<EPI_BIAS_LRELU, true, 6, 3>("no MFMAs", 8192, 2560, 2048, 1, reps);
+        run_ring<EPI_BIAS_LRELU, true, 6, 4>("DMA only", 8192, 2560, 2048, 1, reps);
+        run_ring<EPI_BIAS_LRELU, true, 6, 5>("MFMAs only", 8192, 2560, 2048, 1, reps);
+        run_ring<EPI_BIAS_LRELU, true, 6, 6>("reads + MFMAs, no barrier", 8192, 2560, 2048, 1, reps);
+        run_ring<EPI_BIAS_LRELU, true, 6, 5>("MFMAs only, 7680 rows", 7680, 2560, 2048, 1, reps);
     }
     if (!strcmp(which, "split")) {      // split-K choices of the composed front layer at configs[2] size (1536 windows) and in between
         for (int M : {768, 1024, 1536, 2048, 3072}) {

@@ -51,7 +51,10 @@ static_assert(A_PIECES * 1024 * NW == A_BYTES && B_PIECES * 1024 * NW == B_BYTES
 
 __device__ __forceinline__ int swz4(int row) { return (0x1230 >> (((row >> 2) & 3) * 4)) & 3; }      // F = {0, 3, 2, 1}
 
-template <int EPI, bool OUT_BF16, int S = 6>
+// ABL (ablation, timing only -- the results are wrong): 1 = no global -> LDS transfers inside the loop, 2 = no LDS fragment reads
+// inside the loop, 3 = no MFMAs (the fragments are consumed by an empty asm), 4 = transfers only (no reads, no MFMAs),
+// 5 = MFMAs only (no transfers, no reads, no barrier), 6 = reads + MFMAs without transfers and without the barrier
+template <int EPI, bool OUT_BF16, int S = 6, int ABL = 0>
 __global__ __launch_bounds__(NT) void gemm_ring_kernel(const Args a) {
     static_assert(S >= 3 && S * STAGE <= 160 * 1024, "ring must fit the LDS of a CU");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -137,15 +140,26 @@ __global__ __launch_bounds__(NT) void gemm_ring_kernel(const Args a) {
 #pragma unroll
     for (int s = 0; s < S - 1; ++s) stage(s, kt_begin + min(s, n_steps - 1));
     bf16x8 afX[4], wfX[4], afY[4], wfY[4];
+    if (ABL == 2 || ABL == 4 || ABL == 5) {          // (fragments read once, outside the loop)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        read_frags(0, afX, wfX);
+        read_frags(0, afY, wfY);
+    }
     int slot = 0, slot_in = S - 1;
     auto advance = [&](int k, bf16x8 (&af_new)[4], bf16x8 (&wf_new)[4], const bf16x8 (&af_old)[4], const bf16x8 (&wf_old)[4]) {
         // (lgkmcnt(0): this wave's fragment reads of step k-1 have returned before anybody may overwrite their slot)
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PIECES * (S - 2)) : "memory");
-        __builtin_amdgcn_s_barrier();
-        stage(slot_in, kt_begin + min(k + S - 1, n_steps - 1));
-        read_frags(slot, af_new, wf_new);
+        if (ABL != 5 && ABL != 6) __builtin_amdgcn_s_barrier();
+        if (ABL != 1 && ABL != 5 && ABL != 6) stage(slot_in, kt_begin + min(k + S - 1, n_steps - 1));
+        if (ABL != 2 && ABL != 4 && ABL != 5) read_frags(slot, af_new, wf_new);
         __builtin_amdgcn_sched_barrier(0);
-        if (k > 0) mfmas(af_old, wf_old);
+        if (ABL == 3) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) asm volatile("" ::"v"(af_new[q]), "v"(wf_new[q]));
+        } else if (ABL != 4) {
+            if (k > 0) mfmas(af_old, wf_old);
+        }
         slot = slot + 1 == S ? 0 : slot + 1;
         slot_in = slot_in + 1 == S ? 0 : slot_in + 1;
     };
