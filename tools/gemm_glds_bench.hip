@@ -132,9 +132,9 @@ static double run_ring(const char* name, int M, int N, int K, int n_split, int r
     a.n_split = n_split; a.tiles_per_split = (nTiles + n_split - 1) / n_split; a.slab_stride = (size_t)M * N;
     auto k = gem::ring::gemm_ring_kernel<EPI, OUT_BF16, S, ABL>;
     const size_t smem = (size_t)S * gem::ring::STAGE;
+    const int grid = ((M + gem::ring::BM - 1) / gem::ring::BM) * (N / gem::ring::BN) * n_split, nthreads = gem::ring::NT;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    const int grid = ((M + gem::ring::BM - 1) / gem::ring::BM) * (N / gem::ring::BN) * n_split;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(gem::ring::NT), smem, 0, a);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(nthreads), smem, 0, a);
     CK(hipDeviceSynchronize());
     hipLaunchKernelGGL(ref_kernel<false>, dim3((unsigned)(((size_t)M * N + 255) / 256)), dim3(256), 0, 0, dA, dW, db, dRef, M, N, K, 10, 1,
                        (EPI == EPI_BIAS_LRELU && n_split == 1) ? 1 : 0);
@@ -157,9 +157,9 @@ static double run_ring(const char* name, int M, int N, int K, int n_split, int r
     double maxerr = 0, maxref = 0;
     for (size_t i = 0; i < got.size(); ++i) { maxerr = fmax(maxerr, fabs((double)got[i] - ref[i])); maxref = fmax(maxref, fabs((double)ref[i])); }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(k, dim3(grid), dim3(gem::ring::NT), smem, 0, a);
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(k, dim3(grid), dim3(nthreads), smem, 0, a);
     CK(hipEventRecord(e0));
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k, dim3(grid), dim3(gem::ring::NT), smem, 0, a);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k, dim3(grid), dim3(nthreads), smem, 0, a);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1e3 / reps, tf = 2.0 * M * N * K / (us * 1e-6) / 1e12;
