@@ -463,25 +463,27 @@ def main():
 
     # ---- side records (not `value`): BASELINE configs[2] -- "all 5 test-sequence shapes concurrently on 1 MI355X, bf16 VAE
     # decoder / fp32 energy": 20 + 27 + 27 + 27 + 27 = 128 chunks = 1536 windows in ONE call, fp32 and bf16 -- and configs[3]'s
-    # per-GPU shard -- 8192 windows (683 chunks = 8196), bf16 -- each with the roofline of its own dominant kernels (HIP events on
+    # per-GPU shard -- exactly 8192 windows (the first 8192 of 683 chunks' 8196), bf16 -- each with the roofline of its own dominant kernels (HIP events on
     # the launch stream; kernel names as recorded by the library at launch time)
-    def side_record(nc2, modes, seed, what):
+    def side_record(nc2, modes, seed, what, limit=None):
         rec_all = {}
-        B2 = nc2 * len(window_starts(CHUNK))
+        B_all = nc2 * len(window_starts(CHUNK))
+        B2 = min(limit or B_all, B_all)            # `limit`: the first B2 windows only (the last chunk may then be incomplete)
         seq2 = synth.make_sequence_device(nc2 * CHUNK, seed=seed, device=device, camera=cam, cam_jitter=CAM_JITTER)
-        starts2 = np.concatenate([c * CHUNK + window_starts(CHUNK) for c in range(nc2)]).astype(np.int32)
+        starts2 = np.concatenate([c * CHUNK + window_starts(CHUNK) for c in range(nc2)]).astype(np.int32)[:B2]
         e2 = WindowEngine(shape, cam, max_windows=B2)
         e2.load_vae(LOCAL_STAGE, sd_local)
         e2.load_vae(GLOBAL_STAGE, sd_global)
         est_c = seq2["est_local"].reshape(nc2, CHUNK, 15, 3)
         mb2 = torch.stack([e2.mean_bone_length(est_c[c]) for c in range(nc2)])
-        mb2 = mb2[torch.as_tensor(np.repeat(np.arange(nc2), B2 // nc2), device=device)].contiguous()
+        per2 = B_all // nc2
+        mb2 = mb2[torch.as_tensor(np.repeat(np.arange(nc2), per2)[:B2], device=device)].contiguous()
+        nc_full = B2 // per2                       # whole chunks among the B2 windows: the ones the merged-sequence MPJPE is taken over
         g2 = torch.Generator().manual_seed(987)
         eps2 = torch.randn(B2, 2, shape.latent_dim, generator=g2)
         el2, eg2 = eps2[:, 0].contiguous().to(device), eps2[:, 1].contiguous().to(device)
         f02 = torch.as_tensor(starts2, device=device)
-        per2 = B2 // nc2
-        gt2 = np.concatenate([seq2["gt_global"][c * CHUNK:c * CHUNK + 8 * per2 + 2] for c in range(nc2)])
+        gt2 = np.concatenate([seq2["gt_global"][c * CHUNK:c * CHUNK + 8 * per2 + 2] for c in range(nc_full)])
         n2 = max(3, min(a.steps, 10))
         for mode in modes:
             e2.set_precision(mode)
@@ -500,7 +502,7 @@ def main():
             sn2 = stats_to_numpy(st2)
             ev2 = sn2["func_evals"].reshape(2, B2)
             gl_np = gl2.cpu().numpy()
-            opt2 = np.concatenate([final_smooth(merge_batches(gl_np[c * per2:(c + 1) * per2])) for c in range(nc2)])
+            opt2 = np.concatenate([final_smooth(merge_batches(gl_np[c * per2:(c + 1) * per2])) for c in range(nc_full)])
             rec = {"windows": B2, "windows_per_s": round(B2 * n2 / dt, 1), "ms_per_step": round(dt / n2 * 1e3, 3), "steps": n2,
                    "evals_per_stage": {"local_mean": round(float(ev2[0].mean()), 2), "global_mean": round(float(ev2[1].mean()), 2)},
                    "mpjpe_optimised_mm": round(mpjpe(opt2, gt2) * 1e3, 3), "all_finished": bool(sn2["finished"].all()),
@@ -539,9 +541,9 @@ def main():
                                "BASELINE configs[2]: five sequences of 20+27+27+27+27 chunks = %d windows in one call, local+global "
                                "stage, bf16 = bf16 decoder activations and products / fp32 accumulate, energies and L-BFGS")
         configs3 = side_record(683, ("bf16",), 3000,
-                               "BASELINE configs[3] per-GPU shard: 683 chunks = %d windows (>= 8192) in one call, local+global stage, bf16 "
+                               "BASELINE configs[3] per-GPU shard: the first %d windows of 683 chunks in one call, local+global stage, bf16 "
                                "decoder activations and products / fp32 accumulate, energies and L-BFGS; the 8-GPU leg of this "
-                               "config is `bench.py --gpus 8 --workload configs3`")
+                               "config is `bench.py --gpus 8 --workload configs3`", limit=8192)
 
     # ---- side record (not `value`): BASELINE configs[4] -- "streaming 100k-frame sequence over 8 GPUs, hipGraph-captured":
     # the per-GPU shard, 1563 overlapping windows (stride 8) of ONE continuous 12 506-frame stream, frames stored once, no chunk
