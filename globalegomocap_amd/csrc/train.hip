@@ -386,6 +386,21 @@ static int weight_grad(gem_trainer* t, const float* dC, int ldc, const float* A,
     return 0;
 }
 
+// A linear layer over B rows (64 at the reference's batch): pure weight streaming.  The few-rows kernel (gemm_rows.h) fills the chip
+// at so few rows only when it may cut K; letting it "defer" the reduction gives it that freedom, and the slabs are summed (+ bias)
+// right behind it.
+static int linear_gemm(gem_trainer* t, const Layer& L, int epi, const float* A, int lda, float* C, int ldc, int M, hipStream_t s) {
+    gem_handle* h = t->h;
+    h->ws.defer_reduce = true;
+    const int rc = launch_gemm(h, L, epi, A, lda, nullptr, C, ldc, M, t->T, s, -1);
+    h->ws.defer_reduce = false;
+    const SlabSrc d = h->ws.deferred;
+    h->ws.deferred = SlabSrc{};
+    if (rc) return rc;
+    if (d.base) return launch_splitk_reduce(h, epi, d.nslab, d.stride, L.bias, nullptr, C, M, L.N, ldc, nullptr, s, d.dyn_W, d.n_tiles);
+    return 0;
+}
+
 }  // namespace gem
 
 using namespace gem;
@@ -534,10 +549,10 @@ int gem_trainer_step(gem_trainer* t, int B, const float* d_pose, const float* d_
     const float* in = t->pose_p;
     for (auto& c : t->enc) { if (conv_fwd(c, in)) return 1; in = c.out; }
     { Layer L; L.taps = 1; L.K = t->fc.K; L.N = t->fc.N; L.w = t->P + t->fc.ow; L.bias = t->P + t->fc.ob;
-      if (launch_gemm(h, L, EPI_BIAS, in, L.K, nullptr, t->mulv, L.N, B, T, s, -1)) return 1; }
+      if (linear_gemm(t, L, EPI_BIAS, in, L.K, t->mulv, L.N, B, s)) return 1; }
     if (launch_reparam(t->mulv, d_eps, nullptr, nullptr, nullptr, t->z, B, t->D, t->Dp, s)) return 1;
     { Layer L; L.taps = 1; L.K = t->dec_in.K; L.N = t->dec_in.N; L.w = t->P + t->dec_in.ow; L.bias = t->P + t->dec_in.ob;
-      if (launch_gemm(h, L, EPI_BIAS, t->z, L.K, nullptr, t->h0, L.N, B, T, s, -1)) return 1; }
+      if (linear_gemm(t, L, EPI_BIAS, t->z, L.K, t->h0, L.N, B, s)) return 1; }
     in = t->h0;
     for (auto& c : t->dec) { if (conv_fwd(c, in)) return 1; in = c.out; }
     const float* X = t->dec.back().out;
@@ -574,7 +589,7 @@ int gem_trainer_step(gem_trainer* t, int B, const float* d_pose, const float* d_
       hipLaunchKernelGGL(colsum_kernel, dim3(l.N / 16), dim3(BN_THREADS), 0, s, (const float*)g, B, l.N, t->G + l.ob);
       if (weight_grad<1>(t, g, l.N, t->z, l.K, B, l.N, l.K, l.ow, l.slab, TN_ROWS_LINEAR, s)) return 1;
       Layer L; L.taps = 1; L.K = l.N; L.N = l.K; L.w = l.adj; L.bias = nullptr;
-      if (launch_gemm(h, L, EPI_NONE, g, l.N, nullptr, t->dz, l.K, B, T, s, -1)) return 1; }
+      if (linear_gemm(t, L, EPI_NONE, g, l.N, t->dz, l.K, B, s)) return 1; }
     hipLaunchKernelGGL(latent_bwd_kernel, dim3(n_pl), dim3(LOSS_BLOCK), 0, s, (const float*)t->mulv, d_eps, (const float*)t->dz, B, t->D, t->Dp,
                        (float)(o->kld_weight / B), t->dmulv, part_latent);
     hipLaunchKernelGGL(finish_loss_kernel, dim3(1), dim3(256), 0, s, (const double*)part_recon, n_pr, (const double*)part_latent, n_pl, n_recon,
@@ -587,7 +602,7 @@ int gem_trainer_step(gem_trainer* t, int B, const float* d_pose, const float* d_
       if (weight_grad<1>(t, t->dmulv, l.N, flat, l.K, B, l.N, l.K, l.ow, l.slab, TN_ROWS_LINEAR, s)) return 1;
       Layer L; L.taps = 1; L.K = l.N; L.N = l.K; L.w = l.adj; L.bias = nullptr;
       g = t->gA; g2 = t->gB;
-      if (launch_gemm(h, L, EPI_NONE, t->dmulv, l.N, nullptr, g, l.K, B, T, s, -1)) return 1; }
+      if (linear_gemm(t, L, EPI_NONE, t->dmulv, l.N, g, l.K, B, s)) return 1; }
     // encoder
     for (int i = (int)t->enc.size() - 1; i >= 0; --i) {
         TrainConv& c = t->enc[i];

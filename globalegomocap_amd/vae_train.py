@@ -200,6 +200,8 @@ class VAETrainer:
         cfg.max_windows, cfg.device = self.batch_size, self.device.index
         self._t = C.c_void_p()
         _capi.check(self.lib.gem_trainer_create(C.byref(cfg), C.byref(self._t)), self.lib)
+        import weakref
+        self._finalizer = weakref.finalize(self, VAETrainer._destroy, self.lib, self._t)
         n, ns = C.c_int64(), C.c_int64()
         _capi.check(self.lib.gem_trainer_sizes(self._t, C.byref(n), C.byref(ns)), self.lib)
         self.n_params, self.n_stats = n.value, ns.value
@@ -218,15 +220,15 @@ class VAETrainer:
         self.load_state_dict(state_dict if state_dict is not None else initial_state_dict(self.shape, seed))
 
     def close(self):
-        if getattr(self, "_t", None) is not None and self._t.value:
-            self.lib.gem_trainer_destroy(self._t)
-            self._t = C.c_void_p()
+        """Free the device memory.  Also runs (through weakref.finalize) when the trainer is collected or -- before the HIP runtime
+        is torn down -- at interpreter exit: destroying a handle from __del__ during shutdown can hang under a profiler."""
+        self._finalizer()
 
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
+    @staticmethod
+    def _destroy(lib, handle):
+        if handle.value:
+            lib.gem_trainer_destroy(handle)
+            handle.value = None
 
     # ---- parameters
     def _up(self, what, arr):
