@@ -177,8 +177,13 @@ def test_two_rank_data_parallel_steps_equal_the_mean_gradient_step(tmp_path):
     script = tmp_path / "dp.py"
     script.write_text(DP_SCRIPT % root)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import socket
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29631", str(script), str(tmp_path / "dp")], capture_output=True, text=True, timeout=600, env=env)
+                        "--master-port", str(port), str(script), str(tmp_path / "dp")], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     a, b = np.load(str(tmp_path / "dp.rank0.npz")), np.load(str(tmp_path / "dp.rank1.npz"))
     shape = vae_schema.VAEShape(latent_dim=64, hidden=(32, 64))
