@@ -716,7 +716,6 @@ def main():
             # train-mode forward, loss, backward incl. weight gradients, Adam -- all on the device, against the torch-CPU port
             from globalegomocap_amd import synth as synth_mod
             from globalegomocap_amd.vae_train import VAETrainer, initial_state_dict
-            from oracle.torch_port import TrainPort
             tb = 64
             init = initial_state_dict(shape, 0)
             tw = synth_mod.make_training_windows(tb, shape.seq_len, 0)
@@ -735,21 +734,24 @@ def main():
             ms = e0.elapsed_time(e1) / 20
             n_par = trn.n_params
             trn.close()
-            nthreads = torch.get_num_threads()
-            port = TrainPort(init, lr=1e-4)
-            port.step(tw, te, 0.01)
-            t0 = time.perf_counter()
-            for _ in range(3):
-                port.step(tw, te, 0.01)
-            cpu_ms = (time.perf_counter() - t0) / 3 * 1e3
             # algorithmic HBM bytes of a step: Adam reads p, g, m, v and writes p, m, v; forward and backward-data read every weight
             # once each; the weight gradients are written once (activations are small beside the 130 MB arena at this batch)
             alg_bytes = n_par * 4 * (7 + 2 + 1)
             train = {"batch": tb, "ms_per_step": round(ms, 4), "windows_per_s": round(tb / ms * 1e3, 1), "parameters_padded": int(n_par),
                      "algorithmic_bytes_per_step": int(alg_bytes), "achieved_GBps": round(alg_bytes / ms / 1e6, 1),
-                     "frac_of_hbm_peak": round(alg_bytes / ms / 1e6 / PEAK_HBM_GBPS, 4),
-                     "cpu_port_ms_per_step": round(cpu_ms, 1), "cpu_cores": int(nthreads),
-                     "note": "fp32; torch-CPU port = oracle/torch_port.TrainPort (autograd + torch.optim.Adam), 3 steps"}
+                     "frac_of_hbm_peak": round(alg_bytes / ms / 1e6 / PEAK_HBM_GBPS, 4), "dtype": "f32", "cpu_baseline": None}
+            if a.cpu_windows > 0:          # the cpu_baseline leg of this record: the torch-CPU port of the same step on the host cores
+                from oracle.torch_port import TrainPort
+                nthreads = torch.get_num_threads()
+                port = TrainPort(init, lr=1e-4)
+                port.step(tw, te, 0.01)
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    port.step(tw, te, 0.01)
+                cpu_ms = (time.perf_counter() - t0) / 3 * 1e3
+                train["cpu_baseline"] = {"value": round(cpu_ms, 1), "unit": "ms/step", "cores": int(nthreads), "kind": "port",
+                                         "sample": "3 steps of the same batch: oracle/torch_port.TrainPort (autograd + torch.optim.Adam), torch %s CPU"
+                                                   % torch.__version__}
         total_windows = B * world * a.steps
         line = {
             "metric": "optimised windows/sec (10-frame, 15-joint)",
