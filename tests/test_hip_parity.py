@@ -1149,3 +1149,31 @@ def test_texel_block_cache_does_not_change_a_bit(torch_cuda, golden):
         assert torch.equal(res[0][0], res[2][0])
         assert res[0][1].cpu().numpy()[:, 1].mean() > 20         # the stages really iterate
         eng.close()
+
+
+def test_empty_batches_are_no_ops(torch_cuda):
+    """B = 0 (a rank whose shard is empty, a chunk shorter than one window): every entry point returns empty outputs, launches
+    nothing that could fault, and leaves the engine usable."""
+    import torch
+    from globalegomocap_amd.engine import WindowEngine, energy_weights
+    from globalegomocap_amd.camera import FisheyeCamera, DEFAULT_CALIBRATION
+    eng = WindowEngine(TINY, max_windows=16)
+    sd = vae_schema.synthetic_state_dict(TINY, 1)
+    eng.load_vae(0, sd)
+    eng.load_vae(1, sd)
+    seq = synth.make_sequence_device(30, seed=1, device=eng.device, camera=FisheyeCamera.from_json(DEFAULT_CALIBRATION))
+    f0 = torch.zeros(0, dtype=torch.int32, device=eng.device)
+    none = torch.zeros(0, TINY.latent_dim, device=eng.device)
+    wl, wg = energy_weights(1e-6, 1e-5, 1e-2, 0, 1e-2), energy_weights(1e-2, 1e-3, 1e-2, 0, 0)
+    mid, glob, stats = eng.optimize_windows(seq["est_local"], seq["cams"], seq["heat"], f0, torch.zeros(0, 15, device=eng.device), none, none, wl, wg)
+    assert tuple(mid.shape) == (0, 10, 15, 3) and tuple(glob.shape) == (0, 10, 15, 3) and stats.shape[0] == 0
+    assert tuple(eng.decode(0, none).shape) == (0, 10, 15, 3)
+    assert tuple(eng.encode(0, torch.zeros(0, 10, 45, device=eng.device))[0].shape) == (0, TINY.latent_dim)
+    # ... and a real call afterwards still works
+    f1 = torch.as_tensor([0, 8], dtype=torch.int32, device=eng.device)
+    mb = eng.mean_bone_length(seq["est_local"]).reshape(1, 15).expand(2, 15).contiguous()
+    e2 = torch.randn(2, TINY.latent_dim, device=eng.device)
+    _, g2, st = eng.optimize_windows(seq["est_local"], seq["cams"], seq["heat"], f1, mb, e2, e2, wl, wg)
+    torch.cuda.synchronize()
+    assert torch.isfinite(g2).all()
+    eng.close()
