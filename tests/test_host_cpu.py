@@ -52,6 +52,9 @@ def test_no_gpu_means_no_silent_fallback():
     from globalegomocap_amd.engine import WindowEngine
     with pytest.raises(_capi.GemError):
         WindowEngine(TINY)
+    from globalegomocap_amd.vae_train import VAETrainer
+    with pytest.raises(_capi.GemError, match="no CPU path"):
+        VAETrainer(TINY, batch_size=8)
 
 
 def test_product_package_never_imports_the_oracle():
