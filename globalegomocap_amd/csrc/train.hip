@@ -1,6 +1,7 @@
 // Training step of the motion VAE on the device: the loop body of networks/train.py:65-108 --
 // forward in TRAIN mode (BatchNorm batch statistics, running statistics updated), the VAE loss of
-// networks/models/SeqConvVAE.py:191-219 (M_N form: mean-squared reconstruction error + kld_weight * KL), backward (data AND
+// networks/models/SeqConvVAE.py:191-219 (M_N form: mean-squared reconstruction error + kld_weight * KL; kl_weight form: summed
+// squared error, opts.recon_sum), backward (data AND
 // weight gradients) and one torch.optim.Adam step (L2 weight decay folded into the gradient, bias-corrected moments).
 //
 // Parameters live in ONE fp32 arena in the padded, packed layouts the GEMM kernels read directly (every conv as its equivalent
