@@ -55,8 +55,9 @@ def parse():
     p.add_argument("--no-profile", action="store_true", help="no HIP-event timing of the dominant kernel")
     p.add_argument("--precision", default=None, choices=["f32", "bf16x3", "bf16"],
                    help="arithmetic of the wide decoder/encoder products (f32 = BASELINE configs[1])")
-    p.add_argument("--vae", default="fit", choices=["fit", "structured"],
-                   help="synthetic VAE weights: 'fit' = briefly fitted with Adam on synthetic motion (default, as in round 1); "
+    p.add_argument("--vae", default="fit", choices=["fit", "fit-device", "structured"],
+                   help="synthetic VAE weights: 'fit' = briefly fitted with Adam on synthetic motion (default, as in round 1; PyTorch "
+                        "autograd); 'fit-device' = the same recipe through the HIP trainer (gem_trainer_*, SURVEY 8 f.4); "
                         "'structured' = vae.structured_state_dict, the deterministic well-conditioned VAEs of the full-size "
                         "reference golden (no fitting kernels: profiling runs)")
     p.add_argument("--weights-cache", default=None, help="torch file to load/store the fitted synthetic VAEs (keeps the "
@@ -67,10 +68,13 @@ def parse():
     return a
 
 
-def fit_weights(shape, seed, device, steps, relative):
-    """Untimed: synthetic well-conditioned VAE in the reference's checkpoint schema."""
+def fit_weights(shape, seed, device, steps, relative, on_device=False):
+    """Untimed: synthetic well-conditioned VAE in the reference's checkpoint schema (on_device: fitted by the HIP trainer)."""
     from globalegomocap_amd import synth
-    from globalegomocap_amd.vae_torch import fit_vae
+    if on_device:
+        from globalegomocap_amd.vae_train import fit_vae_device as fit_vae
+    else:
+        from globalegomocap_amd.vae_torch import fit_vae
     win = synth.make_training_windows(4096, shape.seq_len, seed)
     if relative:        # relative-global poses drift with the (true) camera: 4 mm / frame along x
         win = win.reshape(-1, shape.seq_len, 15, 3).copy()
@@ -337,12 +341,12 @@ def main():
     elif a.weights_cache and os.path.exists(a.weights_cache):
         sd_local, err_l, sd_global, err_g = torch.load(a.weights_cache, weights_only=False)
     else:
-        sd_local, err_l = fit_weights(shape, 101, device, a.fit_steps, relative=False)
-        sd_global, err_g = fit_weights(shape, 102, device, a.fit_steps, relative=True)
+        sd_local, err_l = fit_weights(shape, 101, device, a.fit_steps, relative=False, on_device=a.vae == "fit-device")
+        sd_global, err_g = fit_weights(shape, 102, device, a.fit_steps, relative=True, on_device=a.vae == "fit-device")
         if a.weights_cache and rank == 0:
             torch.save((sd_local, err_l, sd_global, err_g), a.weights_cache)
     if a.workload in ("configs3", "configs4"):
-        note = ("synthetic, fitted %d Adam steps (recon %.1f / %.1f mm)" % (a.fit_steps, err_l * 1e3, err_g * 1e3)) if a.vae == "fit" else "synthetic, structured"
+        note = ("synthetic, fitted %d Adam steps (recon %.1f / %.1f mm)" % (a.fit_steps, err_l * 1e3, err_g * 1e3)) if a.vae != "structured" else "synthetic, structured"
         return run_sharded(a, world, rank, device, rehearsal, sd_local, sd_global, note)
     n_frames = n_chunks * CHUNK
     seqd = synth.make_sequence_device(n_frames, seed=1000 + rank, device=device, camera=cam, cam_jitter=CAM_JITTER)
@@ -771,7 +775,8 @@ def main():
                        "windows_per_gpu": B, "latent_dim": shape.latent_dim, "parallelism": "window-shards x%d" % world,
                        "ranks": world, "backend": dist.get_backend() if world > 1 else None,
                        "vae": ("synthetic, fitted %d Adam steps (recon %.1f / %.1f mm)" % (a.fit_steps, err_l * 1e3, err_g * 1e3))
-                              if a.vae == "fit" else "synthetic, structured (vae.structured_state_dict seeds 7 / 8)"},
+                              + (" by the HIP trainer" if a.vae == "fit-device" else "")
+                              if a.vae != "structured" else "synthetic, structured (vae.structured_state_dict seeds 7 / 8)"},
             "evals_per_stage": {"local_mean": float(evals[0].mean()), "global_mean": float(evals[1].mean()),
                                 "min": int(evals.min()), "max": int(evals.max())},
             "mpjpe_mm": {"input": round(mp_in * 1e3, 3), "optimised": round(mp_opt * 1e3, 3)},

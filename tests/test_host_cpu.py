@@ -249,4 +249,10 @@ def test_trainer_arena_layout_roundtrip_and_padding():
     init = initial_state_dict(shape, 0)
     assert np.abs(init["encoder.0.0.weight"]).max() <= 1 / np.sqrt(45 * 3) and np.abs(init["fc_mu.bias"]).max() <= 1 / np.sqrt(72 * 10)
     assert np.abs(init["decoder.0.0.weight"]).max() <= 1 / np.sqrt(40 * 3)          # ConvTranspose1d [72, 40, 3]: fan_in = 40 * 3
-    assert np.all(init["encoder.1.1.weight"] == 1) and np.all(init["encoder.1.1.running_var"] == 1)
+    assert np.all(init["encoder.1.1.weight"] == 1) and np.all(init["encoder.1.1.running_var"] == 1) and np.all(init["decoder.1.1.bias"] == 0)
+    # every conv / linear tensor is drawn (the BatchNorm rule must not catch "encoder.1.0.weight"): uniform, std = bound / sqrt(3)
+    for k, v in init.items():
+        if k.endswith(".0.weight") or k.endswith(".3.weight") or k.startswith(("fc_", "decoder_input")):
+            fan_in = v.shape[1] * (v.shape[2] if v.ndim == 3 else 1) if k.endswith("weight") else None
+            if fan_in:
+                assert abs(v.std() * np.sqrt(3 * fan_in) - 1) < 0.1, k
