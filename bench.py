@@ -43,7 +43,7 @@ def parse():
                    "chunks> | configs3 (65536 windows sharded over the ranks, bf16, strong scaling) | configs4 (12499 overlapping windows of "
                    "one 100k-frame stream, block-cyclic shards, hipGraph replay, strong scaling)")
     p.add_argument("--lanes", type=int, default=None, help="gem_set_lanes: batches of at least this many windows run as two half-batches "
-                   "half a round apart (library default 4352; 0 = one lane always)")
+                   "half a round apart (0 = one lane always = the library default)")
     p.add_argument("--windows", type=int, default=0, help="configs3 / configs4: total number of windows (default 65536 / 12499)")
     p.add_argument("--block", type=int, default=64, help="configs4: windows per block of the block-cyclic shards")
     p.add_argument("--emulate-ranks", type=int, default=0, help="configs3 / configs4 with --gpus 1: run the shards of N ranks one after "

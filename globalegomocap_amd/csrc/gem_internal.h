@@ -242,7 +242,8 @@ struct gem_handle {
                                                                      // would sit between the lanes' kernels)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join_a = nullptr;
     std::vector<hipEvent_t> ev_pool;
-    int lanes_min = 4352;          // gem_set_lanes: batches of at least this many windows run as two lanes (0: never)
+    int lanes_min = 0;             // gem_set_lanes: batches of at least this many windows run as two lanes (0: never = the default
+                                   // since round 4: with two tail workgroups per CU one lane is the faster arrangement)
     int last_split = 0;            // windows in the first lane of the last gem_optimize_windows call (0: one lane)
 };
 
@@ -360,7 +361,8 @@ struct TailArgs {
 };
 size_t plan_tail(const std::vector<Layer>& dec, int start, int T, int J, TailArgs* out);
 
-// bf16 multi-window fused tail (tail_bf16.hip): G = min(8, 80 / T) windows = up to 80 rows (five 16-row MFMA tiles) per workgroup
+// bf16 multi-window fused tail (tail_bf16.hip): G = min(8, 80 / T) windows = up to 80 rows (five 16-row MFMA tiles) per workgroup,
+// two workgroups per CU (<= 80 KB of LDS, <= 128 VGPRs)
 constexpr int TB_MAX_LAYERS = 6;
 struct TailB16Layer { int K, N; const float* bias; };
 struct TailB16Args {
@@ -375,9 +377,13 @@ struct TailB16Args {
     const uint16_t* wstream;   // StageNet::tb_stream
     int steps_f, steps_total;  // steps (1 KB fragments) per wave: forward part / forward + adjoint
     TailB16Layer fwd[TB_MAX_LAYERS], bwd[TB_MAX_LAYERS];
-    // LDS plan, byte offsets / row strides in bytes (row stride = 2 * width + 32: conflict-free ds_read_b128 fragment reads)
-    int off_act[TB_MAX_LAYERS + 1], ld_act[TB_MAX_LAYERS + 1];      // act[0] = input (region shared with the energy scratch / output staging)
-    int off_g[2], ld_g[2], off_x, off_escr, escr, off_zero, off_mask, ld_mask, off_tab;
+    // LDS plan, byte offsets / row strides in bytes (row stride = 2 * width + 32: conflict-free ds_read_b128 fragment reads).
+    // Two ping-pong buffers: act[j] and, in the backward direction, the gradient w.r.t. act[j] both live in buffer j & 1 (the
+    // activations are dead by then: LeakyReLU' comes from one sign BIT per element, kept in mask[j]); the decoded pose (fp32, dense
+    // per window) sits above the activations of act[n-1]'s buffer.
+    int off_act[TB_MAX_LAYERS + 1], ld_act[TB_MAX_LAYERS + 1];      // act[0] = input; [n]: the gradient rows w.r.t. the pose (bf16)
+    int off_mask[TB_MAX_LAYERS], ld_mask[TB_MAX_LAYERS];            // mask[0]: one byte per 8 channels; mask[j > 0]: one byte per 4
+    int off_x, escr, off_mb, off_zero, off_tab;
     EnergyArgs e;
 };
 size_t plan_tail_bf16(const std::vector<Layer>& dec, int start, int T, int J, TailB16Args* out);

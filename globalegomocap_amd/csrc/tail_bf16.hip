@@ -8,9 +8,23 @@
 //
 //   input rows (bf16 matrix, or the producer GEMM's fp32 split-K slabs: summed + bias + LeakyReLU on the way in) -> LDS (bf16)
 //   for each fused layer:  act[i+1] = lrelu(conv3(act[i]) + b)      v_mfma_f32_16x16x32_bf16, fp32 accumulate, bf16 in LDS
-//   X = act[n] (fp32) -> energy terms + dE/dX per window, one wavefront per window, fp32 (energy_device.h)
-//   backward-data through the same layers, LeakyReLU' from the sign of the LDS activations
+//   X = act[n] (fp32) -> energy terms + dE/dX per window, one wavefront per window, fp32 (energy_pairs.h)
+//   backward-data through the same layers, LeakyReLU' from one sign bit per activation element
 //   -> gradient w.r.t. the input's pre-activation, bf16, staged through LDS and written out as whole rows.
+//
+// Round 4: TWO workgroups per CU.  The kernel is a chain of ~12 short dependent phases (a layer is 6-24 k-steps between two
+// barriers; the energy terms are plain VALU code), so one workgroup per CU left the matrix pipe idle most of the time: 33 us per
+// workgroup against 5 us of MFMA work.  A second, independent workgroup on the CU fills those gaps -- its MFMA phases run beside
+// this one's energy / epilogue / barrier phases -- which needs <= 80 KB of LDS and <= 128 VGPRs per workgroup:
+//   * LDS (77 KB at the reference's widths, was 159 KB): two ping-pong buffers P (as wide as the input) and Q (as wide as act[1]).
+//     act[j] lives in buffer j & 1 and is overwritten two layers later; what the backward direction needs of it -- the sign of
+//     every element -- is kept as one BIT per element (a byte per 8 channels for the staged input, per 4 for the layers' own
+//     outputs: the four consecutive channels a lane owns).  The gradient w.r.t. act[j] goes to buffer j & 1 as well; the decoded
+//     pose (fp32, dense per window) sits behind act[n-1] in that activation's buffer; the energy terms need no scratch
+//     (energy_pairs.h recomputes neighbours instead of storing three arrays per window).
+//   * VGPRs: the activation fragments are refreshed in place right behind the MFMA that used them (was a register double buffer),
+//     the inputs of the energy terms are requested in front of the LAST forward layer (the cheapest one) instead of at kernel
+//     start, the slab-summing input path stages two chunks per thread and trip (was five).
 //
 // MFMA operands: the WEIGHT fragment is operand A (rows n), the activation fragment operand B (columns m): D[n][m], so a lane
 // ends up with 4 consecutive output channels of ONE row = one 8-byte bf16 store into the next layer's LDS image.  Activation
@@ -19,16 +33,16 @@
 // immediate offset.  The k=3 conv reads rows t-1, t, t+1 of the same window; rows outside it read a zero line (address select).
 // Weights never touch LDS: at load time every layer is cut into the 1 KB fragments (64 lanes x 8 bf16) each wave will need, in
 // the order it will need them (build_tail_bf16_stream), so a wave walks ONE contiguous stream -- forward layers, then adjoint
-// layers -- with a ring of six fragments in registers, requested six K-steps (~500 MFMA cycles) ahead, across layer boundaries,
-// barriers and the energy phase.  Wave w owns output channels 16w..16w+15 (+128 per extra tile) and all five row tiles; in a
-// 64-wide layer waves w and w+4 share a channel tile and split the row tiles 3 + 2.
+// layers -- with a ring of six fragments in registers, requested six K-steps ahead, across layer boundaries, barriers and the
+// energy phase.  Wave w owns output channels 16w..16w+15 (+128 per extra tile) and all five row tiles; in a 64-wide layer waves
+// w and w+4 share a channel tile and split the row tiles 3 + 2.
 //
 // Reference semantics: ConvTranspose1d/Conv1d k=3 s=1 p=1 + BatchNorm(eval) + LeakyReLU of networks/models/SeqConvVAE.py:76-92
 // (folded at load time), decode_to_bodypose :131-140, total_loss of optimizer.py:226-240, backward-DATA only (frozen VAE).
 #include <algorithm>
 #include <cstring>
 
-#include "energy_device.h"
+#include "energy_pairs.h"
 
 namespace gem {
 
@@ -42,7 +56,6 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int WAVES = 8, THREADS = WAVES * 64;
 constexpr int NRT = 5, ROWS = NRT * 16;        // row tiles / rows per workgroup
-constexpr int RING = 6;                        // weight fragments in flight per wave
 constexpr int ZERO_BYTES = 1024 + 64;          // the zero line covers the K walk of the widest layer (K = 512: 1024 bytes)
 
 __device__ __forceinline__ unsigned int pack2(float lo, float hi) {      // round-to-nearest-even (v_cvt_pk_bf16_f32)
@@ -51,72 +64,76 @@ __device__ __forceinline__ unsigned int pack2(float lo, float hi) {      // roun
     return __builtin_bit_cast(unsigned int, __builtin_convertvector(f2{lo, hi}, bf2));
 }
 __device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : v * LEAKY_SLOPE; }
+// bit e of the result: the e-th of four packed bf16 values (two dwords) is > 0 (sign bit clear and not zero)
+__device__ __forceinline__ unsigned int pos_bits(unsigned int d0, unsigned int d1) {
+    const unsigned int a = d0 & 0xFFFFu, b = d0 >> 16, c = d1 & 0xFFFFu, d = d1 >> 16;
+    return ((a != 0u && a < 0x8000u) ? 1u : 0u) | ((b != 0u && b < 0x8000u) ? 2u : 0u) | ((c != 0u && c < 0x8000u) ? 4u : 0u) |
+           ((d != 0u && d < 0x8000u) ? 8u : 0u);
+}
 
 // LDS writes of this wave done, then the workgroup barrier.  (Not __syncthreads: the weight ring's global loads stay in
 // flight across the barrier.)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// One fused layer for this wave: D[n][m] += W[n][k] . act[m][k] over 3 taps x K.
-//   CPW   column tiles (16 channels) per wave: N / 128, at least 1
+// One fused layer (one column tile of it) for this wave: D[n][m] += W[n][k] . act[m][k] over 3 taps x K.
 //   SPLIT 64-wide layer: waves w and w + 4 share column tile w & 3; w < 4 takes row tiles 0-2, w >= 4 row tiles 3-4
 // The K walk is k-block major, taps inner (the weight stream is packed in the same order): a body of 6 k-steps covers two whole
-// k-blocks, so taps and ring slots are compile-time.  epi(c, tile, acc) gets the accumulator of column tile c
-// (channels 16 * ct + 4 * (lane >> 4) + 0..3) and row tile `tile` (row 16 * tile + (lane & 15)).
-template <int CPW, bool SPLIT, typename Epi>
-__device__ __forceinline__ void gemm_layer(const unsigned char* lds, int in_off, int in_ld, int zero_off, int K, int T, int R,
+// k-blocks, so taps and ring slots are compile-time.  epi(tile, acc) gets the accumulator of row tile `tile`
+// (row 16 * tile + (lane & 15), channels col0 + 4 * (lane >> 4) + 0..3).
+// rowbits: 3 bits per row tile of this lane's row (16 * tile + (lane & 15)): bit 0 = the row exists (< R), bit 1 / 2 = its frame
+// has a predecessor / successor inside the window (taps 0 / 2; computed once per kernel, no division per layer).
+// RING: weight fragments in flight per wave (6 or 3); AFD: 2 = the activation fragments of the next k-step are read into a second
+// register set (one workgroup per CU: nothing else covers the LDS latency), 1 = refreshed in place right behind the MFMA that used
+// them (two workgroups per CU: 20 registers less).
+template <bool SPLIT, int RING, int AFD, typename Epi>
+__device__ __forceinline__ void gemm_layer(const unsigned char* lds, int in_off, int in_ld, int zero_off, int K, unsigned int rowbits,
                                            bf16x8 (&ring)[RING], const bf16x8* __restrict__ wp, int& consumed, int last_step, Epi epi) {
     constexpr int NR = SPLIT ? 3 : NRT;
-    static_assert(CPW == 1 || CPW == 2, "one or two column tiles per wave");
-    constexpr int KS = 6;                             // k-steps (32 deep) per unrolled body = two whole k-blocks x 3 taps (even: the
-    constexpr int U = KS * CPW;                       // register double buffer of the activation fragments keeps its parity)
+    constexpr int KS = 6;                             // k-steps (32 deep) per unrolled body = two whole k-blocks x 3 taps
+    static_assert(KS % RING == 0, "ring slots must be compile-time inside the unrolled body");
+    static_assert(AFD == 1 || AFD == 2, "in place or double-buffered");
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r16 = lane & 15, q = lane >> 4;
     const int tile0 = SPLIT ? 3 * (wave >> 2) : 0;
+    const unsigned int bits = rowbits >> (3 * tile0);
     // fragment read addresses per tap and row tile (bytes); invalid rows (outside the window: the conv's zero padding; past R;
     // the absent sixth tile of the split) read the zero line -- selecting the ADDRESS keeps the reads in flight behind the MFMAs
     int base[3][NR];
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
         const int row = 16 * (tile0 + i) + r16;
-        const int t = row % T;
-        const bool ok = (tile0 + i) < NRT && row < R;
-#pragma unroll
-        for (int tap = 0; tap < 3; ++tap) {
-            const int tt = t + tap - 1;
-            base[tap][i] = (ok && tt >= 0 && tt < T) ? in_off + (row + tap - 1) * in_ld + q * 16 : zero_off + q * 16;
-        }
+        const unsigned int b3 = (bits >> (3 * i)) & 7u;
+        const bool ok = (b3 & 1u) != 0u;
+        const int mid = in_off + row * in_ld + q * 16;
+        base[0][i] = (ok && (b3 & 2u)) ? mid - in_ld : zero_off + q * 16;
+        base[1][i] = ok ? mid : zero_off + q * 16;
+        base[2][i] = (ok && (b3 & 4u)) ? mid + in_ld : zero_off + q * 16;
     }
-    f32x4 acc[CPW][NR];
+    f32x4 acc[NR];
 #pragma unroll
-    for (int c = 0; c < CPW; ++c)
-#pragma unroll
-        for (int i = 0; i < NR; ++i) acc[c][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int nsteps = (3 * K / 32) * CPW;
-    // Program order = issue order (sched_barrier between the groups; left alone, the compiler sinks all six ring refills to the
-    // end of the body, which halves the distance the stream runs ahead): every MFMA is followed by the fragment read of the
-    // NEXT k-step for the same row tile, every k-step by the refill of the ring slot it has just used.  The activation
-    // fragments are double-buffered in registers; the body's last k-step reads the first fragments of the next body (past the
-    // last k-block of the layer that is 16 bytes of row padding / the neighbouring row: read, never used).
-    bf16x8 af[2][NR];
+    for (int i = 0; i < NR; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nsteps = 3 * K / 32;
+    // Program order = issue order (sched_barrier between the groups; left alone, the compiler sinks all ring refills to the end of
+    // the body, which halves the distance the stream runs ahead): every MFMA is followed by the read of the NEXT k-step's
+    // activation fragment for the same row tile, every k-step by the refill of the ring slot it has just used.  The body's last
+    // k-step reads the first fragments of the next body (past the last k-block of the layer that is 16 bytes of row padding /
+    // the neighbouring row: read, never used).
+    bf16x8 af[AFD][NR];
 #pragma unroll
     for (int i = 0; i < NR; ++i) af[0][i] = *reinterpret_cast<const bf16x8*>(lds + base[0][i]);
-    for (int s0 = 0; s0 < nsteps; s0 += U) {
+    for (int s0 = 0; s0 < nsteps; s0 += KS) {
 #pragma unroll
         for (int j = 0; j < KS; ++j) {                // k-step j of the body: tap j % 3 of k-block j / 3
             const int jn = j + 1;                     // next k-step (jn == KS: tap 0 of the next body's first k-block)
 #pragma unroll
-            for (int c = 0; c < CPW; ++c) {
-                const int u = j * CPW + c;            // step of the body (compile time after unrolling)
-#pragma unroll
-                for (int i = 0; i < NR; ++i) {
-                    acc[c][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring[u % RING], af[j & 1][i], acc[c][i], 0, 0, 0);
-                    if (c == CPW - 1) af[jn & 1][i] = *reinterpret_cast<const bf16x8*>(lds + base[jn % 3][i] + (jn / 3) * 64);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                // refill the slot six steps ahead (past the end of the stream: a harmless re-load of the last fragment)
-                ring[u % RING] = wp[(size_t)min(consumed + s0 + u + RING, last_step) * 64];
+            for (int i = 0; i < NR; ++i) {
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring[j % RING], af[j % AFD][i], acc[i], 0, 0, 0);
+                af[jn % AFD][i] = *reinterpret_cast<const bf16x8*>(lds + base[jn % 3][i] + (jn / 3) * 64);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            // refill the slot RING steps ahead (past the end of the stream: a harmless re-load of the last fragment)
+            ring[j % RING] = wp[(size_t)min(consumed + s0 + j + RING, last_step) * 64 + lane];
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int tap = 0; tap < 3; ++tap)
@@ -125,33 +142,128 @@ __device__ __forceinline__ void gemm_layer(const unsigned char* lds, int in_off,
     }
     consumed += nsteps;
 #pragma unroll
-    for (int c = 0; c < CPW; ++c)
-#pragma unroll
-        for (int i = 0; i < NR; ++i)
-            if (tile0 + i < NRT) epi(c, tile0 + i, acc[c][i]);
+    for (int i = 0; i < NR; ++i)
+        if (tile0 + i < NRT) epi(tile0 + i, acc[i]);
 }
 
-template <typename Epi>
-__device__ __forceinline__ void gemm_dispatch(const unsigned char* lds, int in_off, int in_ld, int zero_off, int K, int N, int T, int R,
+// N is 64, 128 or 256 (plan_tail_bf16).  A 256-wide layer runs as two passes over K, one per 128 channels (twice the fragment
+// reads, half the accumulators: the kernel has to stay under 128 VGPRs); the weight stream is packed pass by pass.
+// epi(col0, tile, acc): col0 = first channel of the wave's column tile in this pass.
+template <int RING, int AFD, typename Epi>
+__device__ __forceinline__ void gemm_dispatch(const unsigned char* lds, int in_off, int in_ld, int zero_off, int K, int N, unsigned int rowbits,
                                               bf16x8 (&ring)[RING], const bf16x8* __restrict__ wp, int& consumed, int last_step, Epi epi) {
-    // N is 64, 128 or 256 (plan_tail_bf16)
-    if (N == 64) gemm_layer<1, true>(lds, in_off, in_ld, zero_off, K, T, R, ring, wp, consumed, last_step, epi);
-    else if (N == 128) gemm_layer<1, false>(lds, in_off, in_ld, zero_off, K, T, R, ring, wp, consumed, last_step, epi);
-    else gemm_layer<2, false>(lds, in_off, in_ld, zero_off, K, T, R, ring, wp, consumed, last_step, epi);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (N == 64) {
+        const int col0 = 16 * (wave & 3);
+        gemm_layer<true, RING, AFD>(lds, in_off, in_ld, zero_off, K, rowbits, ring, wp, consumed, last_step, [&](int tile, const f32x4& acc) { epi(col0, tile, acc); });
+    } else {
+#pragma nounroll
+        for (int c = 0; c < N / 128; ++c) {
+            const int col0 = 16 * wave + 128 * c;
+            gemm_layer<false, RING, AFD>(lds, in_off, in_ld, zero_off, K, rowbits, ring, wp, consumed, last_step, [&](int tile, const f32x4& acc) { epi(col0, tile, acc); });
+        }
+    }
 }
 
-// first output channel of column tile c of this wave in a layer of N channels
-__device__ __forceinline__ int col0_of(int N, int wave, int c) { return N == 64 ? 16 * (wave & 3) : 16 * wave + 128 * c; }
+// input rows -> LDS as bf16 (+ one sign bit per element).  UN chunks (8 values) per thread and trip, all their loads in flight
+// together.  SLAB: the producer GEMM left fp32 split-K slabs: summed in slab order, bias + LeakyReLU applied here.
+// (Takes what it needs by value: handed the kernel-argument struct by reference, the UN = 5 form made the compiler keep a copy
+// of the whole struct in scratch.)
+struct StageIn {
+    const uint16_t* a_in_b;
+    const float* slab_base;
+    const float* in_bias;
+    size_t slab_stride;
+    int nslab, in_bias_ld, K0, off0, ld0, offm, ldm;
+};
+// the bf16 path: five chunks per thread and trip (80 rows x 256 channels = one trip), written without arrays
+__device__ __forceinline__ void stage_input_bf16(const StageIn si, unsigned char* lds, int tid, int R, size_t row0) {
+    const int K0 = si.K0, cpr = K0 / 8, nchunk = ROWS * cpr;
+    auto ld = [&](int idx) -> u32x4 {
+        const int r = idx / cpr, c8 = (idx - r * cpr) * 8;
+        if (idx < nchunk && r < R) return *reinterpret_cast<const u32x4*>(si.a_in_b + (row0 + r) * K0 + c8);
+        return u32x4{0u, 0u, 0u, 0u};
+    };
+    auto st = [&](int idx, const u32x4& o) {
+        if (idx >= nchunk) return;
+        const int r = idx / cpr, c8 = (idx - r * cpr) * 8;
+        *reinterpret_cast<u32x4*>(lds + si.off0 + r * si.ld0 + c8 * 2) = o;
+        lds[si.offm + r * si.ldm + (c8 >> 3)] = (unsigned char)(pos_bits(o[0], o[1]) | (pos_bits(o[2], o[3]) << 4));
+    };
+#pragma nounroll
+    for (int u0 = tid; u0 < nchunk; u0 += 5 * THREADS) {
+        const u32x4 o0 = ld(u0), o1 = ld(u0 + THREADS), o2 = ld(u0 + 2 * THREADS), o3 = ld(u0 + 3 * THREADS), o4 = ld(u0 + 4 * THREADS);
+        st(u0, o0); st(u0 + THREADS, o1); st(u0 + 2 * THREADS, o2); st(u0 + 3 * THREADS, o3); st(u0 + 4 * THREADS, o4);
+    }
+}
+template <bool SLAB, int UN>
+__device__ __forceinline__ void stage_input(const StageIn si, unsigned char* lds, int tid, int T, int R, size_t row0) {
+    const int K0 = si.K0, cpr = K0 / 8, nchunk = ROWS * cpr;
+    for (int u0 = 0; u0 < nchunk; u0 += UN * THREADS) {
+        int r[UN], c8[UN];
+        bool ok[UN];
+        u32x4 o[UN];
+#pragma unroll
+        for (int k = 0; k < UN; ++k) {
+            const int idx = u0 + k * THREADS + tid;
+            r[k] = idx / cpr; c8[k] = (idx - r[k] * cpr) * 8;
+            ok[k] = idx < nchunk && r[k] < R;
+            o[k] = u32x4{0u, 0u, 0u, 0u};
+        }
+        if (SLAB) {
+            f32x4 v0[UN], v1[UN];
+#pragma unroll
+            for (int k = 0; k < UN; ++k) {
+                const float* p = si.slab_base + (row0 + (ok[k] ? r[k] : 0)) * K0 + (ok[k] ? c8[k] : 0);
+                v0[k] = *reinterpret_cast<const f32x4*>(p); v1[k] = *reinterpret_cast<const f32x4*>(p + 4);
+            }
+            for (int z = 1; z < si.nslab; ++z) {
+                f32x4 t0[UN], t1[UN];
+#pragma unroll
+                for (int k = 0; k < UN; ++k) {
+                    const float* p = si.slab_base + (size_t)z * si.slab_stride + (row0 + (ok[k] ? r[k] : 0)) * K0 + (ok[k] ? c8[k] : 0);
+                    t0[k] = *reinterpret_cast<const f32x4*>(p); t1[k] = *reinterpret_cast<const f32x4*>(p + 4);
+                }
+#pragma unroll
+                for (int k = 0; k < UN; ++k) { v0[k] += t0[k]; v1[k] += t1[k]; }
+            }
+#pragma unroll
+            for (int k = 0; k < UN; ++k) {
+                const float* bp = si.in_bias + (ok[k] ? (r[k] % T) * si.in_bias_ld + c8[k] : 0);
+                v0[k] += *reinterpret_cast<const f32x4*>(bp); v1[k] += *reinterpret_cast<const f32x4*>(bp + 4);
+                float v[8] = {v0[k][0], v0[k][1], v0[k][2], v0[k][3], v1[k][0], v1[k][1], v1[k][2], v1[k][3]};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = lrelu(v[e]);
+                if (ok[k]) o[k] = u32x4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < UN; ++k)
+                if (ok[k]) o[k] = *reinterpret_cast<const u32x4*>(si.a_in_b + (row0 + r[k]) * K0 + c8[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < UN; ++k) {
+            if (u0 + k * THREADS + tid >= nchunk) continue;
+            *reinterpret_cast<u32x4*>(lds + si.off0 + r[k] * si.ld0 + c8[k] * 2) = o[k];
+            lds[si.offm + r[k] * si.ldm + (c8[k] >> 3)] = (unsigned char)(pos_bits(o[k][0], o[k][1]) | (pos_bits(o[k][2], o[k][3]) << 4));
+        }
+    }
+}
 
-template <int NL>
-__global__ __launch_bounds__(THREADS, 2) void decoder_tail_bf16_kernel(TailB16Args a) {
+// DENSE: built for TWO workgroups per CU (<= 128 VGPRs: a ring of three weight fragments, activation fragments refreshed in place);
+// otherwise for one (launches of at most one workgroup per CU, where nothing but the wave's own run-ahead covers a latency: ring of
+// six, double-buffered activation fragments).  Same LDS plan, same arithmetic in the same order: bitwise the same results.
+// PROBE: per-phase timestamps of workgroup 0 into a.dbg_ts (tools/tail16_bench); the product launches the probe-free instances.
+template <bool DENSE, bool PROBE>
+__global__ __launch_bounds__(THREADS, DENSE ? 4 : 2) void decoder_tail_bf16_kernel(TailB16Args a) {
+    constexpr int RING = DENSE ? 3 : 6, AFD = DENSE ? 1 : 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, q = lane >> 4;
-    const int T = a.e.T;
+    const int T = a.e.T, NL = a.n;
     int probe = 0;
 #define TB_PROBE()                                                                                     \
-    if (a.dbg_ts && blockIdx.x == 0 && tid == 0) {                                                     \
+    if (PROBE && a.dbg_ts && blockIdx.x == 0 && tid == 0) {                                            \
         a.dbg_ts[2 * probe] = clock64();                                                               \
         a.dbg_ts[2 * probe + 1] = wall_clock64();                                                      \
         ++probe;                                                                                       \
@@ -164,174 +276,133 @@ __global__ __launch_bounds__(THREADS, 2) void decoder_tail_bf16_kernel(TailB16Ar
     const size_t row0 = (size_t)w0 * T;
 
     // ---- the wave's weight stream: first six fragments requested before anything else
-    const bf16x8* wp = reinterpret_cast<const bf16x8*>(a.wstream) + (size_t)wave * a.steps_total * 64 + lane;
-    const int last_step = (a.forward_only ? a.steps_f : a.steps_total) - 1;
+    // (uniform base + lane: the fragment address is an SGPR pair plus a 32-bit lane offset, no 64-bit vector arithmetic per load)
+    const bf16x8* wp = reinterpret_cast<const bf16x8*>(a.wstream) + (size_t)wave * a.steps_total * 64;
+    // (the forward layers never request past the last forward fragment: the ring is re-primed with the adjoint layers' first
+    // fragments behind the energy terms, whose registers it would otherwise occupy -- 24 of 128)
+    int last_step = a.steps_f - 1;
     bf16x8 ring[RING];
 #pragma unroll
-    for (int i = 0; i < RING; ++i) ring[i] = wp[(size_t)min(i, last_step) * 64];
+    for (int i = 0; i < RING; ++i) ring[i] = wp[(size_t)min(i, last_step) * 64 + lane];
     int consumed = 0;
-    // ---- what the energy terms need besides the decoded pose (stage-input pose, bone lengths, cached texel blocks of this
-    // wave's window) is requested now and stays in registers across the forward layers: the energy phase then starts without
-    // a global round trip.  (The usual window shape, 10 frames x 15 joints, has compile-time index arithmetic as well.)
+    // this lane's rows 16 * tile + (lane & 15): existence and window-edge flags, once for all layers
+    unsigned int rowbits = 0;
+#pragma unroll
+    for (int i = 0; i < NRT; ++i) {
+        const int row = 16 * i + r16, t = row % T;
+        rowbits |= ((row < R ? 1u : 0u) | (t > 0 ? 2u : 0u) | (t < T - 1 ? 4u : 0u)) << (3 * i);
+    }
     const bool fast_e = T == 10 && a.e.J == 15;
-    EnergyPre<8, 3> pre;
-    const int bwin = (wave < nwin) ? (a.e.perm ? a.e.perm[w0 + wave] : w0 + wave) : 0;
-    if (fast_e && !a.forward_only && wave < nwin) energy_prefetch<10, 15>(a.e, bwin, lane, pre);
+    const int bwin = __builtin_amdgcn_readfirstlane((wave < nwin) ? (a.e.perm ? a.e.perm[w0 + wave] : w0 + wave) : 0);
     TB_PROBE();
 
-    // ---- stage the input rows as bf16 (+ one sign bit per element: the LeakyReLU' mask of the last adjoint layer; the region
-    // itself is reused by the energy terms and the output staging).  In the rounds the producer GEMM leaves fp32 split-K slabs:
-    // summed in slab order, bias + LeakyReLU applied here.
+    // ---- stage the input rows as bf16 (+ one sign bit per element: the LeakyReLU' mask of the last adjoint layer)
     {
-        const int K0 = a.fwd[0].K, cpr = K0 / 8, nchunk = ROWS * cpr;
-        int nslab = 0;
-        size_t stride = 0;
-        if (a.in_slab.base) slab_layout(a.in_slab, nslab, stride);
-        constexpr int UN = 5;                  // chunks (8 values) per thread and trip: all their loads in flight together
-        for (int u0 = 0; u0 < nchunk; u0 += UN * THREADS) {
-            int r[UN], c8[UN];
-            bool ok[UN];
-            u32x4 o[UN];
-#pragma unroll
-            for (int k = 0; k < UN; ++k) {
-                const int idx = u0 + k * THREADS + tid;
-                r[k] = idx / cpr; c8[k] = (idx - r[k] * cpr) * 8;
-                ok[k] = idx < nchunk && r[k] < R;
-                o[k] = u32x4{0u, 0u, 0u, 0u};
-            }
-            if (a.in_slab.base) {
-                f32x4 v0[UN], v1[UN], b0[UN], b1[UN];
-#pragma unroll
-                for (int k = 0; k < UN; ++k) {
-                    const float* p = a.in_slab.base + (row0 + (ok[k] ? r[k] : 0)) * K0 + (ok[k] ? c8[k] : 0);
-                    const float* bp = a.in_bias + (ok[k] ? (r[k] % T) * a.in_bias_ld + c8[k] : 0);
-                    v0[k] = *reinterpret_cast<const f32x4*>(p); v1[k] = *reinterpret_cast<const f32x4*>(p + 4);
-                    b0[k] = *reinterpret_cast<const f32x4*>(bp); b1[k] = *reinterpret_cast<const f32x4*>(bp + 4);
-                }
-                for (int z = 1; z < nslab; ++z) {
-                    f32x4 t0[UN], t1[UN];
-#pragma unroll
-                    for (int k = 0; k < UN; ++k) {
-                        const float* p = a.in_slab.base + (size_t)z * stride + (row0 + (ok[k] ? r[k] : 0)) * K0 + (ok[k] ? c8[k] : 0);
-                        t0[k] = *reinterpret_cast<const f32x4*>(p); t1[k] = *reinterpret_cast<const f32x4*>(p + 4);
-                    }
-#pragma unroll
-                    for (int k = 0; k < UN; ++k) { v0[k] += t0[k]; v1[k] += t1[k]; }
-                }
-#pragma unroll
-                for (int k = 0; k < UN; ++k) {
-                    v0[k] += b0[k]; v1[k] += b1[k];
-                    float v[8] = {v0[k][0], v0[k][1], v0[k][2], v0[k][3], v1[k][0], v1[k][1], v1[k][2], v1[k][3]};
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = lrelu(v[e]);
-                    if (ok[k]) o[k] = u32x4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < UN; ++k)
-                    if (ok[k]) o[k] = *reinterpret_cast<const u32x4*>(a.a_in_b + (row0 + r[k]) * K0 + c8[k]);
-            }
-#pragma unroll
-            for (int k = 0; k < UN; ++k) {
-                if (u0 + k * THREADS + tid >= nchunk) continue;
-                unsigned int bits = 0;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {          // bf16 > 0: sign bit clear and not zero
-                    const unsigned int lo = o[k][e] & 0xFFFFu, hi = o[k][e] >> 16;
-                    bits |= ((lo != 0u && lo < 0x8000u) ? 1u : 0u) << (2 * e);
-                    bits |= ((hi != 0u && hi < 0x8000u) ? 1u : 0u) << (2 * e + 1);
-                }
-                *reinterpret_cast<u32x4*>(lds + a.off_act[0] + r[k] * a.ld_act[0] + c8[k] * 2) = o[k];
-                lds[a.off_mask + r[k] * a.ld_mask + (c8[k] >> 3)] = (unsigned char)bits;
-            }
+        StageIn si;
+        si.a_in_b = a.a_in_b; si.slab_base = a.in_slab.base; si.in_bias = a.in_bias; si.in_bias_ld = a.in_bias_ld;
+        si.nslab = 0; si.slab_stride = 0;
+        si.K0 = a.fwd[0].K; si.off0 = a.off_act[0]; si.ld0 = a.ld_act[0]; si.offm = a.off_mask[0]; si.ldm = a.ld_mask[0];
+        if (a.in_slab.base) {
+            slab_layout(a.in_slab, si.nslab, si.slab_stride);
+            stage_input<true, 2>(si, lds, tid, T, R, row0);
+        } else {
+            stage_input_bf16(si, lds, tid, R, row0);
         }
-        for (int i = tid; i < ZERO_BYTES / 4; i += THREADS) reinterpret_cast<unsigned int*>(lds + a.off_zero)[i] = 0u;
-        if (tid < a.e.J * MAXJ) reinterpret_cast<int*>(lds + a.off_tab)[tid] = a.e.children[tid];
+    }
+    for (int i = tid; i < ZERO_BYTES / 4; i += THREADS) reinterpret_cast<unsigned int*>(lds + a.off_zero)[i] = 0u;
+    if (tid < a.e.J * MAXJ) reinterpret_cast<int*>(lds + a.off_tab)[tid] = a.e.children[tid];
+    if (tid < a.e.J) reinterpret_cast<int*>(lds + a.off_tab)[MAXJ * MAXJ + tid] = a.e.parents[tid];
+    if (!a.forward_only && tid < nwin * a.e.J) {
+        const int wi = tid / a.e.J, j = tid - wi * a.e.J;
+        const int bw = a.e.perm ? a.e.perm[w0 + wi] : w0 + wi;
+        reinterpret_cast<float*>(lds + a.off_mb)[wi * MAXJ + j] = a.e.mean_bone[(size_t)bw * a.e.J + j];
     }
     lds_barrier();
     TB_PROBE();
 
-    // ---- forward layers
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-        const bool last = (i + 1 == NL);
+    // ---- forward layers but the last (the layer loops are NOT unrolled: one body's registers at a time)
+#pragma nounroll
+    for (int i = 0; i + 1 < NL; ++i) {
         const int N = a.fwd[i].N;
         const float* bias = a.fwd[i].bias;
-        f32x4 bv[2];
-#pragma unroll
-        for (int c = 0; c < 2; ++c) bv[c] = (c == 0 || N > 128) ? *reinterpret_cast<const f32x4*>(bias + col0_of(N, wave, c) + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
         const int out_off = a.off_act[i + 1], out_ld = a.ld_act[i + 1];
+        const int m_off = a.off_mask[i + 1], m_ld = a.ld_mask[i + 1];
+        // (the bias of the wave's channels is requested BEFORE the K walk: a load issued in the epilogue would wait for itself and,
+        // the vmcnt queue being in order, for the six weight fragments in flight behind it)
+        const f32x4 bv0 = *reinterpret_cast<const f32x4*>(bias + (N == 64 ? 16 * (wave & 3) : 16 * wave) + 4 * q);
+        const f32x4 bv1 = N > 128 ? *reinterpret_cast<const f32x4*>(bias + 16 * wave + 128 + 4 * q) : bv0;
+        gemm_dispatch<RING, AFD>(lds, a.off_act[i], a.ld_act[i], a.off_zero, a.fwd[i].K, N, rowbits, ring, wp, consumed, last_step,
+                      [&](int col0, int tile, const f32x4& acc) {
+                          const int n0 = col0 + 4 * q, m = 16 * tile + r16;
+                          f32x4 v = acc + (col0 >= 128 ? bv1 : bv0);
+#pragma unroll
+                          for (int e = 0; e < 4; ++e) v[e] = lrelu(v[e]);
+                          const unsigned int d0 = pack2(v[0], v[1]), d1 = pack2(v[2], v[3]);
+                          *reinterpret_cast<u32x2*>(lds + out_off + m * out_ld + n0 * 2) = u32x2{d0, d1};
+                          lds[m_off + m * m_ld + (n0 >> 2)] = (unsigned char)pos_bits(d0, d1);
+                      });
+        lds_barrier();
+        TB_PROBE();
+    }
+    // ---- the last forward layer (64 padded channels: the pose, fp32, no activation)
+    {
+        const int i = NL - 1;
+        const float* bias = a.fwd[i].bias;
         const int JC = a.e.J * 3;
         float* Xd = reinterpret_cast<float*>(lds + a.off_x);
         float* Xp = a.Xp;
-        gemm_dispatch(lds, a.off_act[i], a.ld_act[i], a.off_zero, a.fwd[i].K, N, T, R, ring, wp, consumed, last_step,
-                      [&](int c, int tile, const f32x4& acc) {
-                          const int n0 = col0_of(N, wave, c) + 4 * q, m = 16 * tile + r16;
-                          f32x4 v = acc + bv[c];
-                          if (!last) {
+        const int col0 = 16 * (wave & 3);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + col0 + 4 * q);
+        gemm_layer<true, RING, AFD>(lds, a.off_act[i], a.ld_act[i], a.off_zero, a.fwd[i].K, rowbits, ring, wp, consumed, last_step,
+                         [&](int tile, const f32x4& acc) {
+                             const int n0 = col0 + 4 * q, m = 16 * tile + r16;
+                             const f32x4 v = acc + bv;
+                             if (m < R) {
+                                 // the pose itself: fp32, dense per window ([T][J*3]) for the energy terms
+                                 const int wdw = m / T, t = m - wdw * T;
 #pragma unroll
-                              for (int e = 0; e < 4; ++e) v[e] = lrelu(v[e]);
-                              *reinterpret_cast<u32x2*>(lds + out_off + m * out_ld + n0 * 2) = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
-                          } else if (m < R) {
-                              // the pose itself: fp32, dense per window ([T][J*3]) for the energy terms
-                              const int wdw = m / T, t = m - wdw * T;
-#pragma unroll
-                              for (int e = 0; e < 4; ++e)
-                                  if (n0 + e < JC) Xd[(wdw * T + t) * JC + n0 + e] = v[e];
-                              if (Xp) *reinterpret_cast<f32x4*>(Xp + (row0 + m) * PAD + n0) = v;
-                          }
-                      });
+                                 for (int e = 0; e < 4; ++e)
+                                     if (n0 + e < JC) Xd[wdw * a.escr + t * JC + n0 + e] = v[e];
+                                 if (Xp) *reinterpret_cast<f32x4*>(Xp + (row0 + m) * PAD + n0) = v;
+                             }
+                         });
         lds_barrier();
         TB_PROBE();
     }
     if (a.forward_only) return;
 
-    // ---- energy terms + dE/dX: one wavefront per window (fp32); gradient rows leave as bf16 into g[NL & 1]
-    {
-        const int n = T * a.e.J * 3, p = NL & 1;
-        if (wave < nwin) {
-            float* xs = reinterpret_cast<float*>(lds + a.off_x) + wave * n;
-            float* scr = reinterpret_cast<float*>(lds + a.off_escr) + wave * 3 * a.escr;
-            const int ldg = a.ld_g[p] / 2;
-            uint16_t* gd = reinterpret_cast<uint16_t*>(lds + a.off_g[p]) + wave * T * ldg;
-            const int* ch = reinterpret_cast<const int*>(lds + a.off_tab);
-            if (fast_e)
-                energy_window<false, 64, 10, 15, true, EnergyPre<8, 3>>(a.e, bwin, lane, xs, 45, xs, scr, scr + a.escr, scr + 2 * a.escr, nullptr, ldg,
-                                                                         a.fwd[NL - 1].N, gd, nullptr, nullptr, nullptr, ch, &pre);
-            else
-                energy_window<false, 64, 0, 0, true>(a.e, bwin, lane, xs, a.e.J * 3, xs, scr, scr + a.escr, scr + 2 * a.escr, nullptr, ldg,
-                                                     a.fwd[NL - 1].N, gd, nullptr, nullptr, nullptr, ch);
-        }
+    // ---- energy terms + dE/dX: one wavefront per window (fp32); gradient rows leave as bf16 into the buffer of act[NL]
+    if (wave < nwin) {
+        const float* xs = reinterpret_cast<const float*>(lds + a.off_x) + wave * a.escr;
+        const float* mbl = reinterpret_cast<const float*>(lds + a.off_mb) + wave * MAXJ;
+        const int* ch = reinterpret_cast<const int*>(lds + a.off_tab);
+        const int* par = ch + MAXJ * MAXJ;
+        const int ldg = a.ld_act[NL] / 2;
+        uint16_t* gd = reinterpret_cast<uint16_t*>(lds + a.off_act[NL]) + wave * T * ldg;
+        if (fast_e) energy_pairs<10, 15, 3>(a.e, bwin, lane, xs, mbl, par, ch, gd, ldg, PAD, (PROBE && a.dbg_ts && blockIdx.x == 0 && wave == 0) ? a.dbg_ts + 32 : nullptr);
+        else energy_pairs<0, 0, 4>(a.e, bwin, lane, xs, mbl, par, ch, gd, ldg, PAD);
     }
+    last_step = a.steps_total - 1;
+#pragma unroll
+    for (int i = 0; i < RING; ++i) ring[i] = wp[(size_t)min(consumed + i, last_step) * 64 + lane];
     lds_barrier();
     TB_PROBE();
 
-    // ---- backward-data layers (adjoint convs): gradient w.r.t. act[j] into g[j & 1], masked by LeakyReLU'(act[j])
-#pragma unroll
+    // ---- backward-data layers (adjoint convs): gradient w.r.t. act[j] into the buffer of act[j], masked by LeakyReLU'(act[j])
+#pragma nounroll
     for (int j = NL - 1; j >= 0; --j) {
         const int N = a.bwd[j].N;                      // = K of forward layer j = width of act[j]
-        const int gin = (j + 1) & 1, gout = j & 1;
-        const int act_off = a.off_act[j], act_ld = a.ld_act[j];
-        const int out_off = j > 0 ? a.off_g[gout] : a.off_act[0], out_ld = j > 0 ? a.ld_g[gout] : a.ld_act[0];
+        const int out_off = a.off_act[j], out_ld = a.ld_act[j];
+        const int m_off = a.off_mask[j], m_ld = a.ld_mask[j];
         const bool masked = j > 0 || a.mask_first;
-        gemm_dispatch(lds, a.off_g[gin], a.ld_g[gin], a.off_zero, a.bwd[j].K, N, T, R, ring, wp, consumed, last_step,
-                      [&](int c, int tile, const f32x4& acc) {
-                          const int n0 = col0_of(N, wave, c) + 4 * q, m = 16 * tile + r16;
+        gemm_dispatch<RING, AFD>(lds, a.off_act[j + 1], a.ld_act[j + 1], a.off_zero, a.bwd[j].K, N, rowbits, ring, wp, consumed, last_step,
+                      [&](int col0, int tile, const f32x4& acc) {
+                          const int n0 = col0 + 4 * q, m = 16 * tile + r16;
                           f32x4 v = acc;
                           if (masked) {
-                              unsigned int pos;        // bit e: act[m][n0 + e] > 0
-                              if (j > 0) {
-                                  const u32x2 av = *reinterpret_cast<const u32x2*>(lds + act_off + m * act_ld + n0 * 2);
-                                  pos = 0;
-#pragma unroll
-                                  for (int e = 0; e < 2; ++e) {
-                                      const unsigned int lo = av[e] & 0xFFFFu, hi = av[e] >> 16;
-                                      pos |= ((lo != 0u && lo < 0x8000u) ? 1u : 0u) << (2 * e);
-                                      pos |= ((hi != 0u && hi < 0x8000u) ? 1u : 0u) << (2 * e + 1);
-                                  }
-                              } else {
-                                  pos = (unsigned int)lds[a.off_mask + m * a.ld_mask + (n0 >> 3)] >> (n0 & 7);
-                              }
+                              // bit e: act[j][m][n0 + e] > 0
+                              const unsigned int pos = j > 0 ? (unsigned int)lds[m_off + m * m_ld + (n0 >> 2)]
+                                                             : (unsigned int)lds[m_off + m * m_ld + (n0 >> 3)] >> (n0 & 7);
 #pragma unroll
                               for (int e = 0; e < 4; ++e) v[e] *= ((pos >> e) & 1u) ? 1.f : LEAKY_SLOPE;
                           }
@@ -355,7 +426,8 @@ __global__ __launch_bounds__(THREADS, 2) void decoder_tail_bf16_kernel(TailB16Ar
 }  // namespace tb
 
 // LDS plan of the bf16 tail for the chain starting at decoder conv `start`.  Returns the byte size, or 0 when the chain does not
-// fit this kernel (layer widths other than 64 / 128 / 256 outputs, more than TB_MAX_LAYERS layers, more than 160 KB).
+// fit this kernel (layer widths other than 64 / 128 / 256 outputs, more than TB_MAX_LAYERS layers, more than 80 KB: the kernel is
+// built for two workgroups per CU).
 size_t plan_tail_bf16(const std::vector<Layer>& dec, int start, int T, int J, TailB16Args* out) {
     const int n = (int)dec.size() - start;
     if (start < 1 || n < 1 || n > TB_MAX_LAYERS || T < 3 || T > 16) return 0;
@@ -366,52 +438,49 @@ size_t plan_tail_bf16(const std::vector<Layer>& dec, int start, int T, int J, Ta
         // forward: K_i -> N_i; adjoint: N_i -> K_i (so K_i must be a valid output width too, and N_i a valid K)
         if (!okK(K) || !okN(N) || !okN(K)) return 0;
     }
-    if (dec.back().N != PAD || J * 3 > PAD) return 0;
+    if (dec.back().N != PAD || J * 3 > PAD || J > GEM_MAX_JOINTS) return 0;
     TailB16Args a{};
     a.n = n;
     a.mask_first = 1;
     a.G = std::min(8, tb::ROWS / T);
     auto ld = [](int width) { return 2 * width + 32; };
-    int off = 0;
     const int escr = (T * J * 3 + 3) / 4 * 4;
     a.escr = escr;
-    // region 0: the input image; later the energy scratch (3 arrays per window), later the staged output rows
-    a.off_act[0] = 0;
-    a.ld_act[0] = ld(dec[start].K);
-    a.off_escr = 0;
-    off = std::max(tb::ROWS * a.ld_act[0], a.G * 3 * escr * 4);
-    for (int i = 1; i < n; ++i) {          // act[n] is the pose: kept as fp32 at off_x
-        a.off_act[i] = off;
-        a.ld_act[i] = ld(dec[start + i - 1].N);
-        off += tb::ROWS * a.ld_act[i];
+    // width of act[j] (j = 0 .. n; act[n] is the pose: its slot holds the bf16 gradient rows w.r.t. the pose)
+    int width[TB_MAX_LAYERS + 1];
+    width[0] = dec[start].K;
+    for (int j = 1; j <= n; ++j) width[j] = dec[start + j - 1].N;
+    // two ping-pong buffers: act[j] / the gradient w.r.t. act[j] live at the start of buffer j & 1; the decoded pose (fp32)
+    // sits behind act[n-1] in that activation's buffer (read by the energy terms while they write the gradient rows into the other)
+    int size[2] = {0, 0};
+    for (int j = 0; j <= n; ++j) size[j & 1] = std::max(size[j & 1], tb::ROWS * ld(width[j]));
+    const int xb = (n - 1) & 1, x_rel = tb::ROWS * ld(width[n - 1]);
+    size[xb] = std::max(size[xb], x_rel + a.G * escr * 4);
+    const int buf_off[2] = {0, size[0]};
+    int off = size[0] + size[1];
+    for (int j = 0; j <= n; ++j) { a.off_act[j] = buf_off[j & 1]; a.ld_act[j] = ld(width[j]); }
+    a.off_x = buf_off[xb] + x_rel;
+    for (int j = 0; j < n; ++j) {          // sign bits of act[j]
+        a.off_mask[j] = off;
+        a.ld_mask[j] = j == 0 ? width[0] / 8 : width[j] / 4;
+        off += tb::ROWS * a.ld_mask[j];
     }
-    a.off_act[n] = 0; a.ld_act[n] = 0;
-    a.off_x = off;
-    off += a.G * escr * 4;
-    // gradient w.r.t. act[j] (j = n .. 1) lives in g[j & 1]: each buffer as wide as the widest it ever holds
-    int wg[2] = {0, 0};
-    for (int j = 1; j <= n; ++j) wg[j & 1] = std::max(wg[j & 1], dec[start + j - 1].N);
-    for (int p = 0; p < 2; ++p) {
-        a.off_g[p] = off;
-        a.ld_g[p] = ld(std::max(wg[p], 64));
-        off += tb::ROWS * a.ld_g[p];
-    }
+    off = (off + 15) / 16 * 16;
     a.off_zero = off;
     off += tb::ZERO_BYTES;
-    a.off_mask = off;
-    a.ld_mask = dec[start].K / 8;
-    off += tb::ROWS * a.ld_mask;
-    off = (off + 15) / 16 * 16;
-    a.off_tab = off;                       // children lists of the skeleton ([J][MAXJ] ints)
-    off += GEM_MAX_JOINTS * GEM_MAX_JOINTS * 4;
+    a.off_mb = off;                        // mean bone lengths of the workgroup's windows ([G][MAXJ] floats)
+    off += a.G * GEM_MAX_JOINTS * 4;
+    a.off_tab = off;                       // children lists of the skeleton ([J][MAXJ] ints) + parents ([MAXJ] ints)
+    off += (GEM_MAX_JOINTS + 1) * GEM_MAX_JOINTS * 4;
     off = (off + 15) / 16 * 16 + 64;       // (+ slack: nothing reads past its row, this keeps it that way under edits)
-    if (off > 160 * 1024) return 0;
+    if (off > 80 * 1024) return 0;
     if (out) *out = a;
     return (size_t)off;
 }
 
-// Weight fragments in consumption order.  Must mirror gemm_layer: k-block major, taps inner, column tiles innermost; wave w's
-// column tile c starts at channel col0_of(N, w, c); lane l holds W[tap][n0 + (l & 15)][32 * kb + 8 * (l >> 4) + 0..7].
+// Weight fragments in consumption order.  Must mirror gemm_dispatch / gemm_layer: one pass per 128 output channels (column tile c
+// of wave w starts at channel 16 * w + 128 * c; 64-wide layers: 16 * (w & 3)), inside a pass k-block major, taps inner; lane l
+// holds W[tap][n0 + (l & 15)][32 * kb + 8 * (l >> 4) + 0..7].
 int build_tail_bf16_stream(gem_handle* h, StageNet& net) {
     net.tb_stream = nullptr; net.tb_steps_f = net.tb_steps_b = 0; net.tb_lds = 0;
     const int st = net.tail_start;
@@ -429,9 +498,9 @@ int build_tail_bf16_stream(gem_handle* h, StageNet& net) {
         size_t step = (size_t)w * total;
         auto emit = [&](const Layer& L, const std::vector<float>& W /* [3][N][K] */) {
             const int cpw = L.N / 128 > 0 ? L.N / 128 : 1;
-            for (int kb = 0; kb < L.K / 32; ++kb)
-                for (int tap = 0; tap < 3; ++tap)
-                    for (int c = 0; c < cpw; ++c) {
+            for (int c = 0; c < cpw; ++c)
+                for (int kb = 0; kb < L.K / 32; ++kb)
+                    for (int tap = 0; tap < 3; ++tap) {
                         const int n0 = L.N == 64 ? 16 * (w & 3) : 16 * w + 128 * c;
                         uint16_t* dst = stream.data() + step * 64 * 8;
                         for (int l = 0; l < 64; ++l)
@@ -453,13 +522,20 @@ int build_tail_bf16_stream(gem_handle* h, StageNet& net) {
 }
 
 int launch_tail_bf16(gem_handle* h, const TailB16Args& a, size_t lds_bytes, hipStream_t s) {
+    // at most one workgroup per CU: the one-workgroup-per-CU instance (lower latency); more: the two-per-CU instance
+    const int wgs = (a.B + a.G - 1) / a.G;
+    const bool dense = wgs > h->n_cu && !dev_env("GEM_TAIL16_SPARSE");
+    typedef void (*kern_t)(TailB16Args);
+    const kern_t kern = dense ? (a.dbg_ts ? tb::decoder_tail_bf16_kernel<true, true> : tb::decoder_tail_bf16_kernel<true, false>)
+                              : (a.dbg_ts ? tb::decoder_tail_bf16_kernel<false, true> : tb::decoder_tail_bf16_kernel<false, false>);
+    const void* kfn = reinterpret_cast<const void*>(kern);
     static PerDeviceOnce attr_once;
     if (attr_once.need(h->cfg.device)) {
-        const void* ks[] = {reinterpret_cast<const void*>(tb::decoder_tail_bf16_kernel<1>), reinterpret_cast<const void*>(tb::decoder_tail_bf16_kernel<2>),
-                            reinterpret_cast<const void*>(tb::decoder_tail_bf16_kernel<3>), reinterpret_cast<const void*>(tb::decoder_tail_bf16_kernel<4>),
-                            reinterpret_cast<const void*>(tb::decoder_tail_bf16_kernel<5>), reinterpret_cast<const void*>(tb::decoder_tail_bf16_kernel<6>)};
-        for (const void* k : ks) GEM_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        const kern_t all[] = {tb::decoder_tail_bf16_kernel<true, true>, tb::decoder_tail_bf16_kernel<true, false>,
+                              tb::decoder_tail_bf16_kernel<false, true>, tb::decoder_tail_bf16_kernel<false, false>};
+        for (kern_t k : all) GEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     }
+    if (a.n < 1 || a.n > TB_MAX_LAYERS || lds_bytes > 80 * 1024) { set_error("launch_tail_bf16: unsupported layer chain"); return 1; }
     Profile::Rec rec;
     const bool prof = h->prof.on;
     if (prof) {
@@ -472,16 +548,8 @@ int launch_tail_bf16(gem_handle* h, const TailB16Args& a, size_t lds_bytes, hipS
         if (h->ws.dyn) { rec.log_idx = h->ws.cur_log; rec.flops_per_window = per_window; }
         GEM_HIP(hipEventRecord(rec.a, s));
     }
-    const int wgs = (a.B + a.G - 1) / a.G;
-    switch (a.n) {
-        case 1: note_kernel(h, reinterpret_cast<const void*>(tb::decoder_tail_bf16_kernel<1>)); hipLaunchKernelGGL(tb::decoder_tail_bf16_kernel<1>, dim3(wgs), dim3(tb::THREADS), lds_bytes, s, a); break;
-        case 2: note_kernel(h, reinterpret_cast<const void*>(tb::decoder_tail_bf16_kernel<2>)); hipLaunchKernelGGL(tb::decoder_tail_bf16_kernel<2>, dim3(wgs), dim3(tb::THREADS), lds_bytes, s, a); break;
-        case 3: note_kernel(h, reinterpret_cast<const void*>(tb::decoder_tail_bf16_kernel<3>)); hipLaunchKernelGGL(tb::decoder_tail_bf16_kernel<3>, dim3(wgs), dim3(tb::THREADS), lds_bytes, s, a); break;
-        case 4: note_kernel(h, reinterpret_cast<const void*>(tb::decoder_tail_bf16_kernel<4>)); hipLaunchKernelGGL(tb::decoder_tail_bf16_kernel<4>, dim3(wgs), dim3(tb::THREADS), lds_bytes, s, a); break;
-        case 5: note_kernel(h, reinterpret_cast<const void*>(tb::decoder_tail_bf16_kernel<5>)); hipLaunchKernelGGL(tb::decoder_tail_bf16_kernel<5>, dim3(wgs), dim3(tb::THREADS), lds_bytes, s, a); break;
-        case 6: note_kernel(h, reinterpret_cast<const void*>(tb::decoder_tail_bf16_kernel<6>)); hipLaunchKernelGGL(tb::decoder_tail_bf16_kernel<6>, dim3(wgs), dim3(tb::THREADS), lds_bytes, s, a); break;
-        default: set_error("launch_tail_bf16: unsupported number of fused layers"); return 1;
-    }
+    note_kernel(h, kfn);
+    hipLaunchKernelGGL(kern, dim3(wgs), dim3(tb::THREADS), lds_bytes, s, a);
     GEM_HIP(hipGetLastError());
     if (prof) { GEM_HIP(hipEventRecord(rec.b, s)); h->prof.recs.push_back(rec); }
     commit_kernel_names(h, prof ? 1 : -1);

@@ -120,7 +120,7 @@ class WindowEngine:
 
     def set_lanes(self, min_windows):
         """optimize_windows calls of at least `min_windows` windows run as two half-batches on two streams, half a round apart
-        (gem_set_lanes; default 4352; 0 = never).  Same results, bit for bit, from the default threshold on."""
+        (gem_set_lanes; 0 = never = the default).  Same results, bit for bit, for thresholds >= 4352."""
         _capi.check(self.lib.gem_set_lanes(self._h, int(min_windows)), self.lib)
 
     def set_precision(self, mode):

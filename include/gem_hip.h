@@ -89,8 +89,10 @@ void gem_destroy(gem_handle* h);
 /* Two lanes: gem_optimize_windows calls of at least `min_windows` windows run as two half-batches on two streams (the caller's
  * and one owned by the handle), shifted by half an evaluation round so that the HBM-bound L-BFGS advance of one half shares the
  * device with the matrix-bound kernels of the other (windows are independent: optimizer.py:370).  Results are bitwise those of
- * one lane wherever no product is cut along K (the default threshold, 4352 windows, guarantees it); outputs, statistics and
- * gem_read_trace are assembled in window order.  0 = always one lane.  Costs a second workspace (half the size of the first). */
+ * one lane wherever no product is cut along K (any threshold >= 4352 windows guarantees it); outputs, statistics and
+ * gem_read_trace are assembled in window order.  0 = always one lane = the DEFAULT since round 4: the bf16 tail now keeps two
+ * workgroups per CU busy by itself and one lane measures faster (8192 windows: 264 k vs 256 k windows/s); the call stays for
+ * devices / batch shapes where the split pays.  Costs a second workspace (half the size of the first) when switched on. */
 int gem_set_lanes(gem_handle* h, int min_windows);
 
 /* Arithmetic of the wide decoder / encoder products (the narrow tail layers and every energy term are

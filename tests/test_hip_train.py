@@ -58,6 +58,22 @@ def test_training_steps_against_the_reference_run(golden, case):
         tr.close()
 
 
+def test_full_size_training_step_against_the_reference_run(golden):
+    """ONE device step at D = 2048, batch 8, against the unmodified reference's own step (tests/golden/train_full.npz, made by
+    oracle/make_golden_train.py --full from networks/train.py:77-83 + SeqConvVAE.py:191-219): losses, every tensor's gradient
+    2-norm and 256 sampled entries at 1e-4, the sampled parameters after Adam, the BatchNorm running statistics."""
+    from globalegomocap_amd.vae_train import VAETrainer
+    from helpers import train_full_case, check_full_training_step
+    c = train_full_case(golden("train_full"))
+    tr = VAETrainer(c["shape"], batch_size=64, lr=c["lr"], weight_decay=c["wd"], state_dict=c["init"])
+    try:
+        losses = tr.step(c["poses"], c["w"], eps=c["eps"])
+        sd = tr.state_dict()
+        check_full_training_step(c, losses, tr.gradients(), sd, sd, loss_rtol=5e-5, grad_tol=1e-4)
+    finally:
+        tr.close()
+
+
 def test_full_size_training_step_against_the_port():
     import torch
     from globalegomocap_amd.vae_train import VAETrainer, initial_state_dict

@@ -331,3 +331,16 @@ def test_training_step_port_against_the_reference_run(golden, case):
                 np.testing.assert_allclose(v, c["grad0"][k], rtol=1e-4, atol=1e-6 * max(1.0, float(np.abs(c["grad0"][k]).max())), err_msg=k)
     for k, v in port.state_dict().items():
         np.testing.assert_allclose(v, c["final"][k], rtol=1e-4, atol=2e-6, err_msg=k)
+
+
+def test_training_step_port_at_full_size_against_the_reference_run(golden):
+    """TrainPort at D = 2048 against ONE step of the unmodified reference (tests/golden/train_full.npz): the 32.6 M-parameter
+    layout -- decoder_input / fc_mu / fc_var flattening, ConvTranspose1d taps -- pinned to the reference itself."""
+    import torch
+    from oracle.torch_port import TrainPort
+    from helpers import train_full_case, check_full_training_step
+    c = train_full_case(golden("train_full"))
+    port = TrainPort(c["init"], lr=c["lr"], weight_decay=c["wd"])
+    losses = port.step(c["poses"], c["eps"], c["w"])
+    sd = port.state_dict()
+    check_full_training_step(c, losses, port.gradients(), sd, sd, loss_rtol=2e-5, grad_tol=1e-4)

@@ -1,7 +1,9 @@
 // Stand-alone timing harness for csrc/tail_bf16.hip (developer tool): per-phase timestamps of workgroup 0 and launch times.
-//   hipcc -w --offload-arch=gfx950 -O3 -std=c++17 -o tools/tail16_bench tools/tail16_bench.hip && ./tools/tail16_bench 1536 [nslab]
+//   hipcc -w --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -o tools/tail16_bench tools/tail16_bench.hip && ./tools/tail16_bench 1536 [nslab]
+//   TAIL_DETERMINISM=1 [TAIL_HEAT=1] [TAIL_SCRAMBLE=1] ./tools/tail16_bench 8192: repeated launches must write bitwise identical rows
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include "../globalegomocap_amd/csrc/tail_bf16.hip"
 namespace gem {
@@ -11,6 +13,14 @@ void note_kernel(gem_handle*, const void*) {}
 bool hip_ok(hipError_t e, const char* what) { if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", what, hipGetErrorString(e)); return false; } return true; }
 }
 using namespace gem;
+// fills every CU's LDS with launch-dependent garbage: a read of LDS the tail kernel has not written shows up as non-determinism
+__global__ void lds_scramble_kernel(unsigned seed, unsigned* sink) {
+    extern __shared__ unsigned sl[];
+    unsigned v = seed * 2654435761u + blockIdx.x * 40503u + threadIdx.x;
+    for (int i = threadIdx.x; i < 160 * 1024 / 4; i += blockDim.x) { v = v * 1664525u + 1013904223u; sl[i] = v; }
+    __syncthreads();
+    if (sl[(seed + threadIdx.x) % (160 * 1024 / 4)] == 0x12345678u) sink[0] = 1;
+}
 static std::vector<float> host_rand(size_t n, unsigned seed, float scale) {
     std::vector<float> h(n); srand(seed);
     for (size_t i = 0; i < n; ++i) h[i] = scale * ((rand() / (float)RAND_MAX) * 2.f - 1.f);
@@ -33,6 +43,11 @@ int main(int argc, char** argv) {
         net.host_fwd[i] = host_rand((size_t)3 * dims[i - 1] * dims[i], 10 + i, 0.05f);
         net.host_bwd[i] = host_rand((size_t)3 * dims[i - 1] * dims[i], 30 + i, 0.05f);
         net.dec[i].bias = dev_rand(dims[i], 20 + i, 0.05f);
+    }
+    if (getenv("TAIL_HEAT")) {
+        std::vector<float> pb(64, 0.f);
+        for (int j = 0; j < 15; ++j) { pb[3 * j] = 0.05f * (j - 7); pb[3 * j + 1] = 0.04f * (j % 5 - 2); pb[3 * j + 2] = 0.4f + 0.05f * j; }
+        hipMemcpy((void*)net.dec[5].bias, pb.data(), 64 * 4, hipMemcpyHostToDevice);
     }
     net.tail_start = 1;
     if (build_tail_bf16_stream(&h, net) || !net.tb_stream) { fprintf(stderr, "no stream\n"); return 1; }
@@ -57,6 +72,13 @@ int main(int argc, char** argv) {
     e.X0 = dev_rand((size_t)B * T * 45, 2, 1.f);
     const int F = 8 * B + 10;
     hipMalloc((void**)&e.heat, (size_t)F * 64 * 64 * 15 * 4); hipMemset((void*)e.heat, 0, (size_t)F * 64 * 64 * 15 * 4);
+    if (getenv("TAIL_HEAT")) {       // non-zero texels (bytes 0x3e.. = 0.18 .. 0.25 as fp32): the reprojection gradient is live
+        std::vector<unsigned char> pat(1 << 20);
+        srand(5); for (auto& v : pat) v = (unsigned char)(rand() & 0xFF);
+        for (size_t i = 3; i < pat.size(); i += 4) pat[i] = 0x3e;
+        for (size_t off = 0; off < (size_t)F * 64 * 64 * 15 * 4; off += pat.size())
+            hipMemcpy((char*)e.heat + off, pat.data(), std::min(pat.size(), (size_t)F * 64 * 64 * 15 * 4 - off), hipMemcpyHostToDevice);
+    }
     std::vector<int> f0(B); for (int b = 0; b < B; ++b) f0[b] = 8 * b;
     hipMalloc((void**)&e.frame0, B * 4); hipMemcpy((void*)e.frame0, f0.data(), B * 4, hipMemcpyHostToDevice);
     e.mean_bone = dev_rand((size_t)B * 15, 3, 0.3f);
@@ -88,6 +110,47 @@ int main(int argc, char** argv) {
             printf("  %-14s %7.2f us  (%6lld shader clocks, %.2f GHz)\n", names[i], (ts[2 * i + 1] - ts[2 * i - 1]) * 0.01,
                    ts[2 * i] - ts[2 * i - 2], (ts[2 * i] - ts[2 * i - 2]) / ((ts[2 * i + 1] - ts[2 * i - 1]) * 10.0 + 1e-9));
         printf("  total inside the kernel %.2f us\n", (ts[27] - ts[1]) * 0.01);
+        printf("  energy sub-steps (shader clocks since its start):");
+        for (int i = 1; i < 20 && ts[32 + i]; ++i) printf(" %lld", ts[32 + i] - ts[32]);
+        printf("\n");
+    }
+    if (getenv("TAIL_DETERMINISM")) {   // repeated launches must write bitwise identical gradient rows
+        std::vector<uint16_t> hin(rows * 256);
+        srand(77);
+        for (auto& v : hin) { float f = 0.5f * ((rand() / (float)RAND_MAX) * 2.f - 1.f); uint32_t u; memcpy(&u, &f, 4); v = (uint16_t)(u >> 16); }
+        hipMemcpy((void*)a.a_in_b, hin.data(), hin.size() * 2, hipMemcpyHostToDevice);
+        std::vector<uint16_t> ref(rows * 256), cur(rows * 256);
+        int bad_launches = 0;
+        for (int rep = 0; rep < 12; ++rep) {
+            hipMemsetAsync(a.g_out_b, 0xFF, rows * 256 * 2, s);
+            if (getenv("TAIL_SCRAMBLE")) {
+                static unsigned* sink = nullptr;
+                if (!sink) { hipMalloc(&sink, 4); hipFuncSetAttribute(reinterpret_cast<const void*>(lds_scramble_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
+                hipLaunchKernelGGL(lds_scramble_kernel, dim3(1024), dim3(256), 160 * 1024, s, (unsigned)rep + 1u, sink);
+            }
+            launch_tail_bf16(&h, a, lds, s);
+            hipStreamSynchronize(s);
+            hipMemcpy(rep ? cur.data() : ref.data(), a.g_out_b, rows * 256 * 2, hipMemcpyDeviceToHost);
+            if (!rep) continue;
+            size_t nbad = 0; long first = -1;
+            int colhist[16] = {0}, tilehist[5] = {0};
+            for (size_t i = 0; i < cur.size(); ++i)
+                if (cur[i] != ref[i]) {
+                    if (first < 0) first = (long)i;
+                    ++nbad; ++colhist[(i % 256) / 16]; ++tilehist[((i / 256) % 80) / 16];
+                }
+            if (nbad) {
+                ++bad_launches;
+                printf("  rep %d: %zu differing values, first at row %ld (workgroup %ld, row-in-wg %ld) col %ld; by 16-col group:", rep, nbad, first / 256,
+                       first / 256 / 80, (first / 256) % 80, first % 256);
+                for (int c = 0; c < 16; ++c) printf(" %d", colhist[c]);
+                printf("; by row tile:");
+                for (int c = 0; c < 5; ++c) printf(" %d", tilehist[c]);
+                printf("\n");
+            }
+        }
+        printf("determinism B=%d: %d of 11 launches differ from the first\n", B, bad_launches);
+        return 0;
     }
     for (int fo = 1; fo >= 0; --fo) {
         a.forward_only = fo;
