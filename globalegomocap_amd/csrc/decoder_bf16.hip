@@ -12,6 +12,7 @@
 
 #include "gem_internal.h"
 #include "gemm_glds.h"
+#include "gemm_big.h"
 
 namespace gem {
 
@@ -90,6 +91,42 @@ static int launch_bn(gem_handle* h, const Args& a, int grid, bool bn128, bool ou
     return out_bf16 ? launch_k<TAPS, EPI, 64, true>(h, a, grid, s) : launch_k<TAPS, EPI, 64, false>(h, a, grid, s);
 }
 
+// The composed front layer at large batch: the one-round kernel of gemm_big.h (256 x 256 / 256 x 320 tiles, 16 waves).  From
+// BIG_MIN_ROWS rows on it beats the 128 x 128 kernel (tools/gemm_big_bench: 78 vs ~105 us at 8192 rows, equal near 5500); in
+// the evaluation rounds the row count lives on the device, so BOTH kernels are enqueued and each looks at the count itself:
+// the big one returns below the threshold, the small one (Args::m_max) at or above it.  Same K order and accumulation as the
+// small kernel: the results do not depend on which of the two ran.
+constexpr int BIG_MIN_ROWS = 5376;
+static bool big_fits(const Layer& L, int epi, bool out_bf16) {
+    if (L.taps != 1 || L.K % 64 != 0 || !L.wb_hi) return false;
+    if (epi == EPI_BIAS_LRELU && out_bf16) return L.N % 320 == 0;
+    if (epi == EPI_NONE && !out_bf16) return L.N % 256 == 0;
+    return false;
+}
+static int launch_big(gem_handle* h, const Layer& L, int epi, const uint16_t* A, int lda, void* C, int ldc, int M, hipStream_t s,
+                      const int* row_map, int m_min) {
+    Workspace& w = h->ws;
+    big::Args a{};
+    a.A = A; a.W = L.wb_hi; a.bias = L.bias; a.C = C; a.zero16 = w.zero16;
+    a.m_dev = w.dyn ? w.n_active : nullptr; a.row_map = row_map;
+    a.lda = lda; a.ldc = ldc; a.M = M; a.N = L.N; a.K = L.K; a.m_min = m_min;
+    static PerDeviceOnce once;
+    if (once.need(h->cfg.device)) {
+        GEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(big::gemm_big_kernel<5, big::EPI_BIAS_LRELU, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        GEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(big::gemm_big_kernel<4, big::EPI_NONE, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+    const int n_mt = (M + 255) / 256;
+    if (epi == EPI_BIAS_LRELU) {
+        note_kernel(h, reinterpret_cast<const void*>(big::gemm_big_kernel<5, big::EPI_BIAS_LRELU, true>));
+        hipLaunchKernelGGL((big::gemm_big_kernel<5, big::EPI_BIAS_LRELU, true>), dim3(n_mt * (L.N / 320)), dim3(1024), 2 * (256 + 320) * 128, s, a);
+    } else {
+        note_kernel(h, reinterpret_cast<const void*>(big::gemm_big_kernel<4, big::EPI_NONE, false>));
+        hipLaunchKernelGGL((big::gemm_big_kernel<4, big::EPI_NONE, false>), dim3(n_mt * (L.N / 256)), dim3(1024), 2 * (256 + 256) * 128, s, a);
+    }
+    GEM_HIP(hipGetLastError());
+    return 0;
+}
+
 // C = epi(conv/linear(A)) with bf16 operands.  `out_bf16`: activation / gradient for the next bf16 layer; otherwise fp32.
 // allow_split: small row counts cut K over several workgroups (fp32 slabs in ws.splitk); with `defer` the slabs are left to
 // the consumer (described in ws.deferred), otherwise a reduce pass applies the epilogue.
@@ -109,6 +146,10 @@ static int gemm_bf16a(gem_handle* h, const Layer& L, int epi, const uint16_t* A,
     a.row_map = row_map;
     a.lda = lda; a.ldc = ldc; a.M = M; a.N = L.N; a.K = L.K; a.T = h->T;
     a.n_split = 1; a.tiles_per_split = k_tiles; a.slab_stride = (size_t)M * ldc;
+    // the front products at large batch: gemm_big.h takes the launches with >= BIG_MIN_ROWS rows (family 0 only)
+    static const bool no_big = dev_env("GEM_NO_BIG_GEMM") != nullptr;
+    const bool use_big = family == 0 && !no_big && M >= BIG_MIN_ROWS && big_fits(L, epi, out_bf16);
+    if (use_big) a.m_max = BIG_MIN_ROWS;
     if (allow_split && epi != EPI_MASK) {
         // fill the chip: about two workgroups per CU (the number co-resident with this kernel's 64 KB of LDS; measured at 768 ..
         // 3072 rows, tools/gemm_glds_bench split: the best cut of every shape) while every slice keeps >= 4 k-tiles and the slabs fit
@@ -134,6 +175,13 @@ static int gemm_bf16a(gem_handle* h, const Layer& L, int epi, const uint16_t* A,
     const int grid = tiles * a.n_split;
     const bool kernel_bf16 = out_bf16 && a.n_split == 1;
     int rc = 1;
+    if (use_big) {
+        if (a.n_split != 1) { set_error("gemm_bf16a: the one-round kernel's row range must not be cut along K"); return 1; }
+        if (launch_big(h, L, epi, A, lda, C, ldc, M, s, row_map, w.dyn ? BIG_MIN_ROWS : 1)) return 1;
+    }
+    if (use_big && !w.dyn) {
+        rc = 0;                    // the row count is known here: the big kernel alone
+    } else
     if (L.taps == 1) {
         if (epi == EPI_BIAS) rc = launch_bn<1, EPI_BIAS>(h, a, grid, bn128, kernel_bf16, s);
         else if (epi == EPI_NONE) rc = launch_bn<1, EPI_NONE>(h, a, grid, bn128, kernel_bf16, s);

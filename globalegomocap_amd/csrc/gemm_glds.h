@@ -63,6 +63,7 @@ struct Args {
     int lda, ldc, M, N, K, T;
     int n_split, tiles_per_split;     // split-K over the TAPS*K/BK k-tiles (1: none)
     size_t slab_stride;
+    int m_max;                // > 0: return at once when the (device) row count is >= m_max (gemm_big.h takes those launches)
 };
 
 // logical tile id of this workgroup (XCD-aware, grouped): returns false when the workgroup has nothing to do
@@ -99,7 +100,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_glds_kernel(c
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int M = a.m_dev ? *a.m_dev : a.M;
-    if (M <= 0) return;
+    if (M <= 0 || (a.m_max > 0 && M >= a.m_max)) return;
     const int n_mt = (M + BM - 1) / BM, n_nt = a.N / BN;
     int mt, nt, ks;
     if (!tile_of_block(blockIdx.x, n_mt, n_nt, a.n_split, mt, nt, ks)) return;
