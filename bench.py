@@ -115,23 +115,52 @@ def cpu_baseline(sd_local, sd_global, cam, seqd, starts, mean_bone, eps_l, eps_g
     return np.asarray(out), dt, nthreads
 
 
-def committed_traffic(kernel_names):
+def committed_traffic(kernel_names, windows, precision):
     """HBM bytes per launch of the named kernels from the committed rocprofv3 --pmc summaries (profiles/traffic_r*.json: FETCH_SIZE x 2
-    on gfx950 + WRITE_SIZE, separate passes -- MI355X_MICROARCH.md section HBM), dispatch-weighted over the names; (None, None) when
-    no committed file knows them.  NOT measured in this run: the source file is named next to the number."""
+    on gfx950 + WRITE_SIZE, separate passes -- MI355X_MICROARCH.md section HBM), dispatch-weighted over the names.  Only a file
+    collected on THIS workload (same window count and precision: its `workload` header, or -- files of rounds 1-3 -- its name)
+    qualifies, newest round first; a kernel the matching files do not know gives (None, None): another workload's bytes are never
+    reported.  NOT measured in this run: the source file is named next to the number."""
     import glob
+    import re
     names = [n.strip() for n in kernel_names.split(";") if n.strip()]
+
+    def workload_of(path, d):
+        w = d.get("workload")
+        if isinstance(w, dict):
+            return int(w.get("windows", -1)), str(w.get("precision", ""))
+        m = re.search(r"traffic_r\d+_(f32|bf16)_(\d+)_windows", os.path.basename(path))
+        if m:
+            return int(m.group(2)), m.group(1)
+        if re.fullmatch(r"traffic_r\d+\.json", os.path.basename(path)):
+            return 240, "f32"                              # the default bench command (BASELINE configs[1])
+        return -1, ""
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json")), reverse=True):
         try:
-            k = json.load(open(path)).get("kernels", {})
+            d = json.load(open(path))
         except (OSError, ValueError):
             continue
+        wn, wp = workload_of(path, d)
+        # (8196 = the 683-chunk stand-in of rounds 2-3 for the 8192-window shard: same kernels, same tiles)
+        if wp != precision or not (wn == windows or (windows == 8192 and wn == 8196)):
+            continue
+        k = d.get("kernels", {})
         hit = [k[n] for n in names if n in k]
         if len(hit) == len(names) and hit:
             disp = sum(h["dispatches"] for h in hit)
             tot = sum((h["read_bytes_corrected"] + h["write_bytes"]) * h["dispatches"] for h in hit)
-            return int(tot / disp), "profiles/%s (committed rocprofv3 --pmc passes of the matching bench command; not measured in this run)" % os.path.basename(path)
+            return int(tot / disp), "profiles/%s (committed rocprofv3 --pmc passes of this workload: %d windows, %s; not measured in this run)" % (
+                os.path.basename(path), wn, wp)
     return None, None
+
+
+def kernel_bound(names):
+    """What bounds a timed kernel family, by the kernels that actually ran: the few-rows / tiled / LDS-DMA
+    products are priced against the matrix peak; the fused tails are chains of short dependent phases (their matrix work is a
+    fraction of their time): `latency`, the TFLOP/s figure is kept for comparison only."""
+    if "decoder_tail" in names:
+        return "latency"
+    return "mfma"
 
 
 def spawn_ranks(n):
@@ -150,7 +179,7 @@ def spawn_ranks(n):
     return subprocess.run(cmd, env=env).returncode
 
 
-def run_sharded(a, world, rank, device, rehearsal, sd_local, sd_global, vae_note):
+def run_sharded(a, world, rank, device, rehearsal, sd_local, sd_global, vae_note, emit=True):
     """BASELINE configs[3] / configs[4]: ONE job of n windows sharded over the ranks (strong scaling).
 
     configs3: 65 536 independent windows, contiguous shards (`dist.shard_range`), every rank synthesises its own frames on its
@@ -161,7 +190,9 @@ def run_sharded(a, world, rank, device, rehearsal, sd_local, sd_global, vae_note
       halo between blocks that went to different ranks); every call after the second is one hipGraph replay;
       `all_gather_indexed` restores window order, then overlap-merge + final smoothing (optimizer.py:425-450) of the gathered
       sequence on the device.
-    The timed step = optimise the shard + the collective (+ merge for configs4); value = n windows / step time."""
+    The timed step = optimise the shard + the collective (+ merge for configs4); value = n windows / step time.
+    emit=False: rank 0 returns the record instead of printing it (the side records of the default multi-rank line), the process
+    group stays up."""
     import torch
     import torch.distributed as dist
     from globalegomocap_amd import synth, vae as vae_schema
@@ -256,6 +287,14 @@ def run_sharded(a, world, rank, device, rehearsal, sd_local, sd_global, vae_note
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     fin = all(bool(stats_to_numpy(o[1])["finished"].all()) for o in outs.values() if o[1] is not None)
+    # the load-imbalance term of a window shard: evaluations (= rounds a window stays in the batch) summed per rank
+    my_evals = float(sum(float(stats_to_numpy(o[1])["func_evals"].sum()) for o in outs.values() if o[1] is not None))
+    if world > 1:
+        ev = [None] * world
+        dist.all_gather_object(ev, my_evals)
+    else:
+        ev = [float(stats_to_numpy(outs[r][1])["func_evals"].sum()) if outs[r][1] is not None else 0.0 for r in my_ranks]
+    line = None
     if rank == 0:
         mp = None
         if stream:
@@ -281,12 +320,18 @@ def run_sharded(a, world, rank, device, rehearsal, sd_local, sd_global, vae_note
                        "frames_held_by_rank0_shards": held, "vae": vae_note, "precision": a.precision,
                        "collective": None if world == 1 else ("all_gather_indexed" if stream else "all_gather_windows")},
             "all_finished": fin, "mpjpe_optimised_mm": mp, "graph": gs,
+            "evaluations_per_rank": {"sum": [round(v) for v in ev], "max_over_mean": round(max(ev) / max(1e-9, sum(ev) / len(ev)), 4)},
         }
-        print(json.dumps(line), flush=True)
+        if emit:
+            print(json.dumps(line), flush=True)
     eng.close()
+    del shards
+    torch.cuda.empty_cache()
     if world > 1:
         dist.barrier()
-        dist.destroy_process_group()
+        if emit:
+            dist.destroy_process_group()
+    return line
 
 
 def main():
@@ -469,6 +514,18 @@ def main():
     # decoder / fp32 energy": 20 + 27 + 27 + 27 + 27 = 128 chunks = 1536 windows in ONE call, fp32 and bf16 -- and configs[3]'s
     # per-GPU shard -- exactly 8192 windows (the first 8192 of 683 chunks' 8196), bf16 -- each with the roofline of its own dominant kernels (HIP events on
     # the launch stream; kernel names as recorded by the library at launch time)
+    def lbfgs_record(e, ms_k, n_k, step_s, n_windows, mode):
+        """`lbfgs_advance_kernel` moves vectors, it does no matrix work: priced against HBM with the bytes of the committed PMC
+        passes of the same workload (per launch, dispatch-weighted)."""
+        names = e.profile_kernels(2)
+        tr_b, tr_src = committed_traffic(names, n_windows, mode) if names else (None, None)
+        r = {"bound": "hbm", "kernel": names, "launches": int(n_k), "avg_us": round(ms_k * 1e3 / n_k, 2), "share_of_step": round(ms_k * 1e-3 / step_s, 3),
+             "peak": PEAK_HBM_GBPS, "unit": "GB/s", "traffic": tr_b, "traffic_source": tr_src, "achieved": None, "frac": None}
+        if tr_b:
+            r["achieved"] = round(tr_b / (ms_k * 1e-3 / n_k) / 1e9, 1)
+            r["frac"] = round(r["achieved"] / PEAK_HBM_GBPS, 4)
+        return r
+
     def side_record(nc2, modes, seed, what, limit=None):
         rec_all = {}
         B_all = nc2 * len(window_starts(CHUNK))
@@ -523,15 +580,15 @@ def main():
                         rec["energy_kernel"] = {"kernel": names, "launches": int(n_k), "avg_us": round(ms_k * 1e3 / n_k, 2),
                                                 "share_of_step": round(ms_k * 1e-3 / (dt / n2), 3)}
                         continue
-                    pk = PEAK_BF16_MATRIX_TFLOPS if mode == "bf16" else PEAK_F32_MATRIX_TFLOPS
+                    pk = PEAK_BF16_MATRIX_TFLOPS if (mode == "bf16" and "decoder_tail_kernel" not in names) else PEAK_F32_MATRIX_TFLOPS
                     ach = fl_k / (ms_k * 1e-3) / 1e12
-                    tr_b, tr_src = committed_traffic(names)
-                    rec[key] = {"bound": "mfma", "achieved": round(ach, 2), "peak": pk, "unit": "TFLOP/s", "frac": round(ach / pk, 4),
+                    tr_b, tr_src = committed_traffic(names, B2, mode)
+                    rec[key] = {"bound": kernel_bound(names), "achieved": round(ach, 2), "peak": pk, "unit": "TFLOP/s", "frac": round(ach / pk, 4),
                                 "kernel": names, "launches": int(n_k), "avg_us": round(ms_k * 1e3 / n_k, 2), "flop_per_launch": fl_k / n_k,
                                 "share_of_step": round(ms_k * 1e-3 / (dt / n2), 3), "traffic": tr_b, "traffic_source": tr_src}
                 ms_k, n_k, _ = e2.profile_read(2)
                 if n_k:
-                    rec["lbfgs_advance"] = {"launches": int(n_k), "avg_us": round(ms_k * 1e3 / n_k, 2), "share_of_step": round(ms_k * 1e-3 / (dt / n2), 3)}
+                    rec["lbfgs_advance"] = lbfgs_record(e2, ms_k, n_k, dt / n2, B2, mode)
             rec_all[mode] = rec
         rec_all["workload"] = what % B2
         e2.close()
@@ -595,6 +652,65 @@ def main():
         e4.close()
         del seq4
 
+    # ---- side records of the MULTI-RANK default line (not `value`): BASELINE configs[3] and configs[4] as ONE job sharded over the
+    # ranks (strong scaling: 65 536 windows in contiguous shards; the 12 499 windows of one 100k-frame stream in block-cyclic
+    # shards + halo, graph replay, gather + merge) -- the legs `--workload configs3 | configs4` run alone.  The rehearsal (several
+    # ranks on one card) takes a sixteenth of the windows per rank so that the 2-rank test stays short.
+    strong = {}
+    if world > 1 and a.workload == "seq2k" and not a.no_extra:
+        import copy
+        for wl_name, n_def in (("configs3", 65536), ("configs4", 12499)):
+            a2 = copy.copy(a)
+            a2.workload, a2.precision, a2.dump, a2.emulate_ranks = wl_name, "bf16", None, 0
+            a2.windows = a.windows or (max(64 * world, n_def // 16) if rehearsal else n_def)
+            a2.steps, a2.warmup = max(2, min(a.steps, 5)), 1
+            strong[wl_name] = run_sharded(a2, world, rank, device, rehearsal, sd_local, sd_global,
+                                          "synthetic, fitted %d Adam steps (recon %.1f / %.1f mm)" % (a.fit_steps, err_l * 1e3, err_g * 1e3)
+                                          if a.vae != "structured" else "synthetic, structured", emit=False)
+
+    # ---- side record (not `value`): SURVEY 8f.3, the drop-in interface end to end -- `whole_sequence.optimize_directory` on this
+    # rank's sequence written as 20 chunk directories of `test_data.pkl` files (page-cached): un-pickling / raw-array cache reads,
+    # host -> device copies, the batched optimisation, device merge + report.  Host-inclusive windows/s, never `value`.
+    host_inclusive = None
+    if world == 1 and a.workload == "seq2k" and not a.no_extra and a.precision == "f32":
+        import pickle
+        import shutil
+        import tempfile
+        from globalegomocap_amd import whole_sequence as ws_mod
+        from globalegomocap_amd.optimizer import SequenceOptimizer
+        root_dir = tempfile.mkdtemp(prefix="gem_bench_seq_")
+        try:
+            heat_np = seqd["heat"].cpu().numpy()
+            for c in range(n_chunks):
+                sl = slice(c * CHUNK, (c + 1) * CHUNK)
+                dch = os.path.join(root_dir, "chunk_%d" % c)
+                os.makedirs(dch)
+                with open(os.path.join(dch, "test_data.pkl"), "wb") as f:
+                    pickle.dump({"estimated_local_skeleton": list(seqd["est_local_np"][sl]), "gt_global_skeleton": list(seqd["gt_global"][sl]),
+                                 "camera_pose_list": list(seqd["cams_np"][sl]), "heatmap_list": list(heat_np[sl])}, f, protocol=4)
+            del heat_np
+            opt = SequenceOptimizer(DEFAULT_CALIBRATION, sd_global, sd_local, max_windows=B)
+            host_inclusive = {"frames": int(n_frames), "windows": int(B), "pickle_bytes": int(sum(
+                os.path.getsize(os.path.join(root_dir, dn, "test_data.pkl")) for dn in os.listdir(root_dir)))}
+            for tag, sidecar in (("pickles_only", False), ("raw_array_cache", True)):
+                ws_mod.optimize_directory(root_dir, DEFAULT_CALIBRATION, optimizer=opt, verbose=False, sidecar=sidecar)      # warm-up (writes the cache)
+                best, summ = None, None
+                for _ in range(3 if not sidecar else 5):
+                    torch.cuda.synchronize()
+                    th = time.perf_counter()
+                    summ = ws_mod.optimize_directory(root_dir, DEFAULT_CALIBRATION, optimizer=opt, verbose=False, sidecar=sidecar)[0]
+                    torch.cuda.synchronize()
+                    dtw = time.perf_counter() - th
+                    best = dtw if best is None else min(best, dtw)
+                host_inclusive[tag] = {"ms_end_to_end": round(best * 1e3, 2), "windows_per_s": round(B / best, 1),
+                                       "optimized_global_mpjpe_mm": round(float(summ["optimized_global_mpjpe"]) * 1e3, 3)}
+            host_inclusive["what"] = ("whole_sequence.optimize_directory (the reference's optimize_whole_sequence.py:48-118) on 20 chunk directories, page-cached "
+                                      "files, best of 3 / 5 calls: read + host-to-device + optimise + device merge / report; pickles_only = the reference's "
+                                      "files as they are, raw_array_cache = with the opt-in one-file cache next to every pickle")
+            opt.engine.close()
+        finally:
+            shutil.rmtree(root_dir, ignore_errors=True)
+
     if rank == 0:
         st = stats_to_numpy(stats)
         assert st["finished"].all(), "a window did not finish"
@@ -619,6 +735,7 @@ def main():
                            "mpjpe_optimised_mm": round(seq_mpjpe(gl) * 1e3, 3)} for m, (dt, gl) in other.items()}
         roof = None
         roof_other = None
+        roof_lbfgs = None
         if profile:
             # HIP-event timings of the two kernel families that carry the step: family 0 = the matrix products around the latent
             # (decoder_input o conv 0 composed into one layer, forward + backward-data), family 1 = the fused decoder tail.
@@ -638,11 +755,14 @@ def main():
                 ms, n, fl, names = fam[k]
                 achieved = fl / (ms * 1e-3) / 1e12
                 pk = peak if (k == 0 or "bf16" in names) else PEAK_F32_MATRIX_TFLOPS        # (the one-window tail is fp32 in every mode)
-                tr_b, tr_src = committed_traffic(names)
-                return {"bound": "mfma", "achieved": round(achieved, 3), "peak": round(pk, 1), "unit": "TFLOP/s", "frac": round(achieved / pk, 4),
+                tr_b, tr_src = committed_traffic(names, B, a.precision)
+                return {"bound": kernel_bound(names) if k == 1 else "mfma", "achieved": round(achieved, 3), "peak": round(pk, 1), "unit": "TFLOP/s", "frac": round(achieved / pk, 4),
                         "traffic": tr_b, "traffic_source": tr_src, "kernel": names, "what": what[k], "launches": int(n),
                         "avg_us": round(ms * 1e3 / n, 2), "flop_per_launch": fl / n,
                         "share_of_step": round(ms * 1e-3 / min(PROFILE_STEPS, a.steps) / (elapsed / a.steps), 3)}
+            ms2, n2k, _ = eng.profile_read(2)
+            if n2k:
+                roof_lbfgs = lbfgs_record(eng, ms2, n2k, min(PROFILE_STEPS, a.steps) * (elapsed / a.steps), B, a.precision)
             if fam:
                 dom = max(fam, key=lambda k: fam[k][0])
                 roof = roof_of(dom)
@@ -738,12 +858,33 @@ def main():
             ms = e0.elapsed_time(e1) / 20
             n_par = trn.n_params
             trn.close()
+            # the same step at batch 1024: the matrix products carry it (forward, backward-data and weight gradients: 3 x 2 x 42.32 M
+            # multiply-adds per window), priced against the fp32 matrix peak
+            tb2 = 1024
+            tw2 = torch.as_tensor(synth_mod.make_training_windows(tb2, shape.seq_len, 1), device=device)
+            te2 = torch.as_tensor(np.random.default_rng(1).standard_normal((tb2, shape.latent_dim)).astype(np.float32), device=device)
+            trn2 = VAETrainer(shape, batch_size=tb2, lr=1e-4, state_dict=init)
+            for _ in range(2):
+                trn2.step(tw2, 0.01, eps=te2, sync=False)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(10):
+                trn2.step(tw2, 0.01, eps=te2, sync=False)
+            e1.record()
+            torch.cuda.synchronize()
+            ms2 = e0.elapsed_time(e1) / 10
+            trn2.close()
+            del tw2, te2
+            flop_w = 3 * 2 * (26341760 + 15978880)
             # algorithmic HBM bytes of a step: Adam reads p, g, m, v and writes p, m, v; forward and backward-data read every weight
             # once each; the weight gradients are written once (activations are small beside the 130 MB arena at this batch)
             alg_bytes = n_par * 4 * (7 + 2 + 1)
             train = {"batch": tb, "ms_per_step": round(ms, 4), "windows_per_s": round(tb / ms * 1e3, 1), "parameters_padded": int(n_par),
                      "algorithmic_bytes_per_step": int(alg_bytes), "achieved_GBps": round(alg_bytes / ms / 1e6, 1),
-                     "frac_of_hbm_peak": round(alg_bytes / ms / 1e6 / PEAK_HBM_GBPS, 4), "dtype": "f32", "cpu_baseline": None}
+                     "frac_of_hbm_peak": round(alg_bytes / ms / 1e6 / PEAK_HBM_GBPS, 4), "dtype": "f32", "cpu_baseline": None,
+                     "batch_1024": {"ms_per_step": round(ms2, 4), "windows_per_s": round(tb2 / ms2 * 1e3, 1), "flop_per_window": flop_w,
+                                    "roofline": {"bound": "mfma", "achieved": round(tb2 * flop_w / ms2 / 1e9, 2), "peak": PEAK_F32_MATRIX_TFLOPS,
+                                                 "unit": "TFLOP/s", "frac": round(tb2 * flop_w / ms2 / 1e9 / PEAK_F32_MATRIX_TFLOPS, 4)}}}
             if a.cpu_windows > 0:          # the cpu_baseline leg of this record: the torch-CPU port of the same step on the host cores
                 from oracle.torch_port import TrainPort
                 nthreads = torch.get_num_threads()
@@ -785,11 +926,14 @@ def main():
             "train": train,
             "roofline": roof,
             "roofline_other": roof_other,
+            "roofline_lbfgs": roof_lbfgs,
             "cpu_baseline": cpu,
+            "host_inclusive": host_inclusive,
             "other_precisions": other_modes or None,
             "configs2": configs2,
-            "configs3": configs3,
-            "configs4": configs4,
+            # one GPU: the per-GPU shards of configs[3] / configs[4]; several ranks: the whole jobs, sharded (scaling: strong)
+            "configs3": configs3 if world == 1 else strong.get("configs3"),
+            "configs4": configs4 if world == 1 else strong.get("configs4"),
             "sequences_in_flight": in_flight,
         }
         print(json.dumps(line), flush=True)

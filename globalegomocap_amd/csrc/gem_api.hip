@@ -372,6 +372,7 @@ int gem_load_vae(gem_handle* h, int stage, int n_blobs, const float* const* blob
     StageNet& net = h->net[stage];
     if (net.loaded) GEM_HIP(hipDeviceSynchronize());      // reloading: launches that still read the old weights must be done
     drop_graphs(h);                                       // captured calls hold pointers to the weights freed below
+    ++h->cfg_gen;                                         // a second lane mirrors the new StageNet on its next call
     free_all(net.allocs);
     net = StageNet();
     int bi = 0;
@@ -812,6 +813,9 @@ static int ensure_lane(gem_handle* h, int B_lane) {
 }
 static void sync_lane(gem_handle* h) {          // the lane evaluates the same networks with the same settings (weights are shared, not copied)
     gem_handle* l = h->lane2;
+    l->prof.on = false;
+    if (h->lane_gen == h->cfg_gen) return;      // nothing loaded or switched since the last two-lane call (incl. every graph replay)
+    h->lane_gen = h->cfg_gen;
     for (int st = 0; st < 2; ++st) {
         l->net[st] = h->net[st];
         l->net[st].allocs.clear();              // owned by h
@@ -1046,6 +1050,7 @@ int gem_read_trace(gem_handle* h, int B, int n_rounds, double* d_out, void* stre
 int gem_set_texel_cache(gem_handle* h, int on) {
     if (!h) { set_error("gem_set_texel_cache: null handle"); return 1; }
     h->tex_cache = on != 0;
+    ++h->cfg_gen;
     return 0;
 }
 
@@ -1071,6 +1076,7 @@ int gem_set_lanes(gem_handle* h, int min_windows) {
 int gem_set_precision(gem_handle* h, int mode) {
     if (!h || mode < 0 || mode > 2) { set_error("gem_set_precision: mode must be 0 (f32), 1 (bf16x3) or 2 (bf16)"); return 1; }
     h->precision = mode;
+    ++h->cfg_gen;
     return 0;
 }
 

@@ -245,6 +245,8 @@ struct gem_handle {
     int lanes_min = 0;             // gem_set_lanes: batches of at least this many windows run as two lanes (0: never = the default
                                    // since round 4: with two tail workgroups per CU one lane is the faster arrangement)
     int last_split = 0;            // windows in the first lane of the last gem_optimize_windows call (0: one lane)
+    uint64_t cfg_gen = 1;          // bumped by gem_load_vae / gem_set_precision / gem_set_texel_cache: what a second lane mirrors
+    uint64_t lane_gen = 0;         // ... and the generation the second lane was last synchronised with
 };
 
 namespace gem {

@@ -641,16 +641,21 @@ int launch_lbfgs_advance(gem_handle* h, int B, const gem_lbfgs_opts& o, hipStrea
         GEM_HIP(hipEventRecord(rec.a, s));
     }
     const int ept = (h->Dp + 255) / 256;
-    if (ept <= 1) hipLaunchKernelGGL((lbfgs_advance_kernel<1, false>), dim3(B), dim3(256), 0, s, a);
-    else if (ept <= 2) hipLaunchKernelGGL((lbfgs_advance_kernel<2, false>), dim3(B), dim3(256), 0, s, a);
-    else if (ept <= 4) hipLaunchKernelGGL((lbfgs_advance_kernel<4, false>), dim3(B), dim3(256), 0, s, a);
-    else if (h->Dp == 2048 && h->precision == GEM_PRECISION_BF16) hipLaunchKernelGGL((lbfgs_advance_kernel<8, true, true>), dim3(B), dim3(256), 0, s, a);
-    else if (h->Dp == 2048) hipLaunchKernelGGL((lbfgs_advance_kernel<8, true>), dim3(B), dim3(256), 0, s, a);       // the reference's latent size
-    else if (ept <= 8) hipLaunchKernelGGL((lbfgs_advance_kernel<8, false>), dim3(B), dim3(256), 0, s, a);
-    else if (ept <= 16) hipLaunchKernelGGL((lbfgs_advance_kernel<16, false>), dim3(B), dim3(256), 0, s, a);
+    typedef void (*kern_t)(AdvArgs);
+    kern_t kern = nullptr;
+    if (ept <= 1) kern = lbfgs_advance_kernel<1, false>;
+    else if (ept <= 2) kern = lbfgs_advance_kernel<2, false>;
+    else if (ept <= 4) kern = lbfgs_advance_kernel<4, false>;
+    else if (h->Dp == 2048 && h->precision == GEM_PRECISION_BF16) kern = lbfgs_advance_kernel<8, true, true>;
+    else if (h->Dp == 2048) kern = lbfgs_advance_kernel<8, true>;       // the reference's latent size
+    else if (ept <= 8) kern = lbfgs_advance_kernel<8, false>;
+    else if (ept <= 16) kern = lbfgs_advance_kernel<16, false>;
     else { set_error("latent_dim > 4096 is not supported by the L-BFGS kernel"); return 1; }
+    note_kernel(h, reinterpret_cast<const void*>(kern));
+    hipLaunchKernelGGL(kern, dim3(B), dim3(256), 0, s, a);
     GEM_HIP(hipGetLastError());
     if (prof) { GEM_HIP(hipEventRecord(rec.b, s)); h->prof.recs.push_back(rec); }
+    commit_kernel_names(h, prof ? 2 : -1);
     return 0;
 }
 

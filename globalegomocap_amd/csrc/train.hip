@@ -588,11 +588,13 @@ int gem_trainer_step(gem_trainer* t, int B, const float* d_pose, const float* d_
     // g = dh0 [B, T*topp]: decoder_input
     { const TrainLinear& l = t->dec_in;
       hipLaunchKernelGGL(colsum_kernel, dim3(l.N / 16), dim3(BN_THREADS), 0, s, (const float*)g, B, l.N, t->G + l.ob);
+      GEM_HIP(hipGetLastError());
       if (weight_grad<1>(t, g, l.N, t->z, l.K, B, l.N, l.K, l.ow, l.slab, TN_ROWS_LINEAR, s)) return 1;
       Layer L; L.taps = 1; L.K = l.N; L.N = l.K; L.w = l.adj; L.bias = nullptr;
       if (linear_gemm(t, L, EPI_NONE, g, l.N, t->dz, l.K, B, s)) return 1; }
     hipLaunchKernelGGL(latent_bwd_kernel, dim3(n_pl), dim3(LOSS_BLOCK), 0, s, (const float*)t->mulv, d_eps, (const float*)t->dz, B, t->D, t->Dp,
                        (float)(o->kld_weight / B), t->dmulv, part_latent);
+    GEM_HIP(hipGetLastError());
     hipLaunchKernelGGL(finish_loss_kernel, dim3(1), dim3(256), 0, s, (const double*)part_recon, n_pr, (const double*)part_latent, n_pl, n_recon,
                        o->kld_weight, B, t->red + 4);
     GEM_HIP(hipGetLastError());
@@ -600,6 +602,7 @@ int gem_trainer_step(gem_trainer* t, int B, const float* d_pose, const float* d_
     { const TrainLinear& l = t->fc;
       const float* flat = t->enc.back().out;
       hipLaunchKernelGGL(colsum_kernel, dim3(l.N / 16), dim3(BN_THREADS), 0, s, (const float*)t->dmulv, B, l.N, t->G + l.ob);
+      GEM_HIP(hipGetLastError());
       if (weight_grad<1>(t, t->dmulv, l.N, flat, l.K, B, l.N, l.K, l.ow, l.slab, TN_ROWS_LINEAR, s)) return 1;
       Layer L; L.taps = 1; L.K = l.N; L.N = l.K; L.w = l.adj; L.bias = nullptr;
       g = t->gA; g2 = t->gB;
@@ -619,8 +622,12 @@ int gem_trainer_step(gem_trainer* t, int B, const float* d_pose, const float* d_
     }
     // the weight-gradient slabs -> the gradient arena (slab order: deterministic)
     { const int ns_conv = (rows + TN_ROWS_CONV - 1) / TN_ROWS_CONV, ns_lin = (B + TN_ROWS_LINEAR - 1) / TN_ROWS_LINEAR;
-      if (ns_conv > 1 && t->n_sum > 0)
+      // (every conv layer's weight_grad<3> call above cut the same `rows` into slabs of TN_ROWS_CONV rows: ONE slab count serves
+      // the whole table; the two linear layers' entries sit behind the conv entries)
+      if (ns_conv > 1 && t->n_sum > 0) {
           hipLaunchKernelGGL(slab_sum_all_kernel, dim3((unsigned)((t->sum_max / 4 + 255) / 256), t->n_sum), dim3(256), 0, s, (const SumDesc*)t->sum_tab, ns_conv);
+          GEM_HIP(hipGetLastError());
+      }
       if (ns_lin > 1)
           hipLaunchKernelGGL(slab_sum_all_kernel, dim3((unsigned)((t->sum_max / 4 + 255) / 256), 2), dim3(256), 0, s, (const SumDesc*)t->sum_tab + t->n_sum, ns_lin);
       GEM_HIP(hipGetLastError()); }

@@ -216,6 +216,7 @@ class VAETrainer:
                                        weight_decay=float(weight_decay), kld_weight=0.0, bn_momentum=float(bn_momentum),
                                        recon_sum=1 if recon_reduction == "sum" else 0, reserved=0)
         self.steps = 0
+        self.forwards = 0
         self._grad = None
         self._losses = torch.zeros(3, dtype=torch.float64, device=self.device)
         self._gen = torch.Generator(device=self.device)
@@ -246,13 +247,75 @@ class VAETrainer:
         return a
 
     def load_state_dict(self, state):
-        """network.load_state_dict: parameters and running statistics; Adam's moments and step count start over."""
+        """network.load_state_dict: parameters, running statistics and BatchNorm's num_batches_tracked (when the dict carries it);
+        Adam's moments and step count start over (load_optimizer_state restores them)."""
+        from . import _capi
         P, S = pack_arena(state, self.shape)
         self._up(0, P)
         self._up(2, S)
         self._up(3, np.zeros_like(P))
         self._up(4, np.zeros_like(P))
         self.steps = 0
+        _capi.check(self.lib.gem_trainer_set_step(self._t, 0), self.lib)
+        nbt = [int(np.asarray(v)) for k, v in state.items() if k.endswith("num_batches_tracked")]
+        self.forwards = nbt[0] if nbt else 0
+
+    def _param_keys(self):
+        """Keys of network.parameters() in registration order (the reference's ConvVAE: SeqConvVAE.py:11-92) = the state_dict order
+        without the BatchNorm buffers."""
+        return [k for k in self.shape.schema() if not (k.endswith("running_mean") or k.endswith("running_var") or k.endswith("num_batches_tracked"))]
+
+    def torch_optimizer_state_dict(self):
+        """`torch.optim.Adam.state_dict()` of the reference's optimizer (networks/train.py:102-108 saves exactly that): 'state'
+        indexed by parameter position with 'step' / 'exp_avg' / 'exp_avg_sq', one entry in 'param_groups'.
+        `torch.optim.Adam(network.parameters()).load_state_dict(...)` accepts it."""
+        import torch
+        opt = self.optimizer_state()
+        keys = self._param_keys()
+        state = {i: {"step": torch.tensor(float(opt["step"])), "exp_avg": torch.from_numpy(np.array(opt["exp_avg"][k])),
+                     "exp_avg_sq": torch.from_numpy(np.array(opt["exp_avg_sq"][k]))} for i, k in enumerate(keys)} if opt["step"] > 0 else {}
+        group = {"lr": self.opts.lr, "betas": (self.opts.beta1, self.opts.beta2), "eps": self.opts.eps, "weight_decay": self.opts.weight_decay,
+                 "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "decoupled_weight_decay": False, "params": list(range(len(keys)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_optimizer_state(self, opt_sd):
+        """Resume: Adam's moments and step count from `torch.optim.Adam.state_dict()` (the reference's checkpoints, and this
+        class's own), or from this class's `optimizer_state()` dict."""
+        from . import _capi
+        keys = self._param_keys()
+        if "state" in opt_sd:
+            st = opt_sd["state"]
+            if not st:
+                step, m, v = 0, {}, {}
+            else:
+                step = int(round(float(np.asarray(st[0]["step"]))))
+                m = {k: np.asarray(st[i]["exp_avg"], np.float32) for i, k in enumerate(keys)}
+                v = {k: np.asarray(st[i]["exp_avg_sq"], np.float32) for i, k in enumerate(keys)}
+            g = opt_sd["param_groups"][0]
+            self.opts.lr, self.opts.eps, self.opts.weight_decay = float(g["lr"]), float(g["eps"]), float(g["weight_decay"])
+            self.opts.beta1, self.opts.beta2 = float(g["betas"][0]), float(g["betas"][1])
+        else:
+            step = int(opt_sd["step"])
+            m = {k: np.asarray(x, np.float32) for k, x in opt_sd["exp_avg"].items()}
+            v = {k: np.asarray(x, np.float32) for k, x in opt_sd["exp_avg_sq"].items()}
+        zeros = {k: np.zeros(shp, np.float32) for k, shp in self.shape.schema().items()}
+        for what, d in ((3, m), (4, v)):
+            full = dict(zeros)
+            full.update(d)
+            self._up(what, pack_arena(full, self.shape)[0])
+        self.steps = step
+        _capi.check(self.lib.gem_trainer_set_step(self._t, step), self.lib)
+
+    def load_checkpoint(self, path):
+        """A checkpoint of `fit` (or of the reference's networks/train.py:102-108): weights, statistics, Adam state.  Returns the
+        epoch it was written after."""
+        import torch
+        ck = torch.load(path, map_location="cpu", weights_only=False)
+        self.load_state_dict({k: np.asarray(v) for k, v in ck["state_dict"].items()})
+        if ck.get("optimizer"):
+            self.load_optimizer_state(ck["optimizer"])
+        return int(ck.get("epoch", 0))
 
     def state_dict(self):
         """network.state_dict() in the reference's schema (numpy arrays; incl. num_batches_tracked like torch's BatchNorm)."""
@@ -261,7 +324,8 @@ class VAETrainer:
         for k, v in sd.items():
             out[k] = v
             if k.endswith("running_var"):
-                out[k[:-len("running_var")] + "num_batches_tracked"] = np.array(self.steps, np.int64)
+                # (torch counts FORWARD passes in train mode, not optimiser steps: gradient-only passes count too)
+                out[k[:-len("running_var")] + "num_batches_tracked"] = np.array(self.forwards, np.int64)
         return out
 
     def gradients(self):
@@ -292,6 +356,7 @@ class VAETrainer:
         s = torch.cuda.current_stream(self.device).cuda_stream
         _capi.check(self.lib.gem_trainer_step(self._t, B, x.data_ptr(), e.data_ptr(), C.byref(self.opts), 1 if update else 0,
                                               self._losses.data_ptr(), C.c_void_p(s)), self.lib)
+        self.forwards += 1               # every train-mode forward updates the running statistics (like torch's BatchNorm)
         if update:
             self.steps += 1
         if not sync:
@@ -406,11 +471,9 @@ class VAETrainer:
             if checkpoint_dir is not None:
                 os.makedirs(checkpoint_dir, exist_ok=True)
                 sd = OrderedDict((k, torch.from_numpy(np.array(v))) for k, v in self.state_dict().items())
-                opt = self.optimizer_state()
+                # (train.py:102-108: 'optimizer' is torch.optim.Adam.state_dict(); same schema here, so either side resumes the other's file)
                 torch.save({"epoch": e + 1, "args": dict(args or {}), "state_dict": sd, "eval_result": eval_loss,
-                            "optimizer": {"step": opt["step"],
-                                          "exp_avg": {k: torch.from_numpy(v) for k, v in opt["exp_avg"].items()},
-                                          "exp_avg_sq": {k: torch.from_numpy(v) for k, v in opt["exp_avg_sq"].items()}}},
+                            "optimizer": self.torch_optimizer_state_dict()},
                            os.path.join(checkpoint_dir, str(e) + ".pth.tar"))
         return history
 

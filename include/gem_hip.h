@@ -95,11 +95,16 @@ void gem_destroy(gem_handle* h);
  * devices / batch shapes where the split pays.  Costs a second workspace (half the size of the first) when switched on. */
 int gem_set_lanes(gem_handle* h, int min_windows);
 
-/* Arithmetic of the wide decoder / encoder products (the narrow tail layers and every energy term are
- * always fp32):  0 = fp32 MFMA (default, BASELINE configs[1]);
- *                1 = "bf16x3": operands split into bf16 hi+lo, three bf16 MFMAs per product, fp32 accumulate
- *                    (error ~2^-16 relative, i.e. fp32-grade, at ~1.5x the fp32 rate);
- *                2 = bf16 operands, fp32 accumulate (BASELINE configs[2..3] "bf16 VAE decoder / fp32 energy").
+/* Arithmetic of the decoder / encoder products (every energy term is always fp32 arithmetic on the fp32 decoded pose):
+ *   0 = fp32 MFMA everywhere (default, BASELINE configs[1]);
+ *   1 = "bf16x3": operands of the wide products split into bf16 hi+lo, three bf16 MFMAs per product, fp32 accumulate
+ *       (error ~2^-16 relative, i.e. fp32-grade, at ~1.5x the fp32 rate); the narrow tail layers stay fp32;
+ *   2 = bf16 operands, fp32 accumulate (BASELINE configs[2..4] "bf16 VAE decoder / fp32 energy"): the wide products always; the
+ *       narrow tail layers too from 256 windows per call on (csrc/tail_bf16.hip: bf16 weights and bf16 activations between the
+ *       layers; below 256 windows the fp32 one-window tail runs them).  A window's bf16 result therefore depends on which side of
+ *       that threshold its batch falls; either way it is the fp32 result plus zero-mean noise of the order of 2^-9 per decoded
+ *       coordinate (tests/test_hip_full_size.py::test_bf16_on_fitted_vae_against_the_oracle: ~1.3 mm per window on fitted
+ *       weights, 0.06 mm on a sequence's MPJPE).
  * May be switched at any time between calls. */
 enum { GEM_PRECISION_F32 = 0, GEM_PRECISION_BF16X3 = 1, GEM_PRECISION_BF16 = 2 };
 int gem_set_precision(gem_handle* h, int mode);

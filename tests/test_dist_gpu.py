@@ -81,3 +81,20 @@ def test_two_rank_rehearsal_of_the_sharded_bench_legs_is_bitwise_the_emulated_sh
         # one batch of all windows: same windows, another split-K cut -> rounding-level (fp32) / bf16-level differences
         d = np.linalg.norm(a["glob"] - c["glob"], axis=-1).mean()
         assert d < (0.5e-3 if precision == "f32" else 8e-3), d          # (bf16 on the structured VAEs: DESIGN.md 5.1)
+
+
+def test_default_two_rank_line_carries_the_strong_scaling_legs():
+    """`bench.py --gpus 2` with default flags (what the driver runs with N > 1): the weak-scaling `value` of BASELINE configs[1]
+    PLUS, as side records of the same JSON line, configs[3] and configs[4] as ONE job each sharded over the two ranks (scaling
+    "strong", ranks 2, the per-rank evaluation sums = the load-imbalance term of SURVEY.md 8e).  Two real ranks on the one card
+    of the test box over gloo (GEM_BENCH_REHEARSAL=1; the rehearsal takes a sixteenth of the windows)."""
+    line = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--vae", "structured", "--cpu-windows", "0", "--no-profile"],
+                      {"GEM_BENCH_REHEARSAL": "1"}, timeout=1500)
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["ranks"] == 2 and line["value"] > 0
+    for key, n_windows in (("configs3", 65536 // 16), ("configs4", 12499 // 16)):
+        rec = line[key]
+        assert rec is not None and rec["scaling"] == "strong" and rec["n_gpus"] == 2 and rec["config"]["ranks"] == 2, (key, rec)
+        assert rec["config"]["windows_total"] == n_windows and rec["all_finished"] and rec["value"] > 0, (key, rec)
+        ev = rec["evaluations_per_rank"]
+        assert len(ev["sum"]) == 2 and min(ev["sum"]) > 0 and 1.0 <= ev["max_over_mean"] < 1.5, (key, ev)
+    assert line["configs4"]["graph"]["replays"] >= 1

@@ -146,6 +146,49 @@ def test_fit_lowers_the_loss_and_writes_the_reference_checkpoint_schema(tmp_path
         tr.close()
 
 
+def test_checkpoint_carries_torch_adam_state_and_resumes_bitwise(tmp_path):
+    """networks/train.py:102-108 saves `optimizer.state_dict()`: the checkpoint's 'optimizer' entry must load into
+    torch.optim.Adam over a network with the reference's parameter order (here the CPU port's MotionVAE: same names, same
+    order), and a fresh trainer that loads the checkpoint continues exactly where the first one stands: next step bitwise equal.
+    BatchNorm's num_batches_tracked counts train-mode forwards (gradient-only passes included), like torch's."""
+    import torch
+    from globalegomocap_amd.vae_train import VAETrainer, initial_state_dict
+    from oracle.torch_port import TrainPort
+    shape = vae_schema.VAEShape(latent_dim=64, hidden=(32, 64))
+    data = synth.make_training_windows(256, shape.seq_len, 7)
+    eps = np.random.default_rng(3).standard_normal((3, 64, shape.latent_dim)).astype(np.float32)
+    tr = VAETrainer(shape, batch_size=64, lr=1e-3, weight_decay=1e-4, seed=5)
+    tr2 = None
+    try:
+        tr.step(data[:64], 0.01, eps=eps[0], update=False)                  # a gradient-only pass: a forward, not a step
+        tr.fit(data, epochs=1, kl_weight=0.01, checkpoint_dir=str(tmp_path), log=lambda *a: None, test_windows=False)
+        ck = torch.load(os.path.join(str(tmp_path), "0.pth.tar"), map_location="cpu", weights_only=False)
+        assert int(ck["state_dict"]["encoder.0.1.num_batches_tracked"]) == 5 and tr.steps == 4
+        port = TrainPort(initial_state_dict(shape, 5), lr=1.0)
+        port.opt.load_state_dict(ck["optimizer"])                            # torch accepts the schema
+        st = port.opt.state_dict()
+        assert st["param_groups"][0]["lr"] == 1e-3 and st["param_groups"][0]["weight_decay"] == 1e-4
+        names = [k for k, _ in port.net.named_parameters()]
+        own = tr.optimizer_state()
+        for i, k in enumerate(names):
+            assert float(st["state"][i]["step"]) == 4.0
+            np.testing.assert_array_equal(st["state"][i]["exp_avg"].numpy(), own["exp_avg"][k], err_msg=k)
+            np.testing.assert_array_equal(st["state"][i]["exp_avg_sq"].numpy(), own["exp_avg_sq"][k], err_msg=k)
+        tr2 = VAETrainer(shape, batch_size=64, lr=7.0, seed=99)              # (everything that matters comes from the file)
+        assert tr2.load_checkpoint(os.path.join(str(tmp_path), "0.pth.tar")) == 1
+        assert tr2.steps == 4 and tr2.forwards == 5
+        a = tr.step(data[64:128], 0.01, eps=eps[1])
+        b = tr2.step(data[64:128], 0.01, eps=eps[1])
+        assert a == b
+        sa, sb = tr.state_dict(), tr2.state_dict()
+        for k in sa:
+            np.testing.assert_array_equal(sa[k], sb[k], err_msg=k)
+    finally:
+        tr.close()
+        if tr2 is not None:
+            tr2.close()
+
+
 def test_trainer_rejects_bad_arguments():
     from globalegomocap_amd import _capi
     from globalegomocap_amd.vae_train import VAETrainer
