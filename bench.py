@@ -372,7 +372,7 @@ def main():
     from globalegomocap_amd.sequence import window_starts, merge_batches, final_smooth
     from globalegomocap_amd.errors import mpjpe
 
-    n_chunks = {"seq2k": 20, "w8192": 683, "configs3": 0, "configs4": 0}.get(a.workload)
+    n_chunks = {"seq2k": 20, "w8192": 683, "w8192x": 683, "configs3": 0, "configs4": 0}.get(a.workload)
     if n_chunks is None:
         n_chunks = int(a.workload)
     shape = vae_schema.VAEShape()
@@ -397,6 +397,8 @@ def main():
     seqd = synth.make_sequence_device(n_frames, seed=1000 + rank, device=device, camera=cam, cam_jitter=CAM_JITTER)
     starts = np.concatenate([c * CHUNK + window_starts(CHUNK) for c in range(n_chunks)]).astype(np.int32)
     chunk_of = np.repeat(np.arange(n_chunks), len(window_starts(CHUNK)))
+    if a.workload == "w8192x":          # exactly 8192 windows: the first 8192 of the 683 chunks' 8196 (1024 tail workgroups, 32 row panels)
+        starts, chunk_of = starts[:8192], chunk_of[:8192]
     B = len(starts)
     eng = WindowEngine(shape, cam, max_windows=B)
     eng.load_vae(LOCAL_STAGE, sd_local)
@@ -910,7 +912,8 @@ def main():
             "config": {"workload": "%s: %d-frame sequence per GPU = %d chunks x %d windows = %d windows, %s wide products, "
                                    "local+global stage, L-BFGS max_iter 25 / max_eval 31; decoder_input and the first decoder conv run as ONE composed linear layer"
                                    % ({"seq2k": "BASELINE configs[1] (one ~2k-frame sequence, all windows in one batch)",
-                                       "w8192": "BASELINE configs[3] per-GPU shard (8192 windows; 683 chunks = 8196)"}
+                                       "w8192": "BASELINE configs[3] per-GPU shard (8192 windows; 683 chunks = 8196)",
+                                       "w8192x": "BASELINE configs[3] per-GPU shard (exactly 8192 windows: the first 8192 of 683 chunks)"}
                                       .get(a.workload, "custom workload (--workload %s)" % a.workload),
                                       n_frames, n_chunks, per, B, a.precision),
                        "windows_per_gpu": B, "latent_dim": shape.latent_dim, "parallelism": "window-shards x%d" % world,

@@ -8,8 +8,9 @@
 // Conv1d taps [3][N][K], k contiguous; fc_mu | fc_var stacked; decoder_input time-major), with same-shaped arenas for gradient
 // and the two Adam moments; the reference's checkpoint schema is a permutation of that arena (host side: vae_train.py).  Padded
 // entries are zero and stay zero (their gradients are sums over zero activations).
-//   forward / backward-DATA products: the fp32 MFMA kernels of the optimiser (launch_gemm); the adjoint weight images of ALL
-//     layers are re-packed from the arena by ONE launch at the start of a step (adjoint_all_kernel, 64x64 tiles through LDS)
+//   forward / backward-DATA products: the fp32 MFMA kernels of the optimiser (launch_gemm); the adjoint weight images of the CONV
+//     layers (3 % of the parameters) are re-packed from the arena by ONE launch at the start of a step (adjoint_all_kernel); the
+//     two linear layers' backward-data products contract over the rows of the weights' own layout (linear_bwd_data, round 4)
 //   weight gradients: gemm_tn_kernel, dW[tap][n][k] = sum_r dC[r][n] * A[r + tap - 1][k] (contraction over the ROWS, both
 //     operands row-major: staged through LDS, v_mfma_f32_16x16x4_f32), row range cut into slabs of 64 rows (conv layers: small
 //     tensors, many rows) that ONE launch sums in slab order for all layers before Adam (slab_sum_all_kernel)
@@ -56,6 +57,7 @@ struct gem_trainer {
     float *P = nullptr, *G = nullptr, *M1 = nullptr, *M2 = nullptr, *S = nullptr;
     float *pose_p = nullptr, *mulv = nullptr, *z = nullptr, *h0 = nullptr, *Xp = nullptr;
     float *gA = nullptr, *gB = nullptr, *dmulv = nullptr, *dz = nullptr;
+    float *dYT = nullptr, *lin_slab = nullptr; int lin_slab_cap = 8;      // linear_bwd_data: transposed gradient [N][pad64(B)], K-slabs of dX
     double* red = nullptr;         // [8 + partial sums]: [4..6] loss, recon, kld; [8..) per-block partials of the two loss kernels
     gem::AdjDesc* adj_tab = nullptr; int n_adj = 0, adj_tiles = 0;
     gem::SumDesc* sum_tab = nullptr; int n_sum = 0; size_t sum_max = 0;
@@ -276,7 +278,32 @@ __global__ __launch_bounds__(256) void slab_sum_all_kernel(const SumDesc* __rest
     *reinterpret_cast<f32x4*>(d.out + i) = s;
 }
 
-// adjoint images for the backward-data products of every layer in one launch: conv [3][N][K] -> [3][K][N] with flipped taps,
+// dY [B][N] -> dY^T [N][Bp] (columns >= B zero): the row-major operand the rows-contracting kernel wants for the backward-data
+// product of a linear layer, dX[b][k] = sum_n dY[b][n] W[n][k], taken straight from W's own [N][K] layout (linear_bwd_data)
+__global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restrict__ src, int B, int N, int Bp, float* __restrict__ dst) {
+    __shared__ float tile[64][65];
+    const int n0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int b = b0 + ty + 4 * j;
+        tile[ty + 4 * j][tx] = b < B ? src[(size_t)b * N + n0 + tx] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) dst[(size_t)(n0 + ty + 4 * j) * Bp + b0 + tx] = tile[tx][ty + 4 * j];
+}
+// out[i] = sum over slabs (slab order), i < n_out <= n_slab_elems
+__global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slab, int nslab, size_t n_slab_elems, float* __restrict__ out, size_t n_out) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n_out) return;
+    f32x4 s = *reinterpret_cast<const f32x4*>(slab + i);
+    for (int z = 1; z < nslab; ++z) s += *reinterpret_cast<const f32x4*>(slab + (size_t)z * n_slab_elems + i);
+    *reinterpret_cast<f32x4*>(out + i) = s;
+}
+
+// adjoint images for the backward-data products of every CONV layer in one launch (the two linear layers -- 97 % of the parameters
+// -- need none: linear_bwd_data): conv [3][N][K] -> [3][K][N] with flipped taps,
 // linear [N][K] -> [K][N]; blockIdx.y = layer (table), blockIdx.x = (tap, 64x64 tile), transposed through LDS
 __global__ __launch_bounds__(256) void adjoint_all_kernel(const AdjDesc* __restrict__ tab) {
     __shared__ float tile[64][65];
@@ -402,6 +429,31 @@ static int linear_gemm(gem_trainer* t, const Layer& L, int epi, const float* A, 
     return 0;
 }
 
+// Backward-data of a linear layer from the weights' OWN layout: dX[b][k] = sum_n dY[b][n] W[n][k] is a contraction over the rows
+// of W -- what gemm_tn_kernel does (rows-contracting, both operands row-major) once dY is transposed (1.3 MB at the reference's
+// batch).  The n range is cut into slabs that fill the chip and are summed in slab order.  Replaces the adjoint image of the
+// layer (a 2 x 126 MB transpose of both linear layers' weights per step in round 3) and the few-rows product that read it.
+static int linear_bwd_data(gem_trainer* t, const float* dY, const float* W, float* dX, int B, int N, int K, hipStream_t s) {
+    const int Bp = pad64(B);
+    hipLaunchKernelGGL(transpose_pad_kernel, dim3(N / 64, Bp / 64), dim3(256), 0, s, dY, B, N, Bp, t->dYT);
+    GEM_HIP(hipGetLastError());
+    const int tiles = (Bp / 64) * (K / 64);
+    int nslab = (2 * t->h->n_cu + tiles - 1) / tiles;
+    nslab = std::max(1, std::min(nslab, std::min(N / 64, t->lin_slab_cap)));
+    int rps = ((N + nslab - 1) / nslab + 31) / 32 * 32;
+    nslab = (N + rps - 1) / rps;
+    float* out = nslab > 1 ? t->lin_slab : dX;
+    if (nslab == 1 && Bp != B) { set_error("train: linear backward-data without slabs needs a batch that is a multiple of 64"); return 1; }
+    hipLaunchKernelGGL(gemm_tn_kernel<1>, dim3(tiles, 1, nslab), dim3(256), 0, s, (const float*)t->dYT, Bp, W, K, out, N, Bp, K, t->T, rps);
+    GEM_HIP(hipGetLastError());
+    if (nslab > 1) {
+        const size_t n_out = (size_t)B * K;
+        hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((n_out / 4 + 255) / 256)), dim3(256), 0, s, (const float*)t->lin_slab, nslab, (size_t)Bp * K, dX, n_out);
+        GEM_HIP(hipGetLastError());
+    }
+    return 0;
+}
+
 }  // namespace gem
 
 using namespace gem;
@@ -455,8 +507,6 @@ int gem_trainer_create(const gem_config* cfg, gem_trainer** out) {
     p->n_sum = (int)sums.size();
     for (TrainLinear* l : {&p->fc, &p->dec_in}) {
         const size_t nw = (size_t)l->N * l->K;
-        if (talloc(p, &l->adj, nw)) return 1;
-        adj.push_back(AdjDesc{p->P + l->ow, l->adj, 1, l->N, l->K, (l->N / 64) * (l->K / 64)});
         if (lin_slabs > 1) {
             if (talloc(p, &l->slab, nw * lin_slabs)) return 1;
             sums.push_back(SumDesc{l->slab, p->G + l->ow, nw});
@@ -473,6 +523,8 @@ int gem_trainer_create(const gem_config* cfg, gem_trainer** out) {
     if (talloc(p, &p->pose_p, rows * PAD) || talloc(p, &p->mulv, (size_t)p->Bmax * 2 * p->Dp) || talloc(p, &p->z, (size_t)p->Bmax * p->Dp) ||
         talloc(p, &p->h0, rows * p->topp) || talloc(p, &p->Xp, rows * PAD) || talloc(p, &p->gA, rows * max_width) || talloc(p, &p->gB, rows * max_width) ||
         talloc(p, &p->dmulv, (size_t)p->Bmax * 2 * p->Dp) || talloc(p, &p->dz, (size_t)p->Bmax * p->Dp) ||
+        talloc(p, &p->dYT, (size_t)std::max(p->fc.N, p->dec_in.N) * pad64(p->Bmax)) ||
+        talloc(p, &p->lin_slab, (size_t)p->lin_slab_cap * pad64(p->Bmax) * std::max(p->fc.K, p->dec_in.K)) ||
         talloc(p, &p->red, (size_t)8 + p->part_recon + p->part_latent))
         return 1;
     *out = t.release();
@@ -590,8 +642,7 @@ int gem_trainer_step(gem_trainer* t, int B, const float* d_pose, const float* d_
       hipLaunchKernelGGL(colsum_kernel, dim3(l.N / 16), dim3(BN_THREADS), 0, s, (const float*)g, B, l.N, t->G + l.ob);
       GEM_HIP(hipGetLastError());
       if (weight_grad<1>(t, g, l.N, t->z, l.K, B, l.N, l.K, l.ow, l.slab, TN_ROWS_LINEAR, s)) return 1;
-      Layer L; L.taps = 1; L.K = l.N; L.N = l.K; L.w = l.adj; L.bias = nullptr;
-      if (linear_gemm(t, L, EPI_NONE, g, l.N, t->dz, l.K, B, s)) return 1; }
+      if (linear_bwd_data(t, g, t->P + l.ow, t->dz, B, l.N, l.K, s)) return 1; }
     hipLaunchKernelGGL(latent_bwd_kernel, dim3(n_pl), dim3(LOSS_BLOCK), 0, s, (const float*)t->mulv, d_eps, (const float*)t->dz, B, t->D, t->Dp,
                        (float)(o->kld_weight / B), t->dmulv, part_latent);
     GEM_HIP(hipGetLastError());
@@ -604,9 +655,8 @@ int gem_trainer_step(gem_trainer* t, int B, const float* d_pose, const float* d_
       hipLaunchKernelGGL(colsum_kernel, dim3(l.N / 16), dim3(BN_THREADS), 0, s, (const float*)t->dmulv, B, l.N, t->G + l.ob);
       GEM_HIP(hipGetLastError());
       if (weight_grad<1>(t, t->dmulv, l.N, flat, l.K, B, l.N, l.K, l.ow, l.slab, TN_ROWS_LINEAR, s)) return 1;
-      Layer L; L.taps = 1; L.K = l.N; L.N = l.K; L.w = l.adj; L.bias = nullptr;
       g = t->gA; g2 = t->gB;
-      if (linear_gemm(t, L, EPI_NONE, t->dmulv, l.N, g, l.K, B, s)) return 1; }
+      if (linear_bwd_data(t, t->dmulv, t->P + l.ow, g, B, l.N, l.K, s)) return 1; }
     // encoder
     for (int i = (int)t->enc.size() - 1; i >= 0; --i) {
         TrainConv& c = t->enc[i];

@@ -35,7 +35,7 @@ def kernel_stats(sub, out_name):
                         r["Percentage"], "%.2f" % (float(r["MinNs"]) / 1e3), "%.2f" % (float(r["MaxNs"]) / 1e3)])
 
 
-def traffic(sub, dominant_substr, out_name, note_cmd):
+def traffic(sub, dominant_substr, out_name, note_cmd, windows, precision):
     t = {}
     for key, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         f = glob.glob(os.path.join(src, sub, "pmc_" + key, "*", "*counter_summary.csv"))
@@ -44,14 +44,16 @@ def traffic(sub, dominant_substr, out_name, note_cmd):
         t[key] = {short(r["kernel"]): (float(r["mean_value"]), int(r["dispatches"])) for r in csv.DictReader(open(f[0])) if r["counter"] == counter}
     out = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `%s`; counters are in KiB; on gfx950 FETCH_SIZE "
                    "reports half of a wide coalesced stream, so read bytes = 2 * FETCH_SIZE * 1024 (MI355X_MICROARCH.md section HBM); "
-                   "per launch = mean over dispatches" % note_cmd, "kernels": {}}
+                   "per launch = mean over dispatches" % note_cmd,
+           # what bench.py's committed_traffic() matches on: a kernel's bytes are only ever reported for THIS workload
+           "workload": {"windows": windows, "precision": precision}, "kernels": {}}
     for k in sorted(set(t["fetch"]) | set(t["write"])):
         if not k.startswith("gem::"):
             continue
         fe, wr = t["fetch"].get(k, (0.0, 0)), t["write"].get(k, (0.0, 0))
         out["kernels"][k] = {"dispatches": fe[1], "fetch_kib_raw": round(fe[0], 1), "read_bytes_corrected": round(2 * fe[0] * 1024),
                              "write_bytes": round(wr[0] * 1024)}
-    dom = [k for k in out["kernels"] if dominant_substr in k]
+    dom = [k for k in out["kernels"] if any(d in k for d in dominant_substr.split("|"))]
     if dom:       # (forward and backward-data may be two instantiations: dispatch-weighted mean per launch)
         n = sum(out["kernels"][k]["dispatches"] for k in dom)
         out["dominant_kernel"] = " + ".join(dom)
@@ -64,7 +66,30 @@ def traffic(sub, dominant_substr, out_name, note_cmd):
 kernel_stats("f32", "kernel_stats_%s.csv" % tag)
 kernel_stats("f32_1536", "kernel_stats_%s_f32_1536_windows.csv" % tag)
 kernel_stats("bf16_1536", "kernel_stats_%s_bf16_1536_windows.csv" % tag)
-kernel_stats("bf16_8192", "kernel_stats_%s_bf16_8196_windows.csv" % tag)
+kernel_stats("bf16_8192", "kernel_stats_%s_bf16_8192_windows.csv" % tag)
+
+
+def train_stats(out_name):
+    """rocprofv3 --kernel-trace --stats of tools/train_bench.py 64 50, summarised like the others (per-step launch counts)."""
+    f = glob.glob(os.path.join(src, "train", "trace", "*", "*kernel_stats.csv"))
+    if not f:
+        return
+    rows = list(csv.DictReader(open(f[0])))
+    log = [l for l in open(os.path.join(src, "train", "trace.log")) if l.startswith("B=")]
+    steps = 55                                    # 5 warm-up + 50 timed steps of the tool
+    with open(os.path.join(dst, out_name), "w") as o:
+        o.write("# rocprofv3 --kernel-trace --stats of: python tools/train_bench.py 64 50 (%d steps in the trace); this run printed: %s\n"
+                % (steps, log[-1].strip() if log else "?"))
+        w = csv.writer(o)
+        w.writerow(["kernel", "calls", "calls_per_step", "total_ms", "avg_us", "pct", "min_us", "max_us"])
+        for r in rows:
+            if float(r["Percentage"]) < 0.05:
+                continue
+            w.writerow([short(r["Name"]), r["Calls"], "%.1f" % (int(r["Calls"]) / steps), "%.3f" % (float(r["TotalDurationNs"]) / 1e6),
+                        "%.2f" % (float(r["AverageNs"]) / 1e3), r["Percentage"], "%.2f" % (float(r["MinNs"]) / 1e3), "%.2f" % (float(r["MaxNs"]) / 1e3)])
+
+
+train_stats("kernel_stats_%s_train_b64.csv" % tag)
 # the dominant kernel of the headline run = the kernel (all instantiations of a template counted together) with the most time
 def total_ms(sub, substr):
     f = glob.glob(os.path.join(src, sub, "trace", "*", "*kernel_stats.csv"))
@@ -77,15 +102,15 @@ cands = {"decoder_tail_kernel": total_ms("f32", "decoder_tail_kernel"), "rows::g
 dom = max(cands, key=cands.get)
 print("headline run, total ms per kernel family:", cands, "->", dom)
 o = traffic("f32", dom, "traffic_%s.json" % tag,
-            "python bench.py --steps 2 --warmup 1 --cpu-windows 0 --no-extra --no-profile")
+            "python bench.py --steps 2 --warmup 1 --cpu-windows 0 --no-extra --no-profile", 240, "f32")
 if o and "dominant_kernel" in o:
     json.dump({k: o.get(k) for k in ("note", "dominant_kernel", "hbm_bytes_per_launch")}, open(os.path.join(dst, "traffic_dominant_kernel.json"), "w"), indent=1)
     print("headline dominant kernel:", o["dominant_kernel"], o["hbm_bytes_per_launch"], "bytes per launch")
-b = traffic("bf16_8192", "gemm_glds_kernel<false, 1, ", "traffic_%s_bf16_8196_windows.json" % tag,
-            "python bench.py --steps 1 --warmup 1 --workload w8192 --precision bf16 --cpu-windows 0 --no-extra --no-profile")
+b = traffic("bf16_8192", "gemm_glds_kernel<false, 1, |gemm_big_kernel", "traffic_%s_bf16_8192_windows.json" % tag,
+            "python bench.py --steps 1 --warmup 1 --workload w8192x --precision bf16 --cpu-windows 0 --no-extra --no-profile", 8192, "bf16")
 c = traffic("bf16_1536", "gemm_glds_kernel<false, 1, ", "traffic_%s_bf16_1536_windows.json" % tag,
-            "python bench.py --steps 2 --warmup 1 --workload 128 --precision bf16 --cpu-windows 0 --no-extra --no-profile")
+            "python bench.py --steps 2 --warmup 1 --workload 128 --precision bf16 --cpu-windows 0 --no-extra --no-profile", 1536, "bf16")
 if b:
     for k, v in b["kernels"].items():
-        if "glds" in k or "lbfgs" in k or "energy" in k or "tail" in k:
+        if "glds" in k or "big" in k or "lbfgs" in k or "energy" in k or "tail" in k:
             print(k, v)
