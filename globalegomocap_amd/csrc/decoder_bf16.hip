@@ -264,7 +264,8 @@ int evaluate_bf16(gem_handle* h, int stage, int B, const EnergyArgs& ea_in, hipS
             in = w.dec_act_b[i];
         }
         TailB16Args ta;
-        plan_tail_bf16(net.dec, st, T, h->J, &ta);
+        const size_t tb_lds = plan_tail_bf16(net.dec, st, T, h->J, &ta, tail_bf16_row_tiles(h, B, T));
+        if (!tb_lds) { set_error("evaluate_bf16: the bf16 tail's LDS plan failed"); return 1; }
         ta.B = B; ta.forward_only = forward_only ? 1 : 0; ta.dbg_ts = nullptr;
         ta.in_slab = in_slab; ta.in_bias = front ? net.front.bias : net.dec[st - 1].bias;
         ta.in_bias_ld = front ? net.dec[0].N : 0;
@@ -278,7 +279,7 @@ int evaluate_bf16(gem_handle* h, int stage, int B, const EnergyArgs& ea_in, hipS
         ta.Xp = (w.dyn && !forward_only) ? nullptr : w.dec_act.back();
         ta.wstream = net.tb_stream; ta.steps_f = net.tb_steps_f; ta.steps_total = net.tb_steps_f + net.tb_steps_b;
         ta.e = ea;
-        if (launch_tail_bf16(h, ta, net.tb_lds, s)) return 1;
+        if (launch_tail_bf16(h, ta, tb_lds, s)) return 1;
         if (forward_only) return 0;
         if (record_mid(h, s)) return 1;
         back_from = st - 1;

@@ -368,7 +368,7 @@ size_t plan_tail(const std::vector<Layer>& dec, int start, int T, int J, TailArg
 constexpr int TB_MAX_LAYERS = 6;
 struct TailB16Layer { int K, N; const float* bias; };
 struct TailB16Args {
-    int n, B, G, forward_only, mask_first;
+    int n, B, G, nrt, forward_only, mask_first;      // nrt: 16-row tiles per workgroup (5, 4 or 3); G = min(8, 16 nrt / T) windows
     SlabSrc in_slab;           // the input still lies in fp32 split-K slabs (+ in_bias, LeakyReLU to apply) when in_slab.base != nullptr
     const float* in_bias;      // bias of row r, column c: in_bias[(r % T) * in_bias_ld + c]
     int in_bias_ld;
@@ -388,7 +388,8 @@ struct TailB16Args {
     int off_x, escr, off_mb, off_zero, off_tab;
     EnergyArgs e;
 };
-size_t plan_tail_bf16(const std::vector<Layer>& dec, int start, int T, int J, TailB16Args* out);
+size_t plan_tail_bf16(const std::vector<Layer>& dec, int start, int T, int J, TailB16Args* out, int nrt = 5);
+int tail_bf16_row_tiles(const gem_handle* h, int B, int T);
 int build_tail_bf16_stream(gem_handle* h, StageNet& net);
 int launch_tail_bf16(gem_handle* h, const TailB16Args& a, size_t lds_bytes, hipStream_t s);
 int launch_tail(gem_handle* h, const TailArgs& a, size_t lds_bytes, hipStream_t s);

@@ -664,34 +664,44 @@ int launch_lbfgs_advance(gem_handle* h, int B, const gem_lbfgs_opts& o, hipStrea
 __global__ __launch_bounds__(1024) void compact_kernel(const int* __restrict__ phase_arr, int B, int T, int* __restrict__ perm,
                                                        int* __restrict__ slot_of, int* __restrict__ n_active, int force_all,
                                                        int* __restrict__ log_slot) {
+    // One pass, two barriers (round 4; before: two passes over chunks of 1024 windows with three barriers each -- 14 us at 8192
+    // windows): thread t owns the E consecutive windows [t E, (t + 1) E), E = ceil(B / 1024) <= 64.  ONE block scan of the
+    // per-thread active counts places both groups: an active window goes to slot (#active before it), a finished one to
+    // n_active + (#finished before it) = n_active + (its index - #active before it).  Same stable order as before.
     __shared__ int wsum[16];
-    __shared__ int base_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) base_s = 0;
-    __syncthreads();
-    for (int pass = 0; pass < 2; ++pass) {
-        for (int start = 0; start < B; start += 1024) {
-            const int b = start + tid;
-            const bool active = b < B && (force_all || phase_arr[b] != PH_DONE);
-            const bool flag = b < B && (active == (pass == 0));
-            const unsigned long long m = __ballot(flag);
-            const int prefix = __popcll(m & ((1ull << lane) - 1ull));
-            if (lane == 0) wsum[wave] = __popcll(m);
-            __syncthreads();
-            int woff = 0, total = 0;
-            for (int i = 0; i < 16; ++i) { if (i < wave) woff += wsum[i]; total += wsum[i]; }
-            const int base = base_s;
-            if (flag) { const int sl = base + woff + prefix; perm[sl] = b; slot_of[b] = sl; }
-            __syncthreads();
-            if (tid == 0) base_s = base + total;
-            __syncthreads();
-        }
-        if (pass == 0 && tid == 0) { n_active[0] = base_s; n_active[1] = base_s * T; *log_slot = base_s; }
+    const int E = (B + 1023) >> 10, b0 = tid * E;
+    unsigned long long mask = 0ull;
+    for (int e = 0; e < E; ++e) {
+        const int b = b0 + e;
+        if (b < B && (force_all || phase_arr[b] != PH_DONE)) mask |= 1ull << e;
     }
+    const int cnt = __popcll(mask);
+    int incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(incl, d);
+        if (lane >= d) incl += v;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int woff = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { if (i < wave) woff += wsum[i]; total += wsum[i]; }
+    int pa = woff + incl - cnt;               // active windows before this thread's range
+    int pi = total + (b0 - pa);               // slot of the first finished window of the range
+    for (int e = 0; e < E; ++e) {
+        const int b = b0 + e;
+        if (b >= B) break;
+        if ((mask >> e) & 1ull) { perm[pa] = b; slot_of[b] = pa++; }
+        else { perm[pi] = b; slot_of[b] = pi++; }
+    }
+    if (tid == 0) { n_active[0] = total; n_active[1] = total * T; *log_slot = total; }
 }
 
 int launch_compact(gem_handle* h, int B, int force_all, hipStream_t s) {
     Workspace& w = h->ws;
+    if (B > 65536) { set_error("compact: more than 65536 windows per call"); return 1; }      // (64 windows per thread of the scan)
     hipLaunchKernelGGL(compact_kernel, dim3(1), dim3(1024), 0, s, w.phase, B, h->T, w.perm, w.slot_of, w.n_active, force_all,
                        w.n_log + (w.log_pos % N_LOG));
     GEM_HIP(hipGetLastError());

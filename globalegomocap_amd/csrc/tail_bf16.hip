@@ -55,7 +55,7 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int WAVES = 8, THREADS = WAVES * 64;
-constexpr int NRT = 5, ROWS = NRT * 16;        // row tiles / rows per workgroup
+constexpr int NRT_MAX = 5;                     // row tiles (of 16 rows) per workgroup: 5 (8 windows of 10 frames), 4 (6) or 3 (4)
 constexpr int ZERO_BYTES = 1024 + 64;          // the zero line covers the K walk of the widest layer (K = 512: 1024 bytes)
 
 __device__ __forceinline__ unsigned int pack2(float lo, float hi) {      // round-to-nearest-even (v_cvt_pk_bf16_f32)
@@ -76,7 +76,7 @@ __device__ __forceinline__ unsigned int pos_bits(unsigned int d0, unsigned int d
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // One fused layer (one column tile of it) for this wave: D[n][m] += W[n][k] . act[m][k] over 3 taps x K.
-//   SPLIT 64-wide layer: waves w and w + 4 share column tile w & 3; w < 4 takes row tiles 0-2, w >= 4 row tiles 3-4
+//   SPLIT 64-wide layer: waves w and w + 4 share column tile w & 3; w < 4 takes the first ceil(NRT / 2) row tiles, w >= 4 the rest
 // The K walk is k-block major, taps inner (the weight stream is packed in the same order): a body of 6 k-steps covers two whole
 // k-blocks, so taps and ring slots are compile-time.  epi(tile, acc) gets the accumulator of row tile `tile`
 // (row 16 * tile + (lane & 15), channels col0 + 4 * (lane >> 4) + 0..3).
@@ -85,16 +85,17 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // RING: weight fragments in flight per wave (6 or 3); AFD: 2 = the activation fragments of the next k-step are read into a second
 // register set (one workgroup per CU: nothing else covers the LDS latency), 1 = refreshed in place right behind the MFMA that used
 // them (two workgroups per CU: 20 registers less).
-template <bool SPLIT, int RING, int AFD, typename Epi>
+template <bool SPLIT, int NRT, int RING, int AFD, typename Epi>
 __device__ __forceinline__ void gemm_layer(const unsigned char* lds, int in_off, int in_ld, int zero_off, int K, unsigned int rowbits,
                                            bf16x8 (&ring)[RING], const bf16x8* __restrict__ wp, int& consumed, int last_step, Epi epi) {
-    constexpr int NR = SPLIT ? 3 : NRT;
+    constexpr int NS = (NRT + 1) / 2;                 // split layers: waves 0-3 take row tiles [0, NS), waves 4-7 [NS, NRT)
+    constexpr int NR = SPLIT ? NS : NRT;
     constexpr int KS = 6;                             // k-steps (32 deep) per unrolled body = two whole k-blocks x 3 taps
     static_assert(KS % RING == 0, "ring slots must be compile-time inside the unrolled body");
     static_assert(AFD == 1 || AFD == 2, "in place or double-buffered");
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r16 = lane & 15, q = lane >> 4;
-    const int tile0 = SPLIT ? 3 * (wave >> 2) : 0;
+    const int tile0 = SPLIT ? NS * (wave >> 2) : 0;
     const unsigned int bits = rowbits >> (3 * tile0);
     // fragment read addresses per tap and row tile (bytes); invalid rows (outside the window: the conv's zero padding; past R;
     // the absent sixth tile of the split) read the zero line -- selecting the ADDRESS keeps the reads in flight behind the MFMAs
@@ -149,18 +150,18 @@ __device__ __forceinline__ void gemm_layer(const unsigned char* lds, int in_off,
 // N is 64, 128 or 256 (plan_tail_bf16).  A 256-wide layer runs as two passes over K, one per 128 channels (twice the fragment
 // reads, half the accumulators: the kernel has to stay under 128 VGPRs); the weight stream is packed pass by pass.
 // epi(col0, tile, acc): col0 = first channel of the wave's column tile in this pass.
-template <int RING, int AFD, typename Epi>
+template <int NRT, int RING, int AFD, typename Epi>
 __device__ __forceinline__ void gemm_dispatch(const unsigned char* lds, int in_off, int in_ld, int zero_off, int K, int N, unsigned int rowbits,
                                               bf16x8 (&ring)[RING], const bf16x8* __restrict__ wp, int& consumed, int last_step, Epi epi) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (N == 64) {
         const int col0 = 16 * (wave & 3);
-        gemm_layer<true, RING, AFD>(lds, in_off, in_ld, zero_off, K, rowbits, ring, wp, consumed, last_step, [&](int tile, const f32x4& acc) { epi(col0, tile, acc); });
+        gemm_layer<true, NRT, RING, AFD>(lds, in_off, in_ld, zero_off, K, rowbits, ring, wp, consumed, last_step, [&](int tile, const f32x4& acc) { epi(col0, tile, acc); });
     } else {
 #pragma nounroll
         for (int c = 0; c < N / 128; ++c) {
             const int col0 = 16 * wave + 128 * c;
-            gemm_layer<false, RING, AFD>(lds, in_off, in_ld, zero_off, K, rowbits, ring, wp, consumed, last_step, [&](int tile, const f32x4& acc) { epi(col0, tile, acc); });
+            gemm_layer<false, NRT, RING, AFD>(lds, in_off, in_ld, zero_off, K, rowbits, ring, wp, consumed, last_step, [&](int tile, const f32x4& acc) { epi(col0, tile, acc); });
         }
     }
 }
@@ -174,11 +175,11 @@ struct StageIn {
     const float* slab_base;
     const float* in_bias;
     size_t slab_stride;
-    int nslab, in_bias_ld, K0, off0, ld0, offm, ldm;
+    int nslab, in_bias_ld, K0, off0, ld0, offm, ldm, rows_wg;      // rows_wg: rows of the workgroup image (16 per row tile)
 };
 // the bf16 path: five chunks per thread and trip (80 rows x 256 channels = one trip), written without arrays
 __device__ __forceinline__ void stage_input_bf16(const StageIn si, unsigned char* lds, int tid, int R, size_t row0) {
-    const int K0 = si.K0, cpr = K0 / 8, nchunk = ROWS * cpr;
+    const int K0 = si.K0, cpr = K0 / 8, nchunk = si.rows_wg * cpr;
     auto ld = [&](int idx) -> u32x4 {
         const int r = idx / cpr, c8 = (idx - r * cpr) * 8;
         if (idx < nchunk && r < R) return *reinterpret_cast<const u32x4*>(si.a_in_b + (row0 + r) * K0 + c8);
@@ -198,7 +199,7 @@ __device__ __forceinline__ void stage_input_bf16(const StageIn si, unsigned char
 }
 template <bool SLAB, int UN>
 __device__ __forceinline__ void stage_input(const StageIn si, unsigned char* lds, int tid, int T, int R, size_t row0) {
-    const int K0 = si.K0, cpr = K0 / 8, nchunk = ROWS * cpr;
+    const int K0 = si.K0, cpr = K0 / 8, nchunk = si.rows_wg * cpr;
     for (int u0 = 0; u0 < nchunk; u0 += UN * THREADS) {
         int r[UN], c8[UN];
         bool ok[UN];
@@ -254,7 +255,10 @@ __device__ __forceinline__ void stage_input(const StageIn si, unsigned char* lds
 // otherwise for one (launches of at most one workgroup per CU, where nothing but the wave's own run-ahead covers a latency: ring of
 // six, double-buffered activation fragments).  Same LDS plan, same arithmetic in the same order: bitwise the same results.
 // PROBE: per-phase timestamps of workgroup 0 into a.dbg_ts (tools/tail16_bench); the product launches the probe-free instances.
-template <bool DENSE, bool PROBE>
+// NRT: row tiles per workgroup (5 / 4 / 3 = 8 / 6 / 4 windows of 10 frames): launches that would leave CUs idle with 8 windows per
+// workgroup take fewer windows per workgroup -- 1536 windows are 192 workgroups of 8 (a quarter of the chip idle, five tiles
+// each) or 256 of 6 (every CU, four tiles each).
+template <bool DENSE, int NRT, bool PROBE>
 __global__ __launch_bounds__(THREADS, DENSE ? 4 : 2) void decoder_tail_bf16_kernel(TailB16Args a) {
     constexpr int RING = DENSE ? 3 : 6, AFD = DENSE ? 1 : 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -301,7 +305,7 @@ __global__ __launch_bounds__(THREADS, DENSE ? 4 : 2) void decoder_tail_bf16_kern
         StageIn si;
         si.a_in_b = a.a_in_b; si.slab_base = a.in_slab.base; si.in_bias = a.in_bias; si.in_bias_ld = a.in_bias_ld;
         si.nslab = 0; si.slab_stride = 0;
-        si.K0 = a.fwd[0].K; si.off0 = a.off_act[0]; si.ld0 = a.ld_act[0]; si.offm = a.off_mask[0]; si.ldm = a.ld_mask[0];
+        si.rows_wg = 16 * NRT; si.K0 = a.fwd[0].K; si.off0 = a.off_act[0]; si.ld0 = a.ld_act[0]; si.offm = a.off_mask[0]; si.ldm = a.ld_mask[0];
         if (a.in_slab.base) {
             slab_layout(a.in_slab, si.nslab, si.slab_stride);
             stage_input<true, 2>(si, lds, tid, T, R, row0);
@@ -331,7 +335,7 @@ __global__ __launch_bounds__(THREADS, DENSE ? 4 : 2) void decoder_tail_bf16_kern
         // the vmcnt queue being in order, for the six weight fragments in flight behind it)
         const f32x4 bv0 = *reinterpret_cast<const f32x4*>(bias + (N == 64 ? 16 * (wave & 3) : 16 * wave) + 4 * q);
         const f32x4 bv1 = N > 128 ? *reinterpret_cast<const f32x4*>(bias + 16 * wave + 128 + 4 * q) : bv0;
-        gemm_dispatch<RING, AFD>(lds, a.off_act[i], a.ld_act[i], a.off_zero, a.fwd[i].K, N, rowbits, ring, wp, consumed, last_step,
+        gemm_dispatch<NRT, RING, AFD>(lds, a.off_act[i], a.ld_act[i], a.off_zero, a.fwd[i].K, N, rowbits, ring, wp, consumed, last_step,
                       [&](int col0, int tile, const f32x4& acc) {
                           const int n0 = col0 + 4 * q, m = 16 * tile + r16;
                           f32x4 v = acc + (col0 >= 128 ? bv1 : bv0);
@@ -353,7 +357,7 @@ __global__ __launch_bounds__(THREADS, DENSE ? 4 : 2) void decoder_tail_bf16_kern
         float* Xp = a.Xp;
         const int col0 = 16 * (wave & 3);
         const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + col0 + 4 * q);
-        gemm_layer<true, RING, AFD>(lds, a.off_act[i], a.ld_act[i], a.off_zero, a.fwd[i].K, rowbits, ring, wp, consumed, last_step,
+        gemm_layer<true, NRT, RING, AFD>(lds, a.off_act[i], a.ld_act[i], a.off_zero, a.fwd[i].K, rowbits, ring, wp, consumed, last_step,
                          [&](int tile, const f32x4& acc) {
                              const int n0 = col0 + 4 * q, m = 16 * tile + r16;
                              const f32x4 v = acc + bv;
@@ -395,7 +399,7 @@ __global__ __launch_bounds__(THREADS, DENSE ? 4 : 2) void decoder_tail_bf16_kern
         const int out_off = a.off_act[j], out_ld = a.ld_act[j];
         const int m_off = a.off_mask[j], m_ld = a.ld_mask[j];
         const bool masked = j > 0 || a.mask_first;
-        gemm_dispatch<RING, AFD>(lds, a.off_act[j + 1], a.ld_act[j + 1], a.off_zero, a.bwd[j].K, N, rowbits, ring, wp, consumed, last_step,
+        gemm_dispatch<NRT, RING, AFD>(lds, a.off_act[j + 1], a.ld_act[j + 1], a.off_zero, a.bwd[j].K, N, rowbits, ring, wp, consumed, last_step,
                       [&](int col0, int tile, const f32x4& acc) {
                           const int n0 = col0 + 4 * q, m = 16 * tile + r16;
                           f32x4 v = acc;
@@ -428,9 +432,10 @@ __global__ __launch_bounds__(THREADS, DENSE ? 4 : 2) void decoder_tail_bf16_kern
 // LDS plan of the bf16 tail for the chain starting at decoder conv `start`.  Returns the byte size, or 0 when the chain does not
 // fit this kernel (layer widths other than 64 / 128 / 256 outputs, more than TB_MAX_LAYERS layers, more than 80 KB: the kernel is
 // built for two workgroups per CU).
-size_t plan_tail_bf16(const std::vector<Layer>& dec, int start, int T, int J, TailB16Args* out) {
+size_t plan_tail_bf16(const std::vector<Layer>& dec, int start, int T, int J, TailB16Args* out, int nrt) {
     const int n = (int)dec.size() - start;
-    if (start < 1 || n < 1 || n > TB_MAX_LAYERS || T < 3 || T > 16) return 0;
+    if (start < 1 || n < 1 || n > TB_MAX_LAYERS || T < 3 || T > 16 || nrt < 3 || nrt > tb::NRT_MAX || 16 * nrt < T) return 0;
+    const int ROWS = 16 * nrt;
     for (int i = start; i < (int)dec.size(); ++i) {
         const int K = dec[i].K, N = dec[i].N;
         auto okK = [](int v) { return v == 64 || v == 128 || v == 256 || v == 512; };
@@ -442,7 +447,8 @@ size_t plan_tail_bf16(const std::vector<Layer>& dec, int start, int T, int J, Ta
     TailB16Args a{};
     a.n = n;
     a.mask_first = 1;
-    a.G = std::min(8, tb::ROWS / T);
+    a.nrt = nrt;
+    a.G = std::min(8, ROWS / T);
     auto ld = [](int width) { return 2 * width + 32; };
     const int escr = (T * J * 3 + 3) / 4 * 4;
     a.escr = escr;
@@ -453,8 +459,8 @@ size_t plan_tail_bf16(const std::vector<Layer>& dec, int start, int T, int J, Ta
     // two ping-pong buffers: act[j] / the gradient w.r.t. act[j] live at the start of buffer j & 1; the decoded pose (fp32)
     // sits behind act[n-1] in that activation's buffer (read by the energy terms while they write the gradient rows into the other)
     int size[2] = {0, 0};
-    for (int j = 0; j <= n; ++j) size[j & 1] = std::max(size[j & 1], tb::ROWS * ld(width[j]));
-    const int xb = (n - 1) & 1, x_rel = tb::ROWS * ld(width[n - 1]);
+    for (int j = 0; j <= n; ++j) size[j & 1] = std::max(size[j & 1], ROWS * ld(width[j]));
+    const int xb = (n - 1) & 1, x_rel = ROWS * ld(width[n - 1]);
     size[xb] = std::max(size[xb], x_rel + a.G * escr * 4);
     const int buf_off[2] = {0, size[0]};
     int off = size[0] + size[1];
@@ -463,7 +469,7 @@ size_t plan_tail_bf16(const std::vector<Layer>& dec, int start, int T, int J, Ta
     for (int j = 0; j < n; ++j) {          // sign bits of act[j]
         a.off_mask[j] = off;
         a.ld_mask[j] = j == 0 ? width[0] / 8 : width[j] / 4;
-        off += tb::ROWS * a.ld_mask[j];
+        off += ROWS * a.ld_mask[j];
     }
     off = (off + 15) / 16 * 16;
     a.off_zero = off;
@@ -478,6 +484,16 @@ size_t plan_tail_bf16(const std::vector<Layer>& dec, int start, int T, int J, Ta
     return (size_t)off;
 }
 
+// Row tiles per workgroup for a launch of B windows: the fewest (3, 4, 5 = 4, 6, 8 windows of 10 frames) that still put the whole
+// launch on the chip at once, one workgroup per CU; beyond that eight windows per workgroup, two workgroups per CU.
+int tail_bf16_row_tiles(const gem_handle* h, int B, int T) {
+    for (int nrt = 3; nrt < tb::NRT_MAX; ++nrt) {
+        const int G = std::min(8, 16 * nrt / T);
+        if (G >= 1 && (B + G - 1) / G <= h->n_cu) return nrt;
+    }
+    return tb::NRT_MAX;
+}
+
 // Weight fragments in consumption order.  Must mirror gemm_dispatch / gemm_layer: one pass per 128 output channels (column tile c
 // of wave w starts at channel 16 * w + 128 * c; 64-wide layers: 16 * (w & 3)), inside a pass k-block major, taps inner; lane l
 // holds W[tap][n0 + (l & 15)][32 * kb + 8 * (l >> 4) + 0..7].
@@ -485,7 +501,7 @@ int build_tail_bf16_stream(gem_handle* h, StageNet& net) {
     net.tb_stream = nullptr; net.tb_steps_f = net.tb_steps_b = 0; net.tb_lds = 0;
     const int st = net.tail_start;
     if (st < 1) return 0;
-    const size_t lds = plan_tail_bf16(net.dec, st, h->T, h->J, nullptr);
+    const size_t lds = plan_tail_bf16(net.dec, st, h->T, h->J, nullptr, tb::NRT_MAX);
     if (!lds) return 0;
     const int n = (int)net.dec.size() - st;
     auto steps_of = [](const Layer& L) { const int cpw = L.N / 128 > 0 ? L.N / 128 : 1; return (3 * L.K / 32) * cpw; };
@@ -522,17 +538,22 @@ int build_tail_bf16_stream(gem_handle* h, StageNet& net) {
 }
 
 int launch_tail_bf16(gem_handle* h, const TailB16Args& a, size_t lds_bytes, hipStream_t s) {
-    // at most one workgroup per CU: the one-workgroup-per-CU instance (lower latency); more: the two-per-CU instance
+    // at most one workgroup per CU: the one-workgroup-per-CU instances (lower latency; 5, 4 or 3 row tiles as planned by the
+    // caller: tail_bf16_row_tiles); more: the two-per-CU instance
     const int wgs = (a.B + a.G - 1) / a.G;
     const bool dense = wgs > h->n_cu && !dev_env("GEM_TAIL16_SPARSE");
+    if (dense && a.nrt != tb::NRT_MAX) { set_error("launch_tail_bf16: the two-workgroups-per-CU instance is built for five row tiles"); return 1; }
     typedef void (*kern_t)(TailB16Args);
-    const kern_t kern = dense ? (a.dbg_ts ? tb::decoder_tail_bf16_kernel<true, true> : tb::decoder_tail_bf16_kernel<true, false>)
-                              : (a.dbg_ts ? tb::decoder_tail_bf16_kernel<false, true> : tb::decoder_tail_bf16_kernel<false, false>);
+    kern_t kern;
+    if (dense) kern = a.dbg_ts ? tb::decoder_tail_bf16_kernel<true, 5, true> : tb::decoder_tail_bf16_kernel<true, 5, false>;
+    else if (a.nrt == 5) kern = a.dbg_ts ? tb::decoder_tail_bf16_kernel<false, 5, true> : tb::decoder_tail_bf16_kernel<false, 5, false>;
+    else if (a.nrt == 4) kern = tb::decoder_tail_bf16_kernel<false, 4, false>;
+    else kern = tb::decoder_tail_bf16_kernel<false, 3, false>;
     const void* kfn = reinterpret_cast<const void*>(kern);
     static PerDeviceOnce attr_once;
     if (attr_once.need(h->cfg.device)) {
-        const kern_t all[] = {tb::decoder_tail_bf16_kernel<true, true>, tb::decoder_tail_bf16_kernel<true, false>,
-                              tb::decoder_tail_bf16_kernel<false, true>, tb::decoder_tail_bf16_kernel<false, false>};
+        const kern_t all[] = {tb::decoder_tail_bf16_kernel<true, 5, true>, tb::decoder_tail_bf16_kernel<true, 5, false>, tb::decoder_tail_bf16_kernel<false, 5, true>,
+                              tb::decoder_tail_bf16_kernel<false, 5, false>, tb::decoder_tail_bf16_kernel<false, 4, false>, tb::decoder_tail_bf16_kernel<false, 3, false>};
         for (kern_t k : all) GEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     }
     if (a.n < 1 || a.n > TB_MAX_LAYERS || lds_bytes > 80 * 1024) { set_error("launch_tail_bf16: unsupported layer chain"); return 1; }

@@ -52,8 +52,10 @@ int main(int argc, char** argv) {
     net.tail_start = 1;
     if (build_tail_bf16_stream(&h, net) || !net.tb_stream) { fprintf(stderr, "no stream\n"); return 1; }
     TailB16Args a;
-    const size_t lds = plan_tail_bf16(net.dec, 1, T, J, &a);
-    printf("LDS %zu bytes, n=%d, G=%d, steps %d + %d\n", lds, a.n, a.G, net.tb_steps_f, net.tb_steps_b);
+    gem_handle hh; hh.n_cu = 256;
+    const int nrt = getenv("TAIL_NRT") ? atoi(getenv("TAIL_NRT")) : tail_bf16_row_tiles(&hh, B, T);
+    const size_t lds = plan_tail_bf16(net.dec, 1, T, J, &a, nrt);
+    printf("LDS %zu bytes, n=%d, row tiles %d, G=%d, steps %d + %d\n", lds, a.n, a.nrt, a.G, net.tb_steps_f, net.tb_steps_b);
     for (int i = 0; i < a.n; ++i) {
         a.fwd[i] = TailB16Layer{net.dec[1 + i].K, net.dec[1 + i].N, net.dec[1 + i].bias};
         a.bwd[i] = TailB16Layer{net.dec_bwd[1 + i].K, net.dec_bwd[1 + i].N, nullptr};
