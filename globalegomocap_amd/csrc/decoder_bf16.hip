@@ -154,6 +154,7 @@ static int gemm_bf16a(gem_handle* h, const Layer& L, int epi, const uint16_t* A,
         // fill the chip: about two workgroups per CU (the number co-resident with this kernel's 64 KB of LDS; measured at 768 ..
         // 3072 rows, tools/gemm_glds_bench split: the best cut of every shape) while every slice keeps >= 4 k-tiles and the slabs fit
         int sk = (2 * h->n_cu) / tiles;
+        if (const char* fs = dev_env("GEM_BF16_SK")) sk = atoi(fs);          // developer override (A/B runs)
         if (sk > k_tiles / 4) sk = k_tiles / 4;
         if (sk > 8) sk = 8;
         while (sk > 1 && (size_t)sk * a.slab_stride > w.splitk_elems) --sk;
