@@ -126,7 +126,9 @@ __global__ __launch_bounds__(1024) void gemm_big_kernel(const Args a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto compute = [&](int buf) {
+    // One K-step: the first fragment reads are issued FIRST, the DMA of the next K-step behind them (its issue -- 2-3 pieces of 100+
+    // cycles each -- covers their LDS latency), then the products.
+    auto kstep = [&](int buf, int kt_next, bool has_next) {
         const unsigned char* base = smem + buf * BUF;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -137,20 +139,24 @@ __global__ __launch_bounds__(1024) void gemm_big_kernel(const Args a) {
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
                 const bf16x8 wf = *reinterpret_cast<const bf16x8*>(base + b_base + i * 2048 + ch);
+                if (s == 0 && i == 0) {           // the first fragments are on their way: the DMA issue covers their latency
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (has_next) stage(buf ^ 1, kt_next);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[j], acc[i][j], 0, 0, 0);
             }
         }
     };
 
-    // two buffers: the DMA of K-step t + 1 is issued before the MFMAs of step t; the barrier that ends a step (with the vmcnt(0)
-    // the compiler puts in front of it) completes step t + 1 for everybody.  Four waves per SIMD hide each other's waits.
+    // two buffers: the DMA of K-step t + 1 is issued inside step t; the barrier that ends a step (with the vmcnt(0) the compiler
+    // puts in front of it) completes step t + 1 for everybody.  Four waves per SIMD hide each other's waits.
     stage(0, 0);
     __syncthreads();
     int cur = 0;
     for (int kt = 0; kt < kTiles; ++kt) {
-        if (kt + 1 < kTiles) stage(cur ^ 1, kt + 1);
-        compute(cur);
+        kstep(cur, kt + 1, kt + 1 < kTiles);
         __syncthreads();
         cur ^= 1;
     }
