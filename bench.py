@@ -300,7 +300,9 @@ def run_sharded(a, world, rank, device, rehearsal, sd_local, sd_global, vae_note
         if stream:
             mp = round(mpjpe(merged.cpu().numpy(), gt_all[:merged.shape[0]]) * 1e3, 3)
         if a.dump:
-            np.savez(a.dump, glob=full.cpu().numpy(), merged=merged.cpu().numpy() if merged is not None else np.zeros(0))
+            st0 = stats_to_numpy(outs[my_ranks[0]][1]) if outs[my_ranks[0]][1] is not None else None
+            np.savez(a.dump, glob=full.cpu().numpy(), merged=merged.cpu().numpy() if merged is not None else np.zeros(0),
+                     **({"stats_" + k: np.asarray(st0[k]) for k in st0.dtype.names} if st0 is not None else {}))
         gs = eng.graph_stats() if stream else None
         held = [shards[r]["frames_held"] for r in my_ranks]
         line = {

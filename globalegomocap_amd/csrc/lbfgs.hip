@@ -580,6 +580,10 @@ __device__ __forceinline__ void lbfgs_advance_body(const AdvArgs& a) {
     }
 }
 
+// (Round 4 measured the bf16-ring variant forced to six workgroups per CU -- 78 VGPRs, 24 spilled; all 1536 windows of configs[2]
+// resident at once instead of 1024: 168.7 k vs 169.5 k windows/s at 1536 windows, 293.6 k vs 295.0 k at 8192.  Residency is not what
+// bounds this kernel; not kept.  Keeping the bf16 history vectors packed in registers until use: 101 -> 97 VGPRs, same four
+// waves per SIMD, no gain; not kept either.)
 template <int EPT, bool FULL, bool HB = false>
 __global__ __launch_bounds__(256) void lbfgs_advance_kernel(AdvArgs a) { lbfgs_advance_body<EPT, 256, FULL, HB>(a); }
 
