@@ -296,6 +296,10 @@ int gem_create(const gem_config* cfg, gem_handle** out) {
     w.hist_cap = 32;     // >= max_iter - 1 pairs for the reference's max_iter = 25 (checked per call); a power of two:
                          // lbfgs.hip wraps ring indices with a mask
     static_assert(MAX_HIST >= 32, "ring capacity");
+    if (dev_env("GEM_LBFGS_CLK")) {
+        if (dev_alloc(w.allocs, &w.lbfgs_clk, (size_t)32)) return 1;
+        GEM_HIP(hipMemset(w.lbfgs_clk, 0, 32 * sizeof(unsigned long long)));
+    }
     if (dev_alloc(w.allocs, &w.S, (size_t)B * w.hist_cap * h->Dp)) return 1;
     if (dev_alloc(w.allocs, &w.Y, (size_t)B * w.hist_cap * h->Dp)) return 1;
     if (dev_alloc(w.allocs, &w.state, (size_t)B) || dev_alloc(w.allocs, &w.phase, (size_t)B)) return 1;
@@ -332,6 +336,15 @@ void gem_destroy(gem_handle* h) {
     (void)hipSetDevice(h->cfg.device);
     (void)hipDeviceSynchronize();
     for (auto& r : h->prof.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    if (h->ws.lbfgs_clk) {
+        unsigned long long c[32];
+        if (hipMemcpy(c, h->ws.lbfgs_clk, sizeof(c), hipMemcpyDeviceToHost) == hipSuccess && c[31]) {
+            fprintf(stderr, "[GEM_LBFGS_CLK] %llu window-rounds with a new direction from the ring, mean pairs %.1f; us per phase:", c[31], (double)c[30] / c[31]);
+            double tot = 0;
+            for (int i = 1; i < 10; ++i) { fprintf(stderr, " %d:%.2f", i, c[i] / 100.0 / c[31]); tot += c[i] / 100.0 / c[31]; }
+            fprintf(stderr, " total %.2f\n", tot);
+        }
+    }
     drop_graphs(h);
     if (h->lane2) { gem_destroy(h->lane2); h->lane2 = nullptr; }          // (its nets own nothing: the weights are freed below)
     if (h->lane_stream) (void)hipStreamDestroy(h->lane_stream);

@@ -110,6 +110,7 @@ struct Workspace {
     float *x = nullptr, *d = nullptr, *g = nullptr, *gp = nullptr, *bg0 = nullptr, *bg1 = nullptr, *trial = nullptr;
     float *S = nullptr, *Y = nullptr;   // [B, hist_cap, Dp]
     int hist_cap = 0;
+    unsigned long long* lbfgs_clk = nullptr;      // developer aid (GEM_LBFGS_CLK): per-phase clock sums of lbfgs_advance (-DGEM_LB_PROBE builds)
     LbfgsState* state = nullptr;        // [B]
     int* phase = nullptr;               // [B] copy of state[b].phase for the compaction scan
     double* f = nullptr;                // [B] energy of the trial point

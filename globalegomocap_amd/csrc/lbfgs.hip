@@ -36,6 +36,7 @@ struct AdvArgs {
     int* phase_arr;           // [B] copy of state.phase: what compact_kernel scans (4 bytes per window instead of the 1.2 KB record)
     const int* slot_of;       // window -> slot of its gradient row (nullptr: identity)
     SlabSrc gslab;            // base != nullptr: the gradient rows still lie in split-K slabs (summed here, in slab order)
+    unsigned long long* clk;  // developer aid (GEM_LBFGS_CLK, -DGEM_LB_PROBE builds): [32] accumulated 100 MHz ticks per phase, [31] = windows counted
     int Dp, hist_cap;
     gem_lbfgs_opts o;
 };
@@ -115,6 +116,17 @@ __device__ __forceinline__ void lbfgs_advance_body(const AdvArgs& a) {
     int phase = sp->phase;
     if (phase == PH_DONE) return;
     BlockRed<NT> R{red, 0};
+    // developer aid: a library built with -DGEM_LB_PROBE (tools/lbfgs_phase_run.sh) and run with GEM_LBFGS_CLK=1 prints the mean
+    // time of every phase of the windows that compute a new direction from the ring; the product build has no probes
+#ifdef GEM_LB_PROBE
+    unsigned long long ts[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) ts[i] = 0ull;
+#define LB_PROBE(n) do { if (a.clk) ts[n] = wall_clock64(); } while (0)
+#else
+#define LB_PROBE(n) do { } while (0)
+#endif
+    LB_PROBE(0);
     const int hmask = a.hist_cap - 1;        // the ring capacity is a power of two (checked on the host): no runtime modulo
     const gem_lbfgs_opts& o = a.o;
     const int Dp = a.Dp;
@@ -245,6 +257,7 @@ __device__ __forceinline__ void lbfgs_advance_body(const AdvArgs& a) {
         for (int i = 0; i < EPT; ++i) { const float w = fabsf(u[i] * scale); p = (w > p || w != w) ? w : p; }
         return R.max((double)p);
     };
+    LB_PROBE(1);          // 1: state read
     if (a.gslab.base) {
         int nslab;
         size_t stride;
@@ -274,6 +287,7 @@ __device__ __forceinline__ void lbfgs_advance_body(const AdvArgs& a) {
     bool do_zoom_head = false, do_ls_end = false, do_start_iter = false, finished = false, emit = false;
     bool have_ys = false;
 
+    LB_PROBE(2);          // 2: gradient (+ d, x) loads issued
     if (phase == PH_INIT) {
         loss = f_new;
         evals = 1;
@@ -350,6 +364,7 @@ __device__ __forceinline__ void lbfgs_advance_body(const AdvArgs& a) {
         }
     }
 
+    LB_PROBE(3);          // 3: g.d reduced, bracket / zoom update
     if (do_zoom_head) {
         if (ls_done || ls_iter >= max_ls) {
             do_ls_end = true;
@@ -377,6 +392,7 @@ __device__ __forceinline__ void lbfgs_advance_body(const AdvArgs& a) {
         }
     }
 
+    LB_PROBE(4);          // 4: zoom head
     if (do_ls_end) {
         __syncthreads();                      // bracket gradients written above are read back below
         t = br_t[low];
@@ -406,6 +422,8 @@ __device__ __forceinline__ void lbfgs_advance_body(const AdvArgs& a) {
         }
     }
 
+    LB_PROBE(5);          // 5: end of the line search (x, g stored, two max-norms)
+    bool full_path = false;
     if (do_start_iter) {
         n_iter++;
         if (n_iter == 1) {
@@ -431,6 +449,8 @@ __device__ __forceinline__ void lbfgs_advance_body(const AdvArgs& a) {
                 r3[0] = (double)p0; r3[1] = (double)p1; r3[2] = (double)p2;
             }
             R.template sumN<3>(r3);
+            full_path = true;
+            LB_PROBE(6);          // 6: y.s, y.y, s_prev.y
             const double ys = r3[0];
             const int limit = o.history < a.hist_cap ? o.history : a.hist_cap;
             if (ys > 1e-10) {
@@ -525,6 +545,7 @@ __device__ __forceinline__ void lbfgs_advance_body(const AdvArgs& a) {
 #pragma unroll
             for (int i = 0; i < EPT; ++i) dv[i] = q[i];
         }
+        LB_PROBE(7);          // 7: the two loops
         have_d = true;
         store(a.d, dv);
         prev_loss = loss;
@@ -554,6 +575,7 @@ __device__ __forceinline__ void lbfgs_advance_body(const AdvArgs& a) {
         }
     }
 
+    LB_PROBE(8);          // 8: g.d, max|d|
     if (finished) {
         phase = PH_DONE;
         if (!have_x) load(a.x, xv);
@@ -578,6 +600,19 @@ __device__ __forceinline__ void lbfgs_advance_body(const AdvArgs& a) {
         sp->br_t[0] = br_t[0]; sp->br_t[1] = br_t[1]; sp->br_f[0] = br_f[0]; sp->br_f[1] = br_f[1];
         sp->br_gtd[0] = br_gtd[0]; sp->br_gtd[1] = br_gtd[1];
     }
+    LB_PROBE(9);          // 9: trial point and state stored
+#ifdef GEM_LB_PROBE
+    if (a.clk && tid == 0 && full_path) {
+        unsigned long long prev = ts[0];
+#pragma unroll
+        for (int i = 1; i < 10; ++i)
+            if (ts[i]) { atomicAdd(a.clk + i, ts[i] - prev); prev = ts[i]; }
+        atomicAdd(a.clk + 30, (unsigned long long)hist_count);
+        atomicAdd(a.clk + 31, 1ull);
+    }
+#endif
+    (void)full_path;
+#undef LB_PROBE
 }
 
 // (Round 4 measured the bf16-ring variant forced to six workgroups per CU -- 78 VGPRs, 24 spilled; all 1536 windows of configs[2]
@@ -622,6 +657,7 @@ static AdvArgs make_args(gem_handle* h, const gem_lbfgs_opts& o) {
     a.phase_arr = w.phase;
     a.slot_of = w.dyn ? w.slot_of : nullptr;
     a.gslab = w.dyn ? w.grad_slab : SlabSrc{};
+    a.clk = w.lbfgs_clk;
     a.Dp = h->Dp; a.hist_cap = w.hist_cap; a.o = o;        // hist_cap: power of two (gem_create)
     return a;
 }
