@@ -268,6 +268,100 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
                 out[(size_t)n * K + k] = acc[x][y][e];
             }
 }
+// ---- a LINEAR layer's weight gradient and its Adam step in one kernel (gem_trainer_step, update = 2) ---------------------------
+// The two linear layers hold 97 % of the parameters and their gradient has rank <= batch: dW[n][k] = sum_b dC[b][n] A[b][k] is
+// a 64 x 64 x batch product per tile -- nothing next to the 3 x 16 KB of parameter and moment traffic of the tile.  Forming it
+// where Adam consumes it removes the gradient's round trip through HBM (2 x 4 bytes of the step's 32 bytes per parameter) and the
+// two gemm_tn launches.  Same products in the same order as gemm_tn_kernel<1> with one slab, same arithmetic as adam_kernel: at
+// batches up to TN_ROWS_LINEAR the parameters after the step are bitwise those of the two-kernel path.
+struct AdamScalars { float lr_bc1, b1, b2, eps, wd, bc2_sqrt; };
+__global__ __launch_bounds__(256) void gemm_tn_adam_kernel(const float* __restrict__ dC, int ldc, const float* __restrict__ A, int lda, int rows,
+                                                           int N, int K, float* __restrict__ P, float* __restrict__ M1, float* __restrict__ M2,
+                                                           AdamScalars ad) {
+    __shared__ __attribute__((aligned(16))) float smem[64 * 68];          // operand tiles [32][68] x 2, then the gradient tile [64][68]
+    float (*Cs)[68] = reinterpret_cast<float (*)[68]>(smem);
+    float (*As)[68] = reinterpret_cast<float (*)[68]>(smem + 32 * 68);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nt = blockIdx.x / (K / 64), kt = blockIdx.x - nt * (K / 64);
+    const int n0 = nt * 64, k0 = kt * 64;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fi = lane & 15, fq = lane >> 4;
+    // the tile's parameters and moments travel while the products run
+    f32x4 p4[4], m4[4], v4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const size_t i = (size_t)(n0 + q * 16 + (tid >> 4)) * K + k0 + (tid & 15) * 4;
+        p4[q] = *reinterpret_cast<const f32x4*>(P + i);
+        m4[q] = *reinterpret_cast<const f32x4*>(M1 + i);
+        v4[q] = *reinterpret_cast<const f32x4*>(M2 + i);
+    }
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 vc[2], va[2];
+    auto fetch = [&](int r0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + u * 256, rl = i >> 4, c4 = (i & 15) * 4;
+            const int row = r0 + rl;
+            vc[u] = f32x4{0.f, 0.f, 0.f, 0.f}; va[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (row < rows) {
+                vc[u] = *reinterpret_cast<const f32x4*>(dC + (size_t)row * ldc + n0 + c4);
+                va[u] = *reinterpret_cast<const f32x4*>(A + (size_t)row * lda + k0 + c4);
+            }
+        }
+    };
+    fetch(0);
+    for (int r0 = 0; r0 < rows; r0 += 32) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + u * 256, rl = i >> 4, c4 = (i & 15) * 4;
+            *reinterpret_cast<f32x4*>(&Cs[rl][c4]) = vc[u];
+            *reinterpret_cast<f32x4*>(&As[rl][c4]) = va[u];
+        }
+        __syncthreads();
+        if (r0 + 32 < rows) fetch(r0 + 32);
+#pragma unroll
+        for (int kk = 0; kk < 32; kk += 4) {
+            float a[2], b[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) { a[q] = Cs[kk + fq][wm * 32 + q * 16 + fi]; b[q] = As[kk + fq][wn * 32 + q * 16 + fi]; }
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[x], b[y], acc[x][y], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    float (*Gt)[68] = reinterpret_cast<float (*)[68]>(smem);
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Gt[wm * 32 + x * 16 + 4 * fq + e][wn * 32 + y * 16 + fi] = acc[x][y][e];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = q * 16 + (tid >> 4), c4 = (tid & 15) * 4;
+        const f32x4 g4 = *reinterpret_cast<const f32x4*>(&Gt[r][c4]);
+        f32x4 po, mo, vo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gg = g4[e] + ad.wd * p4[q][e];
+            const float mm = ad.b1 * m4[q][e] + (1.f - ad.b1) * gg;
+            const float vv = ad.b2 * v4[q][e] + (1.f - ad.b2) * gg * gg;
+            mo[e] = mm; vo[e] = vv;
+            po[e] = p4[q][e] - ad.lr_bc1 * mm / (sqrtf(vv) / ad.bc2_sqrt + ad.eps);
+        }
+        const size_t i = (size_t)(n0 + r) * K + k0 + c4;
+        *reinterpret_cast<f32x4*>(P + i) = po;
+        *reinterpret_cast<f32x4*>(M1 + i) = mo;
+        *reinterpret_cast<f32x4*>(M2 + i) = vo;
+    }
+}
 // G = sum over slabs, in slab order; blockIdx.y = layer (table), blockIdx.x = 1024-element chunk
 __global__ __launch_bounds__(256) void slab_sum_all_kernel(const SumDesc* __restrict__ tab, int nslab) {
     const SumDesc d = tab[blockIdx.y];
@@ -380,10 +474,14 @@ __global__ __launch_bounds__(256) void finish_loss_kernel(const double* __restri
 }
 
 // torch.optim.Adam (amsgrad off): g += wd * p; m, v moments; p -= lr / bc1 * m / (sqrt(v) / sqrt(bc2) + eps)
+// (skip0 / skip1: element ranges, in arena order, that gemm_tn_adam_kernel has already stepped; n counts the elements outside them)
+struct SkipRange { size_t begin, len; };
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n, float lr,
-                            float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+                            float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale, SkipRange skip0, SkipRange skip1) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    if (i >= skip0.begin) i += skip0.len;
+    if (i >= skip1.begin) i += skip1.len;
     const float gg = g[i] * gscale + wd * p[i];
     const float mm = b1 * m[i] + (1.f - b1) * gg;
     const float vv = b2 * v[i] + (1.f - b2) * gg * gg;
@@ -574,6 +672,8 @@ int gem_trainer_set_step(gem_trainer* t, int64_t step) {
     return 0;
 }
 
+static int apply_adam(gem_trainer* t, const gem_train_opts* o, double grad_scale, hipStream_t s, bool fused_linears);
+
 int gem_trainer_step(gem_trainer* t, int B, const float* d_pose, const float* d_eps, const gem_train_opts* o, int update, double* d_losses,
                      void* stream) {
     if (!t || !d_pose || !d_eps || !o) { set_error("gem_trainer_step: null argument"); return 1; }
@@ -583,6 +683,21 @@ int gem_trainer_step(gem_trainer* t, int B, const float* d_pose, const float* d_
     hipStream_t s = (hipStream_t)stream;
     const int T = t->T, rows = B * T;
     h->precision = GEM_PRECISION_F32;
+    // update = 2: the linear layers' weight gradients are formed inside their Adam step (gemm_tn_adam_kernel) and NOT left in the
+    // gradient arena -- the training loop's mode (networks/train.py:77-83 never looks at p.grad)
+    const bool fused = update == 2;
+    AdamScalars ad{};
+    if (fused) {
+        const double st = (double)(t->step + 1);
+        const double bc1 = 1.0 - std::pow(o->beta1, st), bc2 = 1.0 - std::pow(o->beta2, st);
+        ad = AdamScalars{(float)o->lr / (float)bc1, (float)o->beta1, (float)o->beta2, (float)o->eps, (float)o->weight_decay, (float)std::sqrt(bc2)};
+    }
+    auto linear_step = [&](const TrainLinear& l, const float* dC, const float* A) -> int {
+        hipLaunchKernelGGL(gemm_tn_adam_kernel, dim3((l.N / 64) * (l.K / 64)), dim3(256), 0, s, dC, l.N, A, l.K, B, l.N, l.K, t->P + l.ow, t->M1 + l.ow,
+                           t->M2 + l.ow, ad);
+        GEM_HIP(hipGetLastError());
+        return 0;
+    };
     // ---- the adjoint weight images of this step's parameters (one launch for all layers)
     hipLaunchKernelGGL(adjoint_all_kernel, dim3(t->adj_tiles, t->n_adj), dim3(256), 0, s, (const AdjDesc*)t->adj_tab);
     GEM_HIP(hipGetLastError());
@@ -641,8 +756,9 @@ int gem_trainer_step(gem_trainer* t, int B, const float* d_pose, const float* d_
     { const TrainLinear& l = t->dec_in;
       hipLaunchKernelGGL(colsum_kernel, dim3(l.N / 16), dim3(BN_THREADS), 0, s, (const float*)g, B, l.N, t->G + l.ob);
       GEM_HIP(hipGetLastError());
-      if (weight_grad<1>(t, g, l.N, t->z, l.K, B, l.N, l.K, l.ow, l.slab, TN_ROWS_LINEAR, s)) return 1;
-      if (linear_bwd_data(t, g, t->P + l.ow, t->dz, B, l.N, l.K, s)) return 1; }
+      if (!fused && weight_grad<1>(t, g, l.N, t->z, l.K, B, l.N, l.K, l.ow, l.slab, TN_ROWS_LINEAR, s)) return 1;
+      if (linear_bwd_data(t, g, t->P + l.ow, t->dz, B, l.N, l.K, s)) return 1;
+      if (fused && linear_step(l, g, t->z)) return 1; }          // (behind the backward-data product: it reads the weights)
     hipLaunchKernelGGL(latent_bwd_kernel, dim3(n_pl), dim3(LOSS_BLOCK), 0, s, (const float*)t->mulv, d_eps, (const float*)t->dz, B, t->D, t->Dp,
                        (float)(o->kld_weight / B), t->dmulv, part_latent);
     GEM_HIP(hipGetLastError());
@@ -654,9 +770,10 @@ int gem_trainer_step(gem_trainer* t, int B, const float* d_pose, const float* d_
       const float* flat = t->enc.back().out;
       hipLaunchKernelGGL(colsum_kernel, dim3(l.N / 16), dim3(BN_THREADS), 0, s, (const float*)t->dmulv, B, l.N, t->G + l.ob);
       GEM_HIP(hipGetLastError());
-      if (weight_grad<1>(t, t->dmulv, l.N, flat, l.K, B, l.N, l.K, l.ow, l.slab, TN_ROWS_LINEAR, s)) return 1;
+      if (!fused && weight_grad<1>(t, t->dmulv, l.N, flat, l.K, B, l.N, l.K, l.ow, l.slab, TN_ROWS_LINEAR, s)) return 1;
       g = t->gA; g2 = t->gB;
-      if (linear_bwd_data(t, t->dmulv, t->P + l.ow, g, B, l.N, l.K, s)) return 1; }
+      if (linear_bwd_data(t, t->dmulv, t->P + l.ow, g, B, l.N, l.K, s)) return 1;
+      if (fused && linear_step(l, t->dmulv, flat)) return 1; }
     // encoder
     for (int i = (int)t->enc.size() - 1; i >= 0; --i) {
         TrainConv& c = t->enc[i];
@@ -678,25 +795,37 @@ int gem_trainer_step(gem_trainer* t, int B, const float* d_pose, const float* d_
           hipLaunchKernelGGL(slab_sum_all_kernel, dim3((unsigned)((t->sum_max / 4 + 255) / 256), t->n_sum), dim3(256), 0, s, (const SumDesc*)t->sum_tab, ns_conv);
           GEM_HIP(hipGetLastError());
       }
-      if (ns_lin > 1)
+      if (ns_lin > 1 && !fused)
           hipLaunchKernelGGL(slab_sum_all_kernel, dim3((unsigned)((t->sum_max / 4 + 255) / 256), 2), dim3(256), 0, s, (const SumDesc*)t->sum_tab + t->n_sum, ns_lin);
       GEM_HIP(hipGetLastError()); }
     if (d_losses) GEM_HIP(hipMemcpyAsync(d_losses, t->red + 4, 3 * sizeof(double), hipMemcpyDeviceToDevice, s));
-    if (update) return gem_trainer_apply(t, o, 1.0, stream);
+    if (update) return apply_adam(t, o, 1.0, s, fused);
+    return 0;
+}
+
+// Adam over the gradient arena; fused_linears: the two linear layers' weights have been stepped by gemm_tn_adam_kernel already
+// (with THIS step's count: t->step is advanced here)
+static int apply_adam(gem_trainer* t, const gem_train_opts* o, double grad_scale, hipStream_t s, bool fused_linears) {
+    ++t->step;
+    const double bc1 = 1.0 - std::pow(o->beta1, (double)t->step), bc2 = 1.0 - std::pow(o->beta2, (double)t->step);
+    SkipRange k0{t->n_params, 0}, k1{t->n_params, 0};
+    size_t n = t->n_params;
+    if (fused_linears) {
+        k0 = SkipRange{t->fc.ow, (size_t)t->fc.N * t->fc.K};
+        k1 = SkipRange{t->dec_in.ow, (size_t)t->dec_in.N * t->dec_in.K};          // (arena order: fc before decoder_input)
+        n -= k0.len + k1.len;            // (the kernel walks the compacted index space and re-inserts the ranges in this order)
+    }
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, t->P, (const float*)t->G, t->M1, t->M2, n,
+                       (float)o->lr, (float)o->beta1, (float)o->beta2, (float)o->eps, (float)o->weight_decay, (float)bc1, (float)std::sqrt(bc2),
+                       (float)grad_scale, k0, k1);
+    GEM_HIP(hipGetLastError());
     return 0;
 }
 
 int gem_trainer_apply(gem_trainer* t, const gem_train_opts* o, double grad_scale, void* stream) {
     if (!t || !o) { set_error("gem_trainer_apply: null argument"); return 1; }
     GEM_HIP(hipSetDevice(t->h->cfg.device));
-    hipStream_t s = (hipStream_t)stream;
-    ++t->step;
-    const double bc1 = 1.0 - std::pow(o->beta1, (double)t->step), bc2 = 1.0 - std::pow(o->beta2, (double)t->step);
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((t->n_params + 255) / 256)), dim3(256), 0, s, t->P, (const float*)t->G, t->M1, t->M2, t->n_params,
-                       (float)o->lr, (float)o->beta1, (float)o->beta2, (float)o->eps, (float)o->weight_decay, (float)bc1, (float)std::sqrt(bc2),
-                       (float)grad_scale);
-    GEM_HIP(hipGetLastError());
-    return 0;
+    return apply_adam(t, o, grad_scale, (hipStream_t)stream, false);
 }
 
 int gem_trainer_arena(gem_trainer* t, int what, void** d_ptr, int64_t* n) {

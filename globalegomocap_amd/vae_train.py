@@ -337,9 +337,13 @@ class VAETrainer:
         return {"step": self.steps, "exp_avg": unpack_arena(self._down(3), self.shape), "exp_avg_sq": unpack_arena(self._down(4), self.shape)}
 
     # ---- one step (train.py:77-83)
-    def step(self, poses, kld_weight, eps=None, update=True, sync=True):
+    def step(self, poses, kld_weight, eps=None, update=True, sync=True, keep_gradients=True):
         """poses [B,T,45] (device or host); eps [B,D] or None (drawn on the device like torch.randn_like).  Returns
-        (loss, recon_loss, kld_loss) as floats (sync=True) or the device tensor that will hold them."""
+        (loss, recon_loss, kld_loss) as floats (sync=True) or the device tensor that will hold them.
+
+        keep_gradients=False (with update): the training loop's mode -- the two linear layers (97 % of the parameters) form their
+        weight gradient inside their Adam step (gem_trainer_step update = 2) and do not leave it in the gradient arena, so
+        `gradients()` is not valid for them afterwards; the parameters, moments and losses are those of the default mode."""
         import torch
         from . import _capi
         x = torch.as_tensor(poses, dtype=torch.float32, device=self.device).contiguous()
@@ -354,8 +358,8 @@ class VAETrainer:
                 raise ValueError("eps must be [B,%d]" % self.shape.latent_dim)
         self.opts.kld_weight = float(kld_weight)
         s = torch.cuda.current_stream(self.device).cuda_stream
-        _capi.check(self.lib.gem_trainer_step(self._t, B, x.data_ptr(), e.data_ptr(), C.byref(self.opts), 1 if update else 0,
-                                              self._losses.data_ptr(), C.c_void_p(s)), self.lib)
+        _capi.check(self.lib.gem_trainer_step(self._t, B, x.data_ptr(), e.data_ptr(), C.byref(self.opts),
+                                              (1 if keep_gradients else 2) if update else 0, self._losses.data_ptr(), C.c_void_p(s)), self.lib)
         self.forwards += 1               # every train-mode forward updates the running statistics (like torch's BatchNorm)
         if update:
             self.steps += 1
@@ -455,7 +459,7 @@ class VAETrainer:
                 if data_parallel:
                     running += self.step_data_parallel(data[perm[i * bs:(i + 1) * bs]], m_n, group=group, sync=False)
                 else:
-                    running += self.step(data[perm[i * bs:(i + 1) * bs]], m_n, sync=False)
+                    running += self.step(data[perm[i * bs:(i + 1) * bs]], m_n, sync=False, keep_gradients=False)
                 if count % log_step == 0 and count != 0:
                     r = running.cpu()
                     log("running loss is: {}".format(float(r[0])))

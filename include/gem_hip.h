@@ -234,6 +234,9 @@ int gem_profile_kernels(gem_handle* h, int family, char* buf, int buf_len);
  * unbiased variance), ConvVAE.loss_function (networks/models/SeqConvVAE.py:191-219: F.mse_loss(recons, input) + kld_weight *
  * mean_b(-0.5 * sum_d(1 + logvar - mu^2 - exp(logvar))), `kld_weight` being train.py:89's M_N), loss.backward() and -- when
  * `update` is non-zero -- one torch.optim.Adam step (train.py:60: lr, betas, eps, L2 weight_decay added to the gradient).
+ * update = 1 leaves every gradient in the gradient arena (p.grad after the step).  update = 2 is the training loop's mode: the two
+ * linear layers (fc_mu | fc_var, decoder_input: 97 % of the parameters) form their weight gradient INSIDE their Adam step and do
+ * not write it to the arena (their arena entries are stale afterwards); parameters, moments, statistics and losses are the same.
  *
  * Parameters, gradients and both Adam moments are fp32 arenas of `n_params` floats in the packed device layout; running
  * statistics an arena of `n_stats` floats.  Arena order (every width padded to a multiple of 64, padding zero):

@@ -336,3 +336,40 @@ def test_device_fit_reaches_the_accuracy_of_the_autograd_fit():
     sd_d, e_d = fit_vae_device(shape, win, steps=600, batch=64, lr=2e-3, kl_weight=0.01, seed=4)
     assert list(sd_d) == list(shape.schema())
     assert e_d < 1.5 * e_t + 2e-3 and e_d < 0.03, (e_d, e_t)
+
+
+def test_training_loop_mode_steps_like_the_default_mode():
+    """gem_trainer_step update = 2 (the linear layers' weight gradient formed inside their Adam step, never written to the gradient
+    arena) against update = 1 on the same batches at full size: losses, parameters, both Adam moments, running statistics."""
+    from globalegomocap_amd.vae_train import VAETrainer, initial_state_dict
+    B = 64
+    init = initial_state_dict(FULL, 5)
+    poses = synth.make_training_windows(3 * B, FULL.seq_len, 4).reshape(3, B, FULL.seq_len, 45)
+    eps = np.random.default_rng(3).standard_normal((3, B, FULL.latent_dim)).astype(np.float32)
+    a = VAETrainer(FULL, batch_size=B, lr=1e-3, weight_decay=1e-5, state_dict=init)
+    b = VAETrainer(FULL, batch_size=B, lr=1e-3, weight_decay=1e-5, state_dict=init)
+    try:
+        for s in range(3):
+            la = a.step(poses[s], 0.01, eps=eps[s])
+            lb = b.step(poses[s], 0.01, eps=eps[s], keep_gradients=False)
+            np.testing.assert_allclose(lb, la, rtol=1e-6)
+        from globalegomocap_amd.vae_train import unpack_arena
+        for what in (0, 3, 4):
+            ua, ub = unpack_arena(a._down(what), FULL), unpack_arena(b._down(what), FULL)
+            for k in ua:
+                # (".0.bias": a conv bias in front of a BatchNorm -- its exact gradient is zero, both runs hold rounding noise, and
+                # Adam moves such an entry by ~lr in the direction of the noise's sign; the fused kernel contracts g + wd * p into
+                # one fma, one rounding less than the two-kernel path, which is enough to flip such signs after the first step)
+                if k.endswith(".0.bias"):
+                    continue
+                x, y = np.asarray(ua[k], np.float64), np.asarray(ub[k], np.float64)
+                # (moments: moving averages of gradients that, from the second step on, are taken at parameters ~lr apart in the noise entries)
+                assert np.linalg.norm(x - y) <= (1e-3 if what == 0 else 5e-3) * max(1e-30, np.linalg.norm(x)), (what, k)
+        sa, sb = a._down(2).astype(np.float64), b._down(2).astype(np.float64)
+        assert np.abs(sa - sb).max() <= 1e-3 * np.abs(sa).max()
+        # (what the two modes agree on to rounding is the FUNCTION: the losses of three successive steps above, to 1e-6; single
+        # gradient entries of this network carry ~1e-3 of rounding noise -- see test_full_size_training_step_against_the_port --
+        # which is what separates the moments here after the first step's 1-ulp differences)
+        assert a.steps == b.steps == 3
+    finally:
+        a.close(); b.close()
