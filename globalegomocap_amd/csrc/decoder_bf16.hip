@@ -112,16 +112,16 @@ static int launch_big(gem_handle* h, const Layer& L, int epi, const uint16_t* A,
     a.lda = lda; a.ldc = ldc; a.M = M; a.N = L.N; a.K = L.K; a.m_min = m_min;
     static PerDeviceOnce once;
     if (once.need(h->cfg.device)) {
-        GEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(big::gemm_big_kernel<5, big::EPI_BIAS_LRELU, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        GEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(big::gemm_big_kernel<4, big::EPI_NONE, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        GEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(big::gemm_big_kernel<4, 4, 4, 5, big::EPI_BIAS_LRELU, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        GEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(big::gemm_big_kernel<4, 4, 4, 4, big::EPI_NONE, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     const int n_mt = (M + 255) / 256;
     if (epi == EPI_BIAS_LRELU) {
-        note_kernel(h, reinterpret_cast<const void*>(big::gemm_big_kernel<5, big::EPI_BIAS_LRELU, true>));
-        hipLaunchKernelGGL((big::gemm_big_kernel<5, big::EPI_BIAS_LRELU, true>), dim3(n_mt * (L.N / 320)), dim3(1024), 2 * (256 + 320) * 128, s, a);
+        note_kernel(h, reinterpret_cast<const void*>(big::gemm_big_kernel<4, 4, 4, 5, big::EPI_BIAS_LRELU, true>));
+        hipLaunchKernelGGL((big::gemm_big_kernel<4, 4, 4, 5, big::EPI_BIAS_LRELU, true>), dim3(n_mt * (L.N / 320)), dim3(1024), 2 * (256 + 320) * 128, s, a);
     } else {
-        note_kernel(h, reinterpret_cast<const void*>(big::gemm_big_kernel<4, big::EPI_NONE, false>));
-        hipLaunchKernelGGL((big::gemm_big_kernel<4, big::EPI_NONE, false>), dim3(n_mt * (L.N / 256)), dim3(1024), 2 * (256 + 256) * 128, s, a);
+        note_kernel(h, reinterpret_cast<const void*>(big::gemm_big_kernel<4, 4, 4, 4, big::EPI_NONE, false>));
+        hipLaunchKernelGGL((big::gemm_big_kernel<4, 4, 4, 4, big::EPI_NONE, false>), dim3(n_mt * (L.N / 256)), dim3(1024), 2 * (256 + 256) * 128, s, a);
     }
     GEM_HIP(hipGetLastError());
     return 0;

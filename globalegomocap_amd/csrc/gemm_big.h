@@ -49,18 +49,26 @@ struct Args {
     int m_min;                // run only when the row count is >= m_min (the small-tile kernel takes the launches below)
 };
 
-// NB: 16-column blocks per wave (4: tile 256 x 256; 5: tile 256 x 320)
-template <int NB, int EPI, bool OUT_BF16>
-__global__ __launch_bounds__(1024) void gemm_big_kernel(const Args a) {
-    constexpr int BM = 256, WN = 16 * NB, BN = 4 * WN, NT = 1024;
+// Tile shape = a grid of WM x WN waves, each owning MB x NB blocks of 16 x 16: BM = 16 MB WM = 256 rows, BN = 16 NB WN = 256
+// (backward) or 320 (forward) columns.  <4, 4, 4, 4 | 5>: sixteen waves of 64 x 64 | 80 (round 4's first form: every K-step moves
+// 256 | 288 KB of fragments LDS -> registers for 2048 | 2560 MFMA cycles per SIMD -- the LDS pipe, 128 bytes per clock, is the
+// longer of the two on paper) -- the form the product launches.  Bigger register tiles cut the fragment traffic but measure SLOWER
+// (profiles/gemm_big_variants_r04.txt, 8192 rows, forward | backward: 16 waves 0.46 | 0.47 of the bf16 peak; eight waves of
+// 64 x 160 | 128: 0.40 | 0.38; eight of 128 x 80 | 64: 0.40 | 0.41; four of 128 x 160 | 128: 0.24 | 0.34): with fewer waves per SIMD
+// nothing covers a wave's own LDS latency and barrier waits; the fragment traffic is not what binds this kernel.
+template <int WM, int WN, int MB, int NB, int EPI, bool OUT_BF16>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_big_kernel(const Args a) {
+    constexpr int NW = WM * WN, NT = NW * 64;
+    constexpr int BM = 16 * MB * WM, BN = 16 * NB * WN;
+    static_assert(BM == 256, "one 256-row panel per workgroup");
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF = A_BYTES + B_BYTES;
     constexpr int A_PIECES = A_BYTES / 1024, B_PIECES = B_BYTES / 1024;          // 32; 32 or 40
-    constexpr int A_PER = A_PIECES / 16, B_PER = (B_PIECES + 15) / 16;            // pieces per wave: 2; 2 or 3
+    constexpr int A_PER = (A_PIECES + NW - 1) / NW, B_PER = (B_PIECES + NW - 1) / NW;      // DMA pieces per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / WN, wn = wave % WN;
     const int M = a.m_dev ? *a.m_dev : a.M;
     if (M < a.m_min || M <= 0) return;
     const int n_mt = (M + BM - 1) / BM, n_nt = a.N / BN;
@@ -77,21 +85,22 @@ __global__ __launch_bounds__(1024) void gemm_big_kernel(const Args a) {
     const int kTiles = a.K / 64;
 
     // ---- DMA source addressing.  Piece p covers tile rows 8p .. 8p + 7; lane l brings the 16-byte chunk (l & 7) ^ swz(row) of
-    // row l >> 3.  A pieces 2 wave, 2 wave + 1; B pieces wave, wave + 16 (, wave + 32).
+    // row l >> 3.  Wave w brings pieces w, w + NW, ... of either operand.
     const int lrow = lane >> 3, lchunk = lane & 7;
     const unsigned char* a_src[A_PER];
     const unsigned char* b_src[B_PER];
     const unsigned char* zsrc = reinterpret_cast<const unsigned char*>(a.zero16);
 #pragma unroll
     for (int j = 0; j < A_PER; ++j) {
-        const int r = (wave * A_PER + j) * 8 + lrow, row = m0 + r;
-        const bool ok = row < M;
+        const int p = wave + NW * j;
+        const int r = p * 8 + lrow, row = m0 + r;
+        const bool ok = p < A_PIECES && row < M;
         const int src = ok ? (a.row_map ? a.row_map[row] : row) : 0;
         a_src[j] = ok ? reinterpret_cast<const unsigned char*>(a.A) + (size_t)src * a.lda * 2 + ((lchunk ^ ((r >> 1) & 7)) << 4) : nullptr;
     }
 #pragma unroll
     for (int j = 0; j < B_PER; ++j) {
-        const int p = wave + 16 * j;
+        const int p = wave + NW * j;
         const int r = p * 8 + lrow;
         b_src[j] = p < B_PIECES ? reinterpret_cast<const unsigned char*>(a.W) + (size_t)(n0 + r) * a.K * 2 + ((lchunk ^ ((r >> 1) & 7)) << 4) : nullptr;
     }
@@ -101,15 +110,17 @@ __global__ __launch_bounds__(1024) void gemm_big_kernel(const Args a) {
         unsigned char* lb = la + A_BYTES;
 #pragma unroll
         for (int j = 0; j < A_PER; ++j) {
-            const unsigned char* p = a_src[j] ? a_src[j] + kb : zsrc;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
-                                             (__attribute__((address_space(3))) void*)(la + (wave * A_PER + j) * 1024), 16, 0, 0);
+            if (wave + NW * j < A_PIECES) {
+                const unsigned char* p = a_src[j] ? a_src[j] + kb : zsrc;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                                                 (__attribute__((address_space(3))) void*)(la + (wave + NW * j) * 1024), 16, 0, 0);
+            }
         }
 #pragma unroll
         for (int j = 0; j < B_PER; ++j) {
-            if (wave + 16 * j < B_PIECES)
+            if (wave + NW * j < B_PIECES)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[j] + kb),
-                                                 (__attribute__((address_space(3))) void*)(lb + (wave + 16 * j) * 1024), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(lb + (wave + NW * j) * 1024), 16, 0, 0);
         }
     };
 
@@ -117,25 +128,25 @@ __global__ __launch_bounds__(1024) void gemm_big_kernel(const Args a) {
     // wave bases and the block offsets are multiples of 16 rows, so the swizzle term ((R >> 1) & 7) depends on the lane only.
     const int fr = lane & 15, fh = lane >> 4;
     const int sw = (fr >> 1) & 7;
-    const int a_base = (wm * 64 + fr) * 128, b_base = A_BYTES + (wn * WN + fr) * 128;
+    const int a_base = (wm * MB * 16 + fr) * 128, b_base = A_BYTES + (wn * NB * 16 + fr) * 128;
     const int ch0 = ((0 + fh) ^ sw) << 4, ch1 = ((4 + fh) ^ sw) << 4;
 
-    f32x4 acc[NB][4];          // [n block][m block]
+    f32x4 acc[NB][MB];          // [n block][m block]
 #pragma unroll
     for (int i = 0; i < NB; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // One K-step: the first fragment reads are issued FIRST, the DMA of the next K-step behind them (its issue -- 2-3 pieces of 100+
+    // One K-step: the first fragment reads are issued FIRST, the DMA of the next K-step behind them (its issue -- 2-5 pieces of 100+
     // cycles each -- covers their LDS latency), then the products.
     auto kstep = [&](int buf, int kt_next, bool has_next) {
         const unsigned char* base = smem + buf * BUF;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int ch = s ? ch1 : ch0;
-            bf16x8 af[4];
+            bf16x8 af[MB];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) af[j] = *reinterpret_cast<const bf16x8*>(base + a_base + j * 2048 + ch);
+            for (int j = 0; j < MB; ++j) af[j] = *reinterpret_cast<const bf16x8*>(base + a_base + j * 2048 + ch);
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
                 const bf16x8 wf = *reinterpret_cast<const bf16x8*>(base + b_base + i * 2048 + ch);
@@ -145,13 +156,13 @@ __global__ __launch_bounds__(1024) void gemm_big_kernel(const Args a) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < MB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[j], acc[i][j], 0, 0, 0);
             }
         }
     };
 
     // two buffers: the DMA of K-step t + 1 is issued inside step t; the barrier that ends a step (with the vmcnt(0) the compiler
-    // puts in front of it) completes step t + 1 for everybody.  Four waves per SIMD hide each other's waits.
+    // puts in front of it) completes step t + 1 for everybody.  The waves of a SIMD hide each other's waits.
     stage(0, 0);
     __syncthreads();
     int cur = 0;
@@ -161,23 +172,27 @@ __global__ __launch_bounds__(1024) void gemm_big_kernel(const Args a) {
         cur ^= 1;
     }
 
-    // ---- epilogue: four passes of 64 rows (one row group of waves each): fp32 tile rows -> LDS (row m, 16-byte chunk q at
-    // position q ^ (m & 15)) -> whole rows out.  D[n][m]: the lane's accumulator quad is 4 consecutive columns of ONE row.
+    // ---- epilogue: four passes of 64 rows: fp32 tile rows -> LDS (row m, 16-byte chunk q at position q ^ (m & 15)) -> whole
+    // rows out.  D[n][m]: the lane's accumulator quad is 4 consecutive columns of ONE row.  Pass p = the rows of wave row
+    // (64 p) / (16 MB), its m blocks [(64 p) % (16 MB) / 16, + 4).
     constexpr int ROWB = BN * 4;                                  // bytes per staged row
     constexpr int CW = OUT_BF16 ? 8 : 4;                          // columns per store chunk (16 bytes out either way)
     constexpr int CHUNKS = 64 * (BN / CW);                        // per pass
+    static_assert(64 * ROWB <= 2 * BUF, "a pass fits the operand buffers");
     unsigned char* Cb = reinterpret_cast<unsigned char*>(a.C);
-#pragma unroll 1
+#pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
         if (pass) __syncthreads();                                // the previous pass has been read out
-        if (wm == pass) {
+        constexpr int RPW = 16 * MB;                              // rows per wave row
+        const int wrow = (pass * 64) / RPW, j0 = ((pass * 64) % RPW) / 16;
+        if (wm == wrow) {
 #pragma unroll
             for (int i = 0; i < NB; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int m = j * 16 + fr;
-                    const int q = (wn * WN + i * 16 + 4 * fh) >> 2;
-                    *reinterpret_cast<f32x4*>(smem + m * ROWB + ((q ^ (m & 15)) << 4)) = acc[i][j];
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int m = jj * 16 + fr;
+                    const int q = (wn * NB * 16 + i * 16 + 4 * fh) >> 2;
+                    *reinterpret_cast<f32x4*>(smem + m * ROWB + ((q ^ (m & 15)) << 4)) = acc[i][j0 + jj];
                 }
         }
         __syncthreads();

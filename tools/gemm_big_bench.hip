@@ -27,7 +27,7 @@ __global__ void ref_kernel(const uint16_t* A, const uint16_t* W, const float* bi
     C[i] = acc;
 }
 
-template <int NB, int EPI, bool OUT_BF16>
+template <int WM, int WN, int MB, int NB, int EPI, bool OUT_BF16>
 static void run(const char* name, int M, int Mcap, int N, int K, bool gather, int reps) {
     std::vector<uint16_t> hA((size_t)Mcap * K), hW((size_t)N * K);
     std::vector<float> hb(N);
@@ -46,12 +46,12 @@ static void run(const char* name, int M, int Mcap, int N, int K, bool gather, in
     big::Args a{};
     a.A = dA; a.W = dW; a.bias = db; a.C = dC; a.zero16 = dZ; a.m_dev = dM; a.row_map = gather ? dMap : nullptr;
     a.lda = K; a.ldc = N; a.M = Mcap; a.N = N; a.K = K; a.m_min = 1;
-    auto k = big::gemm_big_kernel<NB, EPI, OUT_BF16>;
-    constexpr int BN = 64 * NB;
+    auto k = big::gemm_big_kernel<WM, WN, MB, NB, EPI, OUT_BF16>;
+    constexpr int BN = 16 * NB * WN, NTH = WM * WN * 64;
     const size_t smem = 2 * (size_t)(256 + BN) * 128;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const int grid = ((Mcap + 255) / 256) * (N / BN);
-    hipLaunchKernelGGL(k, dim3(grid), dim3(1024), smem, 0, a);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NTH), smem, 0, a);
     CK(hipDeviceSynchronize());
     hipLaunchKernelGGL(ref_kernel, dim3((unsigned)(((size_t)M * N + 255) / 256)), dim3(256), 0, 0, dA, dW, db, gather ? dMap : nullptr, dRef, M, N, K,
                        EPI == big::EPI_BIAS_LRELU ? 1 : 0);
@@ -68,13 +68,13 @@ static void run(const char* name, int M, int Mcap, int N, int K, bool gather, in
     double maxerr = 0, maxref = 0;
     for (size_t i = 0; i < got.size(); ++i) { maxerr = fmax(maxerr, fabs((double)got[i] - ref[i])); maxref = fmax(maxref, fabs((double)ref[i])); }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(k, dim3(grid), dim3(1024), smem, 0, a);
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(k, dim3(grid), dim3(NTH), smem, 0, a);
     CK(hipEventRecord(e0));
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k, dim3(grid), dim3(1024), smem, 0, a);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k, dim3(grid), dim3(NTH), smem, 0, a);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1e3 / reps, tf = 2.0 * M * N * K / (us * 1e-6) / 1e12;
-    printf("%-10s M %5d (cap %5d) N %5d K %5d gather %d out %s: %8.2f us  %7.1f TFLOP/s (%.3f of 2500)  max err %.3e (ref max %.2f)%s\n", name, M, Mcap, N, K,
+    printf("%-10s %dx%d waves of %dx%d M %5d (cap %5d) N %5d K %5d gather %d out %s: %8.2f us  %7.1f TFLOP/s (%.3f of 2500)  max err %.3e (ref max %.2f)%s\n", name, WM, WN, 16 * MB, 16 * NB, M, Mcap, N, K,
            (int)gather, OUT_BF16 ? "bf16" : "f32 ", us, tf, tf / 2500.0, maxerr, maxref, maxerr > (OUT_BF16 ? 0.02 : 1e-3) * fmax(1.0, maxref) ? "  <-- MISMATCH" : "");
     CK(hipFree(dA)); CK(hipFree(dW)); CK(hipFree(db)); CK(hipFree(dZ)); CK(hipFree(dC)); CK(hipFree(dRef)); CK(hipFree(dMap)); CK(hipFree(dM));
 }
@@ -106,15 +106,22 @@ static void run_old(const char* name, int M, int N, int K, int reps) {
 
 int main(int argc, char** argv) {
     const int reps = argc > 1 ? atoi(argv[1]) : 30;
-    run<5, big::EPI_BIAS_LRELU, true>("forward", 8192, 8192, 2560, 2048, true, reps);
-    run<4, big::EPI_NONE, false>("backward", 8192, 8192, 2048, 2560, false, reps);
-    run<5, big::EPI_BIAS_LRELU, true>("forward", 6001, 8192, 2560, 2048, true, reps);
-    run<4, big::EPI_NONE, false>("backward", 6001, 8192, 2048, 2560, false, reps);
-    run<5, big::EPI_BIAS_LRELU, true>("forward", 4096, 4096, 2560, 2048, false, reps);
-    run<4, big::EPI_NONE, false>("backward", 300, 8192, 2048, 2560, false, reps);
-    for (int M : {2048, 3072, 4096, 5120, 6144, 8192}) {
-        run_old<glds::EPI_BIAS_LRELU, true>("old fwd", M, 2560, 2048, reps);
-        run<5, big::EPI_BIAS_LRELU, true>("big fwd", M, 8192, 2560, 2048, false, reps);
-    }
+    // sixteen waves of 64 x 64 | 80, eight of 64 x 128 | 160, eight of 128 x 64 | 80, four of 128 x 128 | 160
+    run<4, 4, 4, 5, big::EPI_BIAS_LRELU, true>("forward", 8192, 8192, 2560, 2048, true, reps);
+    run<4, 4, 4, 4, big::EPI_NONE, false>("backward", 8192, 8192, 2048, 2560, false, reps);
+    run<4, 2, 4, 10, big::EPI_BIAS_LRELU, true>("forward", 8192, 8192, 2560, 2048, true, reps);
+    run<4, 2, 4, 8, big::EPI_NONE, false>("backward", 8192, 8192, 2048, 2560, false, reps);
+    run<2, 4, 8, 5, big::EPI_BIAS_LRELU, true>("forward", 8192, 8192, 2560, 2048, true, reps);
+    run<2, 4, 8, 4, big::EPI_NONE, false>("backward", 8192, 8192, 2048, 2560, false, reps);
+    run<2, 2, 8, 10, big::EPI_BIAS_LRELU, true>("forward", 8192, 8192, 2560, 2048, true, reps);
+    run<2, 2, 8, 8, big::EPI_NONE, false>("backward", 8192, 8192, 2048, 2560, false, reps);
+    run<4, 2, 4, 10, big::EPI_BIAS_LRELU, true>("forward", 6001, 8192, 2560, 2048, true, reps);
+    run<4, 2, 4, 8, big::EPI_NONE, false>("backward", 6001, 8192, 2048, 2560, false, reps);
+    run<4, 2, 4, 8, big::EPI_NONE, false>("backward", 300, 8192, 2048, 2560, false, reps);
+    if (argc > 2)
+        for (int M : {2048, 3072, 4096, 5120, 6144, 8192}) {
+            run_old<glds::EPI_BIAS_LRELU, true>("old fwd", M, 2560, 2048, reps);
+            run<4, 4, 4, 5, big::EPI_BIAS_LRELU, true>("big fwd", M, 8192, 2560, 2048, false, reps);
+        }
     return 0;
 }
