@@ -148,8 +148,9 @@ static int gemm_bf16a(gem_handle* h, const Layer& L, int epi, const uint16_t* A,
     a.n_split = 1; a.tiles_per_split = k_tiles; a.slab_stride = (size_t)M * ldc;
     // the front products at large batch: gemm_big.h takes the launches with >= BIG_MIN_ROWS rows (family 0 only)
     static const bool no_big = dev_env("GEM_NO_BIG_GEMM") != nullptr;
-    const bool use_big = family == 0 && !no_big && M >= BIG_MIN_ROWS && big_fits(L, epi, out_bf16);
-    if (use_big) a.m_max = BIG_MIN_ROWS;
+    static const int big_min = dev_env("GEM_BIG_MIN") ? atoi(dev_env("GEM_BIG_MIN")) : BIG_MIN_ROWS;          // developer override (A/B runs)
+    const bool use_big = family == 0 && !no_big && M >= big_min && big_fits(L, epi, out_bf16);
+    if (use_big) a.m_max = big_min;
     if (allow_split && epi != EPI_MASK) {
         // fill the chip: about two workgroups per CU (the number co-resident with this kernel's 64 KB of LDS; measured at 768 ..
         // 3072 rows, tools/gemm_glds_bench split: the best cut of every shape) while every slice keeps >= 4 k-tiles and the slabs fit
@@ -178,7 +179,7 @@ static int gemm_bf16a(gem_handle* h, const Layer& L, int epi, const uint16_t* A,
     int rc = 1;
     if (use_big) {
         if (a.n_split != 1) { set_error("gemm_bf16a: the one-round kernel's row range must not be cut along K"); return 1; }
-        if (launch_big(h, L, epi, A, lda, C, ldc, M, s, row_map, w.dyn ? BIG_MIN_ROWS : 1)) return 1;
+        if (launch_big(h, L, epi, A, lda, C, ldc, M, s, row_map, w.dyn ? big_min : 1)) return 1;
     }
     if (use_big && !w.dyn) {
         rc = 0;                    // the row count is known here: the big kernel alone

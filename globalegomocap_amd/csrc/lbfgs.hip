@@ -114,6 +114,10 @@ __device__ __forceinline__ void lbfgs_advance_body(const AdvArgs& a) {
     const int b = blockIdx.x, tid = threadIdx.x;
     LbfgsState* sp = a.state + b;
     int phase = sp->phase;
+    // (what every live window needs to ADDRESS its round's inputs is requested with the phase: the kernel's prologue is two dependent
+    // round trips -- these scalars, then state + ring scalars + gradient + d + x together -- instead of four)
+    const int gslot = a.slot_of ? a.slot_of[b] : b;
+    const double f_new = a.f[b];
     if (phase == PH_DONE) return;
     BlockRed<NT> R{red, 0};
     // developer aid: a library built with -DGEM_LB_PROBE (tools/lbfgs_phase_run.sh) and run with GEM_LBFGS_CLK=1 prints the mean
@@ -139,13 +143,11 @@ __device__ __forceinline__ void lbfgs_advance_body(const AdvArgs& a) {
     double t_prev = sp->t_prev, f_prev = sp->f_prev, gtd_prev = sp->gtd_prev;
     double br_t[2] = {sp->br_t[0], sp->br_t[1]}, br_f[2] = {sp->br_f[0], sp->br_f[1]};
     double br_gtd[2] = {sp->br_gtd[0], sp->br_gtd[1]};
-    for (int i = tid; i < a.hist_cap; i += NT) { ro_s[i] = sp->ro[i]; cadj_s[i] = sp->cadj[i]; }
-    __syncthreads();
+    static_assert(MAX_HIST <= NT, "one ring scalar per thread");
 
-    const double f_new = a.f[b];
     if (a.trace && tid == 0) a.trace[b] = f_new;
     if (f_new != f_new && tid == 0) sp->nan_seen = 1;
-    const float* gsrc = a.gnew + (size_t)(a.slot_of ? a.slot_of[b] : b) * Dp;
+    const float* gsrc = a.gnew + (size_t)gslot * Dp;
     float gn[EPT], xv[EPT], dv[EPT], gcur[EPT], yv[EPT], sv[EPT];
     bool have_x = false, have_d = false;
 #pragma unroll
@@ -258,17 +260,25 @@ __device__ __forceinline__ void lbfgs_advance_body(const AdvArgs& a) {
         return R.max((double)p);
     };
     LB_PROBE(1);          // 1: state read
+    // d and x are needed on every path but the very first evaluation, the ring's scalars by the two-loop recursion: requested
+    // behind the gradient's first loads, in the same round trip
+    double ro_v = 0.0, cadj_v = 0.0;
+    auto request_rest = [&]() {
+        if (tid < a.hist_cap) { ro_v = sp->ro[tid]; cadj_v = sp->cadj[tid]; }
+        if (phase != PH_INIT) { load(a.d, dv); load(a.x, xv); have_d = have_x = true; }
+    };
     if (a.gslab.base) {
         int nslab;
         size_t stride;
         slab_layout(a.gslab, nslab, stride);
-        const float* gs = a.gslab.base + (size_t)(a.slot_of ? a.slot_of[b] : b) * Dp;
+        const float* gs = a.gslab.base + (size_t)gslot * Dp;
 #pragma unroll
         for (int i = 0; i < EPT; ++i) gn[i] = 0.f;
         for (int z0 = 0; z0 < nslab; z0 += 8) {                 // eight slabs in flight per trip (the usual cut is 8)
             float t[8][EPT];
 #pragma unroll
             for (int k = 0; k < 8; ++k) load(gs + (size_t)min(z0 + k, nslab - 1) * stride - off, t[k]);
+            if (z0 == 0) request_rest();
 #pragma unroll
             for (int k = 0; k < 8; ++k)
                 if (z0 + k < nslab) {
@@ -276,12 +286,13 @@ __device__ __forceinline__ void lbfgs_advance_body(const AdvArgs& a) {
                     for (int i = 0; i < EPT; ++i) gn[i] += t[k][i];
                 }
         }
+        if (nslab <= 0) request_rest();
     } else {
         load(gsrc - off, gn);
+        request_rest();
     }
-    // d and x are needed on every path but the very first evaluation: fetch them with the gradient instead of one
-    // dependent round trip later
-    if (phase != PH_INIT) { load(a.d, dv); load(a.x, xv); have_d = have_x = true; }
+    if (tid < a.hist_cap) { ro_s[tid] = ro_v; cadj_s[tid] = cadj_v; }
+    __syncthreads();
     float* BG[2] = {a.bg0, a.bg1};
 
     bool do_zoom_head = false, do_ls_end = false, do_start_iter = false, finished = false, emit = false;
