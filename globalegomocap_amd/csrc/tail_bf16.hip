@@ -434,7 +434,7 @@ __global__ __launch_bounds__(THREADS, DENSE ? 4 : 2) void decoder_tail_bf16_kern
 // built for two workgroups per CU).
 size_t plan_tail_bf16(const std::vector<Layer>& dec, int start, int T, int J, TailB16Args* out, int nrt) {
     const int n = (int)dec.size() - start;
-    if (start < 1 || n < 1 || n > TB_MAX_LAYERS || T < 3 || T > 16 || nrt < 3 || nrt > tb::NRT_MAX || 16 * nrt < T) return 0;
+    if (start < 1 || n < 1 || n > TB_MAX_LAYERS || T < 3 || T > 16 || nrt < 2 || nrt > tb::NRT_MAX || 16 * nrt < T) return 0;
     const int ROWS = 16 * nrt;
     for (int i = start; i < (int)dec.size(); ++i) {
         const int K = dec[i].K, N = dec[i].N;
@@ -484,13 +484,19 @@ size_t plan_tail_bf16(const std::vector<Layer>& dec, int start, int T, int J, Ta
     return (size_t)off;
 }
 
-// Row tiles per workgroup for a launch of B windows: the fewest (3, 4, 5 = 4, 6, 8 windows of 10 frames) that still put the whole
-// launch on the chip at once, one workgroup per CU; beyond that eight windows per workgroup, two workgroups per CU.
+// Row tiles per workgroup for a launch of B windows (3, 4, 6, 8 windows of 10 frames for 2, 3, 4, 5 tiles):
+//   * up to four windows for every CU: three tiles, ONE workgroup per CU (the low-latency instance: ring of six, 160+ VGPRs);
+//   * beyond that TWO workgroups per CU (the 128-VGPR instance) with the FEWEST tiles that keep the launch inside one round of
+//     2 x CUs workgroups: a workgroup's time is a chain of ~12 dependent phases that shrinks little with its rows, and a second,
+//     independent workgroup on the CU fills its gaps -- 1536 windows as 512 workgroups of three windows take 37 us per launch, as 256
+//     one-per-CU workgroups of six 42 us, as 192 of eight 45 us (round 4, `GEM_TAIL16_NRT`);
+//   * more than 2 x CUs workgroups even with eight windows each: five tiles, several rounds.
 int tail_bf16_row_tiles(const gem_handle* h, int B, int T) {
-    for (int nrt = 3; nrt < tb::NRT_MAX; ++nrt) {
-        const int G = std::min(8, 16 * nrt / T);
-        if (G >= 1 && (B + G - 1) / G <= h->n_cu) return nrt;
-    }
+    if (const char* f = dev_env("GEM_TAIL16_NRT")) return atoi(f);          // developer override (A/B runs, tests)
+    auto wgs = [&](int nrt) { const int G = std::min(8, 16 * nrt / T); return G >= 1 ? (B + G - 1) / G : 1 << 30; };
+    if (wgs(3) <= h->n_cu) return 3;
+    for (int nrt = 2; nrt <= tb::NRT_MAX; ++nrt)
+        if (wgs(nrt) <= 2 * h->n_cu) return nrt;
     return tb::NRT_MAX;
 }
 
@@ -542,18 +548,31 @@ int launch_tail_bf16(gem_handle* h, const TailB16Args& a, size_t lds_bytes, hipS
     // caller: tail_bf16_row_tiles); more: the two-per-CU instance
     const int wgs = (a.B + a.G - 1) / a.G;
     const bool dense = wgs > h->n_cu && !dev_env("GEM_TAIL16_SPARSE");
-    if (dense && a.nrt != tb::NRT_MAX) { set_error("launch_tail_bf16: the two-workgroups-per-CU instance is built for five row tiles"); return 1; }
     typedef void (*kern_t)(TailB16Args);
-    kern_t kern;
-    if (dense) kern = a.dbg_ts ? tb::decoder_tail_bf16_kernel<true, 5, true> : tb::decoder_tail_bf16_kernel<true, 5, false>;
-    else if (a.nrt == 5) kern = a.dbg_ts ? tb::decoder_tail_bf16_kernel<false, 5, true> : tb::decoder_tail_bf16_kernel<false, 5, false>;
-    else if (a.nrt == 4) kern = tb::decoder_tail_bf16_kernel<false, 4, false>;
-    else kern = tb::decoder_tail_bf16_kernel<false, 3, false>;
+    kern_t kern = nullptr;
+    if (dense) {
+        switch (a.nrt) {
+            case 5: kern = a.dbg_ts ? tb::decoder_tail_bf16_kernel<true, 5, true> : tb::decoder_tail_bf16_kernel<true, 5, false>; break;
+            case 4: kern = tb::decoder_tail_bf16_kernel<true, 4, false>; break;
+            case 3: kern = tb::decoder_tail_bf16_kernel<true, 3, false>; break;
+            case 2: kern = tb::decoder_tail_bf16_kernel<true, 2, false>; break;
+        }
+    } else {
+        switch (a.nrt) {
+            case 5: kern = a.dbg_ts ? tb::decoder_tail_bf16_kernel<false, 5, true> : tb::decoder_tail_bf16_kernel<false, 5, false>; break;
+            case 4: kern = tb::decoder_tail_bf16_kernel<false, 4, false>; break;
+            case 3: kern = tb::decoder_tail_bf16_kernel<false, 3, false>; break;
+            case 2: kern = tb::decoder_tail_bf16_kernel<false, 2, false>; break;
+        }
+    }
+    if (!kern) { set_error("launch_tail_bf16: unsupported row-tile count"); return 1; }
     const void* kfn = reinterpret_cast<const void*>(kern);
     static PerDeviceOnce attr_once;
     if (attr_once.need(h->cfg.device)) {
         const kern_t all[] = {tb::decoder_tail_bf16_kernel<true, 5, true>, tb::decoder_tail_bf16_kernel<true, 5, false>, tb::decoder_tail_bf16_kernel<false, 5, true>,
-                              tb::decoder_tail_bf16_kernel<false, 5, false>, tb::decoder_tail_bf16_kernel<false, 4, false>, tb::decoder_tail_bf16_kernel<false, 3, false>};
+                              tb::decoder_tail_bf16_kernel<false, 5, false>, tb::decoder_tail_bf16_kernel<false, 4, false>, tb::decoder_tail_bf16_kernel<false, 3, false>,
+                              tb::decoder_tail_bf16_kernel<false, 2, false>, tb::decoder_tail_bf16_kernel<true, 4, false>, tb::decoder_tail_bf16_kernel<true, 3, false>,
+                              tb::decoder_tail_bf16_kernel<true, 2, false>};
         for (kern_t k : all) GEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     }
     if (a.n < 1 || a.n > TB_MAX_LAYERS || lds_bytes > 80 * 1024) { set_error("launch_tail_bf16: unsupported layer chain"); return 1; }

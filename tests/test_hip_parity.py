@@ -575,6 +575,44 @@ def test_bf16_multi_window_tail_against_the_batched_bf16_layers(torch_cuda, monk
         assert np.abs(Xa[k] - Xo).max() <= 8e-3 * max(1.0, np.abs(Xo).max()), k
 
 
+def test_bf16_tail_row_tile_variants_compute_the_same(torch_cuda, monkeypatch):
+    """The bf16 tail is launched with 2 .. 5 row tiles per workgroup (3 .. 8 windows) and one or two workgroups per CU depending on the
+    batch (tail_bf16.hip: tail_bf16_row_tiles).  Every variant runs the same products in the same order on a window's rows: energies,
+    decoded poses and latent gradients of 1100 windows are BITWISE the same whichever variant computes them (GEM_TAIL16_NRT forces
+    one: two tiles = 367 workgroups, two per CU; three = 275; four = 184 and five = 138, one per CU), and the batch's own choice is
+    one of them."""
+    torch = torch_cuda
+    shape, sd = FULL, vae_schema.structured_state_dict(FULL, 7, feature_offset=0.0)
+    B = 1100
+    seq = synth.make_sequence(n_frames=200, seed=41)
+    est = np.asarray(seq["estimated_local_skeleton"], dtype=np.float32)
+    heat = torch.as_tensor(np.asarray(seq["heatmap_list"], dtype=np.float32), device="cuda")
+    rng = np.random.default_rng(B)
+    starts = rng.integers(0, 190, B).astype(np.int32)
+    pose = np.stack([est[s:s + 10] for s in starts])
+    mb = O.mean_bone_length(est)
+    z = rng.normal(size=(B, shape.latent_dim)).astype(np.float32) * 0.3
+    monkeypatch.setenv("GEM_DEV", "1")
+    monkeypatch.setenv("GEM_TAIL16", "1")
+    res = {}
+    for nrt in (None, 2, 3, 4, 5):
+        if nrt is None:
+            monkeypatch.delenv("GEM_TAIL16_NRT", raising=False)
+        else:
+            monkeypatch.setenv("GEM_TAIL16_NRT", str(nrt))
+        eng = _engine(shape, max_windows=B)
+        eng.load_vae(0, sd)
+        eng.set_precision("bf16")
+        E, parts, dz, X = eng.energy_grad(0, z, pose, mb, _ew(W_ALL), heat, starts)
+        torch.cuda.synchronize()
+        res[nrt] = (E.cpu().numpy(), parts.cpu().numpy(), dz.cpu().numpy(), X.cpu().numpy())
+        eng.close()
+    for nrt in (None, 3, 4, 5):
+        for a_, b_ in zip(res[nrt], res[2]):
+            assert np.array_equal(a_, b_), nrt
+    assert np.isfinite(res[2][0]).all() and np.abs(res[2][2]).max() > 0
+
+
 @pytest.mark.parametrize("T,B", [(12, 13), (16, 7), (5, 19)])
 def test_bf16_multi_window_tail_with_other_window_lengths(torch_cuda, monkeypatch, T, B):
     """The bf16 tail packs G = min(8, 80 // T) windows into its 80 rows and uses the run-time-shaped energy code for anything but
