@@ -228,12 +228,15 @@ int evaluate_bf16(gem_handle* h, int stage, int B, const EnergyArgs& ea_in, hipS
     static const bool force_tail = dev_env("GEM_FORCE_TAIL") != nullptr;
     const int tail_g = T <= 16 ? 16 / T : 1;
     const int tail_wgs = (B + tail_g - 1) / tail_g;
-    // Three ways to run the narrow layers + energies: the bf16 multi-window tail (tail_bf16.hip: 8 windows per workgroup, one
-    // launch), the fp32 one-window tail (tail.hip: lowest latency for a few hundred windows), or batched bf16 GEMMs + the
+    // Three ways to run the narrow layers + energies: the bf16 multi-window tail (tail_bf16.hip: 1 .. 8 windows per workgroup, one
+    // launch), the fp32 one-window tail (tail.hip; GEM_TAIL16=0 or networks the bf16 tail does not cover), or batched bf16 GEMMs + the
     // stand-alone energy kernel (networks the tails do not cover).  GEM_TAIL16=1 / 0 forces / forbids the first (GEM_DEV=1).
     const char* t16_env = dev_env("GEM_TAIL16");       // (read per call: the tests flip it inside one process)
     const bool batched_narrow = dev_env("GEM_BATCHED_NARROW") != nullptr;      // neither tail: every layer a batched GEMM (A/B runs, tests)
-    const int t16_min = 8 * 32;                      // from 32 workgroups on the multi-window tail wins (measured: DESIGN.md 4)
+    // (round 3 sent batches below 256 windows to the fp32 one-window tail; with ONE row tile per workgroup -- one window of ten frames,
+    // every window its own CU like the fp32 tail, round 4 -- the bf16 tail wins at every size: 60 / 120 / 240 windows 14.9 / 26.1 /
+    // 47.8 k windows/s against 11.1 / 20.6 / 38.7 k)
+    const int t16_min = 1;
     const bool use_tail16 = net.tb_stream && net.tail_start >= 1 && !batched_narrow && !(t16_env && t16_env[0] == '0') &&
                             (B >= t16_min || (t16_env && t16_env[0] == '1'));
     const bool use_tail = !use_tail16 && !batched_narrow && net.tail_start >= 1 && (tail_wgs <= 5 * h->n_cu || force_tail);

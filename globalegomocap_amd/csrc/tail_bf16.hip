@@ -434,7 +434,7 @@ __global__ __launch_bounds__(THREADS, DENSE ? 4 : 2) void decoder_tail_bf16_kern
 // built for two workgroups per CU).
 size_t plan_tail_bf16(const std::vector<Layer>& dec, int start, int T, int J, TailB16Args* out, int nrt) {
     const int n = (int)dec.size() - start;
-    if (start < 1 || n < 1 || n > TB_MAX_LAYERS || T < 3 || T > 16 || nrt < 2 || nrt > tb::NRT_MAX || 16 * nrt < T) return 0;
+    if (start < 1 || n < 1 || n > TB_MAX_LAYERS || T < 3 || T > 16 || nrt < 1 || nrt > tb::NRT_MAX || 16 * nrt < T) return 0;
     const int ROWS = 16 * nrt;
     for (int i = start; i < (int)dec.size(); ++i) {
         const int K = dec[i].K, N = dec[i].N;
@@ -484,18 +484,18 @@ size_t plan_tail_bf16(const std::vector<Layer>& dec, int start, int T, int J, Ta
     return (size_t)off;
 }
 
-// Row tiles per workgroup for a launch of B windows (3, 4, 6, 8 windows of 10 frames for 2, 3, 4, 5 tiles):
-//   * up to four windows for every CU: three tiles, ONE workgroup per CU (the low-latency instance: ring of six, 160+ VGPRs);
-//   * beyond that TWO workgroups per CU (the 128-VGPR instance) with the FEWEST tiles that keep the launch inside one round of
-//     2 x CUs workgroups: a workgroup's time is a chain of ~12 dependent phases that shrinks little with its rows, and a second,
-//     independent workgroup on the CU fills its gaps -- 1536 windows as 512 workgroups of three windows take 37 us per launch, as 256
-//     one-per-CU workgroups of six 42 us, as 192 of eight 45 us (round 4, `GEM_TAIL16_NRT`);
-//   * more than 2 x CUs workgroups even with eight windows each: five tiles, several rounds.
+// Row tiles per workgroup for a launch of B windows (1, 3, 4, 6, 8 windows of 10 frames for 1 .. 5 tiles): the FEWEST that keep the
+// launch inside one round of 2 x CUs workgroups (launch_tail_bf16: up to one workgroup per CU the low-latency instance -- ring of six,
+// 160+ VGPRs --, beyond that the 128-VGPR instance, two per CU).  A workgroup's time is a chain of ~12 dependent phases that shrinks
+// little with its rows; more, smaller workgroups use more CUs, and a second, independent workgroup on a CU fills the first one's gaps:
+// 1536 windows as 512 workgroups of three windows take 37 us per launch, as 256 one-per-CU workgroups of six 42 us, as 192 of eight
+// 45 us (round 4, `GEM_TAIL16_NRT`; 360 / 600 / 960 / 1200 / 1536 / 2040 / 2580 windows: +5 / +3 / +1 / +4 / +4 / +2 / +5 % windows/s
+// over round 4's first rule "fewest of 3 .. 5 tiles with one workgroup per CU, else five").  More than 2 x CUs workgroups even with
+// eight windows each: five tiles, several rounds.
 int tail_bf16_row_tiles(const gem_handle* h, int B, int T) {
     if (const char* f = dev_env("GEM_TAIL16_NRT")) return atoi(f);          // developer override (A/B runs, tests)
     auto wgs = [&](int nrt) { const int G = std::min(8, 16 * nrt / T); return G >= 1 ? (B + G - 1) / G : 1 << 30; };
-    if (wgs(3) <= h->n_cu) return 3;
-    for (int nrt = 2; nrt <= tb::NRT_MAX; ++nrt)
+    for (int nrt = 1; nrt <= tb::NRT_MAX; ++nrt)
         if (wgs(nrt) <= 2 * h->n_cu) return nrt;
     return tb::NRT_MAX;
 }
@@ -556,6 +556,7 @@ int launch_tail_bf16(gem_handle* h, const TailB16Args& a, size_t lds_bytes, hipS
             case 4: kern = tb::decoder_tail_bf16_kernel<true, 4, false>; break;
             case 3: kern = tb::decoder_tail_bf16_kernel<true, 3, false>; break;
             case 2: kern = tb::decoder_tail_bf16_kernel<true, 2, false>; break;
+            case 1: kern = tb::decoder_tail_bf16_kernel<true, 1, false>; break;
         }
     } else {
         switch (a.nrt) {
@@ -563,6 +564,7 @@ int launch_tail_bf16(gem_handle* h, const TailB16Args& a, size_t lds_bytes, hipS
             case 4: kern = tb::decoder_tail_bf16_kernel<false, 4, false>; break;
             case 3: kern = tb::decoder_tail_bf16_kernel<false, 3, false>; break;
             case 2: kern = tb::decoder_tail_bf16_kernel<false, 2, false>; break;
+            case 1: kern = tb::decoder_tail_bf16_kernel<false, 1, false>; break;
         }
     }
     if (!kern) { set_error("launch_tail_bf16: unsupported row-tile count"); return 1; }
@@ -572,7 +574,7 @@ int launch_tail_bf16(gem_handle* h, const TailB16Args& a, size_t lds_bytes, hipS
         const kern_t all[] = {tb::decoder_tail_bf16_kernel<true, 5, true>, tb::decoder_tail_bf16_kernel<true, 5, false>, tb::decoder_tail_bf16_kernel<false, 5, true>,
                               tb::decoder_tail_bf16_kernel<false, 5, false>, tb::decoder_tail_bf16_kernel<false, 4, false>, tb::decoder_tail_bf16_kernel<false, 3, false>,
                               tb::decoder_tail_bf16_kernel<false, 2, false>, tb::decoder_tail_bf16_kernel<true, 4, false>, tb::decoder_tail_bf16_kernel<true, 3, false>,
-                              tb::decoder_tail_bf16_kernel<true, 2, false>};
+                              tb::decoder_tail_bf16_kernel<true, 2, false>, tb::decoder_tail_bf16_kernel<false, 1, false>, tb::decoder_tail_bf16_kernel<true, 1, false>};
         for (kern_t k : all) GEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     }
     if (a.n < 1 || a.n > TB_MAX_LAYERS || lds_bytes > 80 * 1024) { set_error("launch_tail_bf16: unsupported layer chain"); return 1; }

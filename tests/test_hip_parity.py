@@ -324,9 +324,12 @@ def test_full_size_batch_properties_at_baseline_size(torch_cuda):
     assert np.isfinite(out.cpu().numpy()).all()
 
 
-@pytest.mark.parametrize("mode,tol_x,tol_e,tol_g", [("bf16x3", 2e-5, 2e-4, 2e-3), ("bf16", 3e-3, 5e-2, 1e-1)])
+@pytest.mark.parametrize("mode,tol_x,tol_e,tol_g", [("bf16x3", 2e-5, 2e-4, 2e-3), ("bf16", 3e-3, 5e-2, 1.5e-1)])
 def test_precision_modes_energy_and_gradient(torch_cuda, mode, tol_x, tol_e, tol_g):
-    """Wide products in split-bf16 (fp32-grade) and plain bf16 against the fp32 oracle, full-size network."""
+    """Wide products in split-bf16 (fp32-grade) and plain bf16 against the fp32 oracle, full-size network.
+    (bf16, round 4: the narrow layers run in bf16 at EVERY batch size now -- the multi-window tail with one row tile per workgroup
+    replaced the fp32 one-window tail below 256 windows -- so a 4-window call carries the bf16 mode's full rounding: the worst
+    gradient entry moved from 7 % to 10 % of the largest one; the gate on it went from 0.10 to 0.15.)"""
     sd = vae_schema.synthetic_state_dict(FULL, 5)
     eng = _engine(FULL, max_windows=8)
     eng.load_vae(0, sd)
@@ -595,7 +598,7 @@ def test_bf16_tail_row_tile_variants_compute_the_same(torch_cuda, monkeypatch):
     monkeypatch.setenv("GEM_DEV", "1")
     monkeypatch.setenv("GEM_TAIL16", "1")
     res = {}
-    for nrt in (None, 2, 3, 4, 5):
+    for nrt in (None, 1, 2, 3, 4, 5):
         if nrt is None:
             monkeypatch.delenv("GEM_TAIL16_NRT", raising=False)
         else:
@@ -607,7 +610,7 @@ def test_bf16_tail_row_tile_variants_compute_the_same(torch_cuda, monkeypatch):
         torch.cuda.synchronize()
         res[nrt] = (E.cpu().numpy(), parts.cpu().numpy(), dz.cpu().numpy(), X.cpu().numpy())
         eng.close()
-    for nrt in (None, 3, 4, 5):
+    for nrt in (None, 1, 3, 4, 5):
         for a_, b_ in zip(res[nrt], res[2]):
             assert np.array_equal(a_, b_), nrt
     assert np.isfinite(res[2][0]).all() and np.abs(res[2][2]).max() > 0
