@@ -238,6 +238,25 @@ int main(int argc, char** argv) {
             run<false, 1, EPI_NONE, 128, 128, false, 16, 2>("front bwd", M, 2048, 2560, 10, 4, reps);
         }
     }
+    if (!strcmp(which, "mid")) {        // the composed front layer below ~2000 rows: tile shape x pipeline depth x K cut (round 4)
+        for (int M : {384, 768, 1536}) {
+            run<false, 1, EPI_BIAS_LRELU, 128, 128, false, 16, 2>("fwd 128x128 S2", M, 2560, 2048, 10, 2, reps);
+            run<false, 1, EPI_BIAS_LRELU, 128, 128, false, 16, 2>("fwd 128x128 S2", M, 2560, 2048, 10, 4, reps);
+            run<false, 1, EPI_BIAS_LRELU, 128, 128, false, 16, 3>("fwd 128x128 S3", M, 2560, 2048, 10, 1, reps);
+            run<false, 1, EPI_BIAS_LRELU, 128, 128, false, 16, 3>("fwd 128x128 S3", M, 2560, 2048, 10, 2, reps);
+            run<false, 1, EPI_BIAS_LRELU, 128, 128, false, 16, 3>("fwd 128x128 S3", M, 2560, 2048, 10, 4, reps);
+            run<false, 1, EPI_BIAS_LRELU, 64, 128, false, 16, 2>("fwd 64x128 S2", M, 2560, 2048, 10, 1, reps);
+            run<false, 1, EPI_BIAS_LRELU, 64, 128, false, 16, 2>("fwd 64x128 S2", M, 2560, 2048, 10, 2, reps);
+            run<false, 1, EPI_BIAS_LRELU, 64, 128, false, 16, 3>("fwd 64x128 S3", M, 2560, 2048, 10, 1, reps);
+            run<false, 1, EPI_BIAS_LRELU, 64, 128, false, 16, 3>("fwd 64x128 S3", M, 2560, 2048, 10, 2, reps);
+            run<false, 1, EPI_BIAS_LRELU, 64, 128, false, 16, 3>("fwd 64x128 S3", M, 2560, 2048, 10, 4, reps);
+            run<false, 1, EPI_BIAS_LRELU, 64, 64, false, 16, 3>("fwd 64x64 S3", M, 2560, 2048, 10, 1, reps);
+            run<false, 1, EPI_BIAS_LRELU, 64, 64, false, 16, 3>("fwd 64x64 S3", M, 2560, 2048, 10, 2, reps);
+            run<false, 1, EPI_NONE, 128, 128, false, 16, 2>("bwd 128x128 S2", M, 2048, 2560, 10, 2, reps);
+            run<false, 1, EPI_NONE, 128, 128, false, 16, 3>("bwd 128x128 S3", M, 2048, 2560, 10, 2, reps);
+            run<false, 1, EPI_NONE, 64, 128, false, 16, 3>("bwd 64x128 S3", M, 2048, 2560, 10, 2, reps);
+        }
+    }
     if (!strcmp(which, "front")) {      // the composed front layer (decoder_input o conv 0) and its transpose, bf16
         run<false, 1, EPI_BIAS_LRELU, 128, 128, true, 16, 2>("front fwd 8192w", 8192, 2560, 2048, 10, 1, reps);
         run<false, 1, EPI_BIAS_LRELU, 128, 128, true, 16, 3>("front fwd 8192w", 8192, 2560, 2048, 10, 1, reps);
