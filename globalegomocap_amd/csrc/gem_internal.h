@@ -387,6 +387,7 @@ struct TailB16Args {
     int off_act[TB_MAX_LAYERS + 1], ld_act[TB_MAX_LAYERS + 1];      // act[0] = input; [n]: the gradient rows w.r.t. the pose (bf16)
     int off_mask[TB_MAX_LAYERS], ld_mask[TB_MAX_LAYERS];            // mask[0]: one byte per 8 channels; mask[j > 0]: one byte per 4
     int off_x, escr, off_mb, off_zero, off_tab;
+    int off_bwin, off_epair;   // [G] global window indices; (up to three row tiles, 10 x 15 windows) [G * T*J][5] fp32 energy terms per pair, else -1
     EnergyArgs e;
 };
 size_t plan_tail_bf16(const std::vector<Layer>& dec, int start, int T, int J, TailB16Args* out, int nrt = 5);

@@ -316,6 +316,7 @@ __global__ __launch_bounds__(THREADS, DENSE ? 4 : 2) void decoder_tail_bf16_kern
     for (int i = tid; i < ZERO_BYTES / 4; i += THREADS) reinterpret_cast<unsigned int*>(lds + a.off_zero)[i] = 0u;
     if (tid < a.e.J * MAXJ) reinterpret_cast<int*>(lds + a.off_tab)[tid] = a.e.children[tid];
     if (tid < a.e.J) reinterpret_cast<int*>(lds + a.off_tab)[MAXJ * MAXJ + tid] = a.e.parents[tid];
+    if (tid < nwin) reinterpret_cast<int*>(lds + a.off_bwin)[tid] = a.e.perm ? a.e.perm[w0 + tid] : w0 + tid;
     if (!a.forward_only && tid < nwin * a.e.J) {
         const int wi = tid / a.e.J, j = tid - wi * a.e.J;
         const int bw = a.e.perm ? a.e.perm[w0 + wi] : w0 + wi;
@@ -348,6 +349,15 @@ __global__ __launch_bounds__(THREADS, DENSE ? 4 : 2) void decoder_tail_bf16_kern
         lds_barrier();
         TB_PROBE();
     }
+    // the bf16 gradient rows w.r.t. the pose (act[NL]'s slot: the buffer of act[NL - 2], dead since the barrier above) are zeroed here
+    // -- their pad columns stay zero, the energy terms write the J*3 value columns behind the next barrier
+    if (!a.forward_only) {
+        const int ldg_b = a.ld_act[NL];
+        for (int i = tid; i < R * (PAD / 4); i += THREADS) {
+            const int r = i / (PAD / 4), c4 = (i - r * (PAD / 4)) * 4;
+            *reinterpret_cast<unsigned long long*>(lds + a.off_act[NL] + r * ldg_b + c4 * 2) = 0ull;
+        }
+    }
     // ---- the last forward layer (64 padded channels: the pose, fp32, no activation)
     {
         const int i = NL - 1;
@@ -376,15 +386,25 @@ __global__ __launch_bounds__(THREADS, DENSE ? 4 : 2) void decoder_tail_bf16_kern
     if (a.forward_only) return;
 
     // ---- energy terms + dE/dX: one wavefront per window (fp32); gradient rows leave as bf16 into the buffer of act[NL]
-    if (wave < nwin) {
-        const float* xs = reinterpret_cast<const float*>(lds + a.off_x) + wave * a.escr;
-        const float* mbl = reinterpret_cast<const float*>(lds + a.off_mb) + wave * MAXJ;
+    // Up to three row tiles (one, three or four windows of 10 x 15): the WHOLE workgroup on the windows' pairs (one or two trips of 512
+    // threads instead of three trips of one wavefront per window); else one wavefront per window.  Same bits either way.
+    {
         const int* ch = reinterpret_cast<const int*>(lds + a.off_tab);
         const int* par = ch + MAXJ * MAXJ;
         const int ldg = a.ld_act[NL] / 2;
-        uint16_t* gd = reinterpret_cast<uint16_t*>(lds + a.off_act[NL]) + wave * T * ldg;
-        if (fast_e) energy_pairs<10, 15, 3>(a.e, bwin, lane, xs, mbl, par, ch, gd, ldg, PAD, (PROBE && a.dbg_ts && blockIdx.x == 0 && wave == 0) ? a.dbg_ts + 32 : nullptr);
-        else energy_pairs<0, 0, 4>(a.e, bwin, lane, xs, mbl, par, ch, gd, ldg, PAD);
+        const float* xs0 = reinterpret_cast<const float*>(lds + a.off_x);
+        const float* mbl0 = reinterpret_cast<const float*>(lds + a.off_mb);
+        uint16_t* gd0 = reinterpret_cast<uint16_t*>(lds + a.off_act[NL]);
+        constexpr int G10 = 16 * NRT / 10 < 8 ? 16 * NRT / 10 : 8;          // windows of ten frames per workgroup
+        if (NRT <= 3 && fast_e && a.off_epair >= 0) {
+            energy_pairs_wg<10, 15, (G10 * 150 + THREADS - 1) / THREADS, THREADS>(a.e, reinterpret_cast<const int*>(lds + a.off_bwin), nwin, tid, xs0,
+                                                                                a.escr, mbl0, par, ch, gd0, T * ldg, ldg,
+                                                                                reinterpret_cast<float*>(lds + a.off_epair), [] { lds_barrier(); });
+        } else if (wave < nwin) {
+            if (fast_e) energy_pairs<10, 15, 3>(a.e, bwin, lane, xs0 + wave * a.escr, mbl0 + wave * MAXJ, par, ch, gd0 + wave * T * ldg, ldg,
+                                                (PROBE && a.dbg_ts && blockIdx.x == 0 && wave == 0) ? a.dbg_ts + 32 : nullptr);
+            else energy_pairs<0, 0, 4>(a.e, bwin, lane, xs0 + wave * a.escr, mbl0 + wave * MAXJ, par, ch, gd0 + wave * T * ldg, ldg);
+        }
     }
     last_step = a.steps_total - 1;
 #pragma unroll
@@ -478,6 +498,13 @@ size_t plan_tail_bf16(const std::vector<Layer>& dec, int start, int T, int J, Ta
     off += a.G * GEM_MAX_JOINTS * 4;
     a.off_tab = off;                       // children lists of the skeleton ([J][MAXJ] ints) + parents ([MAXJ] ints)
     off += (GEM_MAX_JOINTS + 1) * GEM_MAX_JOINTS * 4;
+    off = (off + 15) / 16 * 16;
+    a.off_bwin = off;                      // global window index of each of the workgroup's windows
+    off += 8 * 4;
+    // up to three row tiles: the energy terms are computed by the whole workgroup, pairs dealt over all threads (energy_pairs_wg);
+    // every pair parks its five terms here for the per-window reduction
+    a.off_epair = -1;
+    if (nrt <= 3) { a.off_epair = off; off += a.G * T * J * 5 * 4; }
     off = (off + 15) / 16 * 16 + 64;       // (+ slack: nothing reads past its row, this keeps it that way under edits)
     if (off > 80 * 1024) return 0;
     if (out) *out = a;
