@@ -212,13 +212,22 @@ __device__ __forceinline__ void stage_input(const StageIn si, unsigned char* lds
             o[k] = u32x4{0u, 0u, 0u, 0u};
         }
         if (SLAB) {
-            f32x4 v0[UN], v1[UN];
+            // (the first two slabs and the bias are requested together: ONE round trip for the usual cut in two, not three)
+            f32x4 v0[UN], v1[UN], s0[UN], s1[UN], b0[UN], b1[UN];
+            const size_t second = si.nslab > 1 ? si.slab_stride : 0;
 #pragma unroll
             for (int k = 0; k < UN; ++k) {
                 const float* p = si.slab_base + (row0 + (ok[k] ? r[k] : 0)) * K0 + (ok[k] ? c8[k] : 0);
                 v0[k] = *reinterpret_cast<const f32x4*>(p); v1[k] = *reinterpret_cast<const f32x4*>(p + 4);
+                s0[k] = *reinterpret_cast<const f32x4*>(p + second); s1[k] = *reinterpret_cast<const f32x4*>(p + second + 4);
+                const float* bp = si.in_bias + (ok[k] ? (r[k] % T) * si.in_bias_ld + c8[k] : 0);
+                b0[k] = *reinterpret_cast<const f32x4*>(bp); b1[k] = *reinterpret_cast<const f32x4*>(bp + 4);
             }
-            for (int z = 1; z < si.nslab; ++z) {
+            if (si.nslab > 1) {
+#pragma unroll
+                for (int k = 0; k < UN; ++k) { v0[k] += s0[k]; v1[k] += s1[k]; }
+            }
+            for (int z = 2; z < si.nslab; ++z) {
                 f32x4 t0[UN], t1[UN];
 #pragma unroll
                 for (int k = 0; k < UN; ++k) {
@@ -230,8 +239,7 @@ __device__ __forceinline__ void stage_input(const StageIn si, unsigned char* lds
             }
 #pragma unroll
             for (int k = 0; k < UN; ++k) {
-                const float* bp = si.in_bias + (ok[k] ? (r[k] % T) * si.in_bias_ld + c8[k] : 0);
-                v0[k] += *reinterpret_cast<const f32x4*>(bp); v1[k] += *reinterpret_cast<const f32x4*>(bp + 4);
+                v0[k] += b0[k]; v1[k] += b1[k];
                 float v[8] = {v0[k][0], v0[k][1], v0[k][2], v0[k][3], v1[k][0], v1[k][1], v1[k][2], v1[k][3]};
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = lrelu(v[e]);
@@ -582,7 +590,7 @@ int launch_tail_bf16(gem_handle* h, const TailB16Args& a, size_t lds_bytes, hipS
             case 5: kern = a.dbg_ts ? tb::decoder_tail_bf16_kernel<true, 5, true> : tb::decoder_tail_bf16_kernel<true, 5, false>; break;
             case 4: kern = tb::decoder_tail_bf16_kernel<true, 4, false>; break;
             case 3: kern = tb::decoder_tail_bf16_kernel<true, 3, false>; break;
-            case 2: kern = tb::decoder_tail_bf16_kernel<true, 2, false>; break;
+            case 2: kern = a.dbg_ts ? tb::decoder_tail_bf16_kernel<true, 2, true> : tb::decoder_tail_bf16_kernel<true, 2, false>; break;
             case 1: kern = tb::decoder_tail_bf16_kernel<true, 1, false>; break;
         }
     } else {
@@ -591,7 +599,7 @@ int launch_tail_bf16(gem_handle* h, const TailB16Args& a, size_t lds_bytes, hipS
             case 4: kern = tb::decoder_tail_bf16_kernel<false, 4, false>; break;
             case 3: kern = tb::decoder_tail_bf16_kernel<false, 3, false>; break;
             case 2: kern = tb::decoder_tail_bf16_kernel<false, 2, false>; break;
-            case 1: kern = tb::decoder_tail_bf16_kernel<false, 1, false>; break;
+            case 1: kern = a.dbg_ts ? tb::decoder_tail_bf16_kernel<false, 1, true> : tb::decoder_tail_bf16_kernel<false, 1, false>; break;
         }
     }
     if (!kern) { set_error("launch_tail_bf16: unsupported row-tile count"); return 1; }
@@ -601,7 +609,8 @@ int launch_tail_bf16(gem_handle* h, const TailB16Args& a, size_t lds_bytes, hipS
         const kern_t all[] = {tb::decoder_tail_bf16_kernel<true, 5, true>, tb::decoder_tail_bf16_kernel<true, 5, false>, tb::decoder_tail_bf16_kernel<false, 5, true>,
                               tb::decoder_tail_bf16_kernel<false, 5, false>, tb::decoder_tail_bf16_kernel<false, 4, false>, tb::decoder_tail_bf16_kernel<false, 3, false>,
                               tb::decoder_tail_bf16_kernel<false, 2, false>, tb::decoder_tail_bf16_kernel<true, 4, false>, tb::decoder_tail_bf16_kernel<true, 3, false>,
-                              tb::decoder_tail_bf16_kernel<true, 2, false>, tb::decoder_tail_bf16_kernel<false, 1, false>, tb::decoder_tail_bf16_kernel<true, 1, false>};
+                              tb::decoder_tail_bf16_kernel<true, 2, false>, tb::decoder_tail_bf16_kernel<false, 1, false>, tb::decoder_tail_bf16_kernel<true, 1, false>,
+                              tb::decoder_tail_bf16_kernel<true, 2, true>, tb::decoder_tail_bf16_kernel<false, 1, true>};
         for (kern_t k : all) GEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     }
     if (a.n < 1 || a.n > TB_MAX_LAYERS || lds_bytes > 80 * 1024) { set_error("launch_tail_bf16: unsupported layer chain"); return 1; }
