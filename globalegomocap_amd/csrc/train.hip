@@ -42,7 +42,14 @@ struct TrainLinear {
 };
 struct AdjDesc { const float* W; float* out; int taps, N, K, tiles; };
 struct SumDesc { const float* slab; float* out; unsigned long long n; };
-constexpr int TN_ROWS_CONV = 64, TN_ROWS_LINEAR = 256;     // rows per weight-gradient slab
+constexpr int TN_ROWS_CONV = 64, TN_ROWS_LINEAR = 256;     // rows per weight-gradient slab (conv: at least; see conv_slab_rows)
+constexpr int TN_CONV_SLABS_MAX = 16;
+// rows per conv weight-gradient slab for a step of `rows` rows: 64 up to 1024 rows (the reference's batch: ten slabs fill the chip),
+// beyond that at most TN_CONV_SLABS_MAX slabs -- at 10 240 rows the sum over 160 slabs of 64 rows read 655 MB per step (round 4)
+static inline int conv_slab_rows(int rows) {
+    const int per = (rows + TN_CONV_SLABS_MAX - 1) / TN_CONV_SLABS_MAX;
+    return std::max(TN_ROWS_CONV, (per + 31) / 32 * 32);
+}
 constexpr int LOSS_BLOCK = 1024;
 
 }  // namespace gem
@@ -58,6 +65,7 @@ struct gem_trainer {
     float *pose_p = nullptr, *mulv = nullptr, *z = nullptr, *h0 = nullptr, *Xp = nullptr;
     float *gA = nullptr, *gB = nullptr, *dmulv = nullptr, *dz = nullptr;
     float *dYT = nullptr, *lin_slab = nullptr; int lin_slab_cap = 8;      // linear_bwd_data: transposed gradient [N][pad64(B)], K-slabs of dX
+    double* bn_part = nullptr; int bn_nrb_cap = 0;      // large-batch BatchNorm (bnl_*_kernel): [nrb][N][3] partial sums
     double* red = nullptr;         // [8 + partial sums]: [4..6] loss, recon, kld; [8..) per-block partials of the two loss kernels
     gem::AdjDesc* adj_tab = nullptr; int n_adj = 0, adj_tiles = 0;
     gem::SumDesc* sum_tab = nullptr; int n_sum = 0; size_t sum_max = 0;
@@ -69,8 +77,8 @@ struct gem_trainer {
 namespace gem {
 
 // ---- BatchNorm1d (training mode) + LeakyReLU over [rows, N]: one workgroup per 16 channels, BN_GROUPS row groups -------------
-// A thread owns channel c = lane & 15 of the rows g, g + 64, ...; up to BN_REGS of them live in registers, so that the statistics
-// and the normalisation need ONE trip to memory (rows <= 1024, i.e. batches up to 102 windows); longer inputs loop.
+// A thread owns channel c = lane & 15 of the rows g, g + 64, ...; BN_REGS of them live in registers, so that the statistics
+// and the normalisation need ONE trip to memory (rows <= 1024, i.e. batches up to 102 windows); longer inputs: bnl_*_kernel below.
 constexpr int BN_GROUPS = 64, BN_THREADS = 16 * BN_GROUPS, BN_REGS = 16;
 // column sums of NV per-thread values over the row groups of a workgroup: lanes of a wave that share a channel first (4 row
 // groups per wave), then the 16 waves through LDS; every thread returns the totals of its channel
@@ -93,7 +101,6 @@ __device__ __forceinline__ void bn_reduce(double (&v)[NV], double (*sh)[16][17])
     }
     __syncthreads();
 }
-template <bool IN_REGS>
 __global__ __launch_bounds__(BN_THREADS) void bn_train_fwd_kernel(const float* __restrict__ Y, int rows, int N, const float* __restrict__ gamma,
                                                                   const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
                                                                   float* __restrict__ mean_out, float* __restrict__ invstd_out, float* __restrict__ out,
@@ -102,32 +109,21 @@ __global__ __launch_bounds__(BN_THREADS) void bn_train_fwd_kernel(const float* _
     const int c = blockIdx.x * 16 + (threadIdx.x & 15), g = threadIdx.x >> 4;
     float y[BN_REGS];
     double v[2] = {0.0, 0.0};
-    if (IN_REGS) {
 #pragma unroll
-        for (int j = 0; j < BN_REGS; ++j) { const int r = g + j * BN_GROUPS; y[j] = r < rows ? Y[(size_t)r * N + c] : 0.f; }
+    for (int j = 0; j < BN_REGS; ++j) { const int r = g + j * BN_GROUPS; y[j] = r < rows ? Y[(size_t)r * N + c] : 0.f; }
 #pragma unroll
-        for (int j = 0; j < BN_REGS; ++j) { v[0] += (double)y[j]; v[1] += (double)y[j] * y[j]; }
-    } else {
-        for (int r = g; r < rows; r += BN_GROUPS) { const double q = Y[(size_t)r * N + c]; v[0] += q; v[1] += q * q; }
-    }
+    for (int j = 0; j < BN_REGS; ++j) { v[0] += (double)y[j]; v[1] += (double)y[j] * y[j]; }
     bn_reduce<2>(v, sh);
     const double mean = v[0] / rows;
     double var = v[1] / rows - mean * mean;                 // biased (what normalises the batch)
     if (var < 0.0) var = 0.0;
     const float invstd = (float)(1.0 / sqrt(var + (double)eps)), mf = (float)mean;
     const float ga = gamma[c], be = beta[c];
-    if (IN_REGS) {
 #pragma unroll
-        for (int j = 0; j < BN_REGS; ++j) {
-            const int r = g + j * BN_GROUPS;
-            const float o = ga * ((y[j] - mf) * invstd) + be;
-            if (r < rows) out[(size_t)r * N + c] = o > 0.f ? o : o * LEAKY_SLOPE;
-        }
-    } else {
-        for (int r = g; r < rows; r += BN_GROUPS) {
-            const float o = ga * ((Y[(size_t)r * N + c] - mf) * invstd) + be;
-            out[(size_t)r * N + c] = o > 0.f ? o : o * LEAKY_SLOPE;
-        }
+    for (int j = 0; j < BN_REGS; ++j) {
+        const int r = g + j * BN_GROUPS;
+        const float o = ga * ((y[j] - mf) * invstd) + be;
+        if (r < rows) out[(size_t)r * N + c] = o > 0.f ? o : o * LEAKY_SLOPE;
     }
     if (g == 0) {
         mean_out[c] = mf; invstd_out[c] = invstd;
@@ -139,7 +135,6 @@ __global__ __launch_bounds__(BN_THREADS) void bn_train_fwd_kernel(const float* _
 
 // dOut (w.r.t. the block's output) -> dY (w.r.t. the conv output), dgamma, dbeta, and the conv's bias gradient sum_r dY (zero up
 // to rounding -- the batch mean is subtracted --, computed the way autograd does).  LeakyReLU' from the sign of the output.
-template <bool IN_REGS>
 __global__ __launch_bounds__(BN_THREADS) void bn_train_bwd_kernel(const float* __restrict__ dOut, const float* __restrict__ out,
                                                                   const float* __restrict__ Y, int rows, int N, const float* __restrict__ gamma,
                                                                   const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -150,46 +145,154 @@ __global__ __launch_bounds__(BN_THREADS) void bn_train_bwd_kernel(const float* _
     const float mf = mean[c], is = invstd[c], ga = gamma[c];
     float dzv[BN_REGS], xh[BN_REGS];
     double v[2] = {0.0, 0.0};
-    if (IN_REGS) {
 #pragma unroll
-        for (int j = 0; j < BN_REGS; ++j) {
-            const int r = g + j * BN_GROUPS;
-            const size_t i = (size_t)r * N + c;
-            const bool ok = r < rows;
-            const float d = ok ? dOut[i] : 0.f, o = ok ? out[i] : 0.f, yy = ok ? Y[i] : mf;
-            dzv[j] = d * (o > 0.f ? 1.f : LEAKY_SLOPE);
-            xh[j] = (yy - mf) * is;
-        }
-#pragma unroll
-        for (int j = 0; j < BN_REGS; ++j) { v[0] += dzv[j]; v[1] += (double)dzv[j] * xh[j]; }
-    } else {
-        for (int r = g; r < rows; r += BN_GROUPS) {
-            const size_t i = (size_t)r * N + c;
-            const float d = dOut[i] * (out[i] > 0.f ? 1.f : LEAKY_SLOPE);
-            v[0] += d; v[1] += (double)d * ((Y[i] - mf) * is);
-        }
+    for (int j = 0; j < BN_REGS; ++j) {
+        const int r = g + j * BN_GROUPS;
+        const size_t i = (size_t)r * N + c;
+        const bool ok = r < rows;
+        const float d = ok ? dOut[i] : 0.f, o = ok ? out[i] : 0.f, yy = ok ? Y[i] : mf;
+        dzv[j] = d * (o > 0.f ? 1.f : LEAKY_SLOPE);
+        xh[j] = (yy - mf) * is;
     }
+#pragma unroll
+    for (int j = 0; j < BN_REGS; ++j) { v[0] += dzv[j]; v[1] += (double)dzv[j] * xh[j]; }
     bn_reduce<2>(v, sh);
     const float mb = (float)(v[0] / rows), mg = (float)(v[1] / rows);
     double w[1] = {0.0};
-    if (IN_REGS) {
 #pragma unroll
-        for (int j = 0; j < BN_REGS; ++j) {
-            const int r = g + j * BN_GROUPS;
-            const float d = ga * is * (dzv[j] - mb - xh[j] * mg);
-            if (r < rows) { dY[(size_t)r * N + c] = d; w[0] += d; }
-        }
-    } else {
-        for (int r = g; r < rows; r += BN_GROUPS) {
-            const size_t i = (size_t)r * N + c;
-            const float dz0 = dOut[i] * (out[i] > 0.f ? 1.f : LEAKY_SLOPE);
-            const float d = ga * is * (dz0 - mb - ((Y[i] - mf) * is) * mg);
-            dY[i] = d;
-            w[0] += d;
-        }
+    for (int j = 0; j < BN_REGS; ++j) {
+        const int r = g + j * BN_GROUPS;
+        const float d = ga * is * (dzv[j] - mb - xh[j] * mg);
+        if (r < rows) { dY[(size_t)r * N + c] = d; w[0] += d; }
     }
     bn_reduce<1>(w, sh);
     if (g == 0) { dgamma[c] = (float)v[1]; dbeta[c] = (float)v[0]; dbias[c] = (float)w[0]; }
+}
+
+// ---- BatchNorm for MORE rows than a workgroup holds in registers (rows > BN_REGS * BN_GROUPS = 1024: batches above 102 windows) ----
+// The one-workgroup-per-16-channels kernels above are built for the reference's batch of 64 (640 rows): at 10 240 rows (batch 1024)
+// their 4-32 workgroups read the layer two or three times at a few percent of the chip's bandwidth -- 2.1 of that step's 5.2 ms
+// (round 4).  Here a workgroup owns 64 channels x BNL_ROWS rows (256-byte row segments per wavefront): a first launch leaves
+// per-row-block partial sums (fp64), the second launch's workgroups each add them up for their 64 channels in row-block order (the
+// same bits in every workgroup) and normalise / form dY.  No atomics and no device-scope fences inside a kernel (a first version
+// that let the last workgroup of a channel group finish the statistics behind `__threadfence()` took 28-32 us per launch against 8
+// for the same pass without it: with eight non-coherent L2s a device-scope release is an L2 write-back).  Same formulas as
+// bn_train_fwd_kernel / bn_train_bwd_kernel; the conv bias gradient sum_r dY -- zero up to rounding -- is formed from the sums
+// (gamma invstd (sum dz - rows mean_dz - mean_dzx sum xhat)) instead of by a third pass.
+constexpr int BNL_ROWS = 128;
+// sums of NV per-thread values over the 4 row groups of a workgroup: every thread gets the totals of its channel
+template <int NV>
+__device__ __forceinline__ void bnl_block_sum(double (&v)[NV], double (*sh)[4][64]) {
+    const int l = threadIdx.x & 63, rg = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) sh[i][rg][l] = v[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = ((sh[i][0][l] + sh[i][1][l]) + sh[i][2][l]) + sh[i][3][l];
+    __syncthreads();
+}
+// totals over all row blocks of the partials [nrb][N][NV] for this thread's channel: a quarter of the row blocks per row group (all of
+// a thread's loads in flight together), the quarters added in order
+template <int NV>
+__device__ __forceinline__ void bnl_totals(const double* __restrict__ part, int nrb, int N, int c, double (&v)[NV], double (*sh)[4][64]) {
+    const int rg = threadIdx.x >> 6;
+    const int per = (nrb + 3) / 4, rb0 = rg * per, rb1 = min(nrb, rb0 + per);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = 0.0;
+#pragma unroll 8
+    for (int rb = rb0; rb < rb1; ++rb) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] += part[((size_t)rb * N + c) * NV + i];
+    }
+    bnl_block_sum<NV>(v, sh);
+}
+__global__ __launch_bounds__(256) void bnl_fwd_stats_kernel(const float* __restrict__ Y, int rows, int N, double* __restrict__ part) {
+    __shared__ double sh[2][4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6, r0 = blockIdx.y * BNL_ROWS;
+    double v[2] = {0.0, 0.0};
+#pragma unroll 8
+    for (int i = rg; i < BNL_ROWS; i += 4) {
+        const int r = r0 + i;
+        if (r < rows) { const double q = Y[(size_t)r * N + c]; v[0] += q; v[1] += q * q; }
+    }
+    bnl_block_sum<2>(v, sh);
+    if (rg == 0) { part[((size_t)blockIdx.y * N + c) * 2] = v[0]; part[((size_t)blockIdx.y * N + c) * 2 + 1] = v[1]; }
+}
+__global__ __launch_bounds__(256) void bnl_fwd_apply_kernel(const float* __restrict__ Y, int rows, int N, const double* __restrict__ part, int nrb,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ rmean,
+                                                            float* __restrict__ rvar, float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                                            float* __restrict__ out, float momentum, float eps) {
+    __shared__ double sh[2][4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6, r0 = blockIdx.y * BNL_ROWS;
+    double v[2];
+    bnl_totals<2>(part, nrb, N, c, v, sh);
+    const double mean = v[0] / rows;
+    double var = v[1] / rows - mean * mean;                 // biased (what normalises the batch)
+    if (var < 0.0) var = 0.0;
+    const float is = (float)(1.0 / sqrt(var + (double)eps)), mf = (float)mean;
+    if (blockIdx.y == 0 && rg == 0) {
+        mean_out[c] = mf; invstd_out[c] = is;
+        const double unbiased = rows > 1 ? var * rows / (rows - 1) : var;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * mf;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+    }
+    const float ga = gamma[c], be = beta[c];
+#pragma unroll 8
+    for (int i = rg; i < BNL_ROWS; i += 4) {
+        const int r = r0 + i;
+        if (r < rows) {
+            const float o = ga * ((Y[(size_t)r * N + c] - mf) * is) + be;
+            out[(size_t)r * N + c] = o > 0.f ? o : o * LEAKY_SLOPE;
+        }
+    }
+}
+// backward, first launch: partial sums of dz, dz xhat and xhat
+__global__ __launch_bounds__(256) void bnl_bwd_stats_kernel(const float* __restrict__ dOut, const float* __restrict__ out, const float* __restrict__ Y,
+                                                            int rows, int N, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            double* __restrict__ part) {
+    __shared__ double sh[3][4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6, r0 = blockIdx.y * BNL_ROWS;
+    const float mf = mean[c], is = invstd[c];
+    double v[3] = {0.0, 0.0, 0.0};
+#pragma unroll 8
+    for (int i = rg; i < BNL_ROWS; i += 4) {
+        const int r = r0 + i;
+        if (r < rows) {
+            const size_t k = (size_t)r * N + c;
+            const float d = dOut[k] * (out[k] > 0.f ? 1.f : LEAKY_SLOPE), xh = (Y[k] - mf) * is;
+            v[0] += d; v[1] += (double)d * xh; v[2] += xh;
+        }
+    }
+    bnl_block_sum<3>(v, sh);
+    if (rg == 0) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) part[((size_t)blockIdx.y * N + c) * 3 + i] = v[i];
+    }
+}
+// backward, second launch: dgamma, dbeta, the conv bias gradient (row block 0) and dY
+__global__ __launch_bounds__(256) void bnl_bwd_apply_kernel(const float* __restrict__ dOut, const float* __restrict__ out, const float* __restrict__ Y,
+                                                            int rows, int N, const double* __restrict__ part, int nrb, const float* __restrict__ gamma,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ dY,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dbias) {
+    __shared__ double sh[3][4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6, r0 = blockIdx.y * BNL_ROWS;
+    double v[3];
+    bnl_totals<3>(part, nrb, N, c, v, sh);
+    const float mf = mean[c], is = invstd[c], ga = gamma[c];
+    const float mb = (float)(v[0] / rows), mg = (float)(v[1] / rows);
+    if (blockIdx.y == 0 && rg == 0) {
+        dgamma[c] = (float)v[1]; dbeta[c] = (float)v[0];
+        dbias[c] = (float)((double)ga * is * (v[0] - (double)rows * mb - (double)mg * v[2]));
+    }
+#pragma unroll 8
+    for (int i = rg; i < BNL_ROWS; i += 4) {
+        const int r = r0 + i;
+        if (r < rows) {
+            const size_t k = (size_t)r * N + c;
+            const float dz0 = dOut[k] * (out[k] > 0.f ? 1.f : LEAKY_SLOPE);
+            dY[k] = ga * is * (dz0 - mb - ((Y[k] - mf) * is) * mg);
+        }
+    }
 }
 
 __global__ __launch_bounds__(BN_THREADS) void colsum_kernel(const float* __restrict__ dC, int rows, int N, float* __restrict__ out) {
@@ -585,7 +688,7 @@ int gem_trainer_create(const gem_config* cfg, gem_trainer** out) {
     gem_trainer* p = t.get();
     if (talloc(p, &p->P, off) || talloc(p, &p->G, off) || talloc(p, &p->M1, off) || talloc(p, &p->M2, off) || talloc(p, &p->S, soff)) return 1;
     size_t max_width = PAD;
-    const size_t conv_slabs = (rows + TN_ROWS_CONV - 1) / TN_ROWS_CONV, lin_slabs = ((size_t)p->Bmax + TN_ROWS_LINEAR - 1) / TN_ROWS_LINEAR;
+    const size_t conv_slabs = std::min<size_t>((rows + TN_ROWS_CONV - 1) / TN_ROWS_CONV, TN_CONV_SLABS_MAX), lin_slabs = ((size_t)p->Bmax + TN_ROWS_LINEAR - 1) / TN_ROWS_LINEAR;
     std::vector<AdjDesc> adj;
     std::vector<SumDesc> sums;          // conv layers first, then (only when they need slabs) the two linear layers
     for (auto* v : {&p->enc, &p->dec})
@@ -618,6 +721,8 @@ int gem_trainer_create(const gem_config* cfg, gem_trainer** out) {
     if (!sums.empty()) GEM_HIP(hipMemcpy(p->sum_tab, sums.data(), sums.size() * sizeof(SumDesc), hipMemcpyHostToDevice));
     p->part_recon = (int)((rows * PAD + LOSS_BLOCK - 1) / LOSS_BLOCK);
     p->part_latent = (int)(((size_t)p->Bmax * p->Dp + LOSS_BLOCK - 1) / LOSS_BLOCK);
+    p->bn_nrb_cap = (int)((rows + BNL_ROWS - 1) / BNL_ROWS);
+    if (talloc(p, &p->bn_part, (size_t)p->bn_nrb_cap * max_width * 3)) return 1;
     if (talloc(p, &p->pose_p, rows * PAD) || talloc(p, &p->mulv, (size_t)p->Bmax * 2 * p->Dp) || talloc(p, &p->z, (size_t)p->Bmax * p->Dp) ||
         talloc(p, &p->h0, rows * p->topp) || talloc(p, &p->Xp, rows * PAD) || talloc(p, &p->gA, rows * max_width) || talloc(p, &p->gB, rows * max_width) ||
         talloc(p, &p->dmulv, (size_t)p->Bmax * 2 * p->Dp) || talloc(p, &p->dz, (size_t)p->Bmax * p->Dp) ||
@@ -707,9 +812,17 @@ int gem_trainer_step(gem_trainer* t, int B, const float* d_pose, const float* d_
         Layer L; L.taps = 3; L.K = c.K; L.N = c.N; L.w = t->P + c.ow; L.bias = t->P + c.ob;
         if (launch_gemm(h, L, EPI_BIAS, in, c.K, nullptr, c.bn ? c.Y : c.out, c.N, rows, T, s, -1)) return 1;
         if (c.bn) {
-            auto k = rows <= BN_REGS * BN_GROUPS ? bn_train_fwd_kernel<true> : bn_train_fwd_kernel<false>;
-            hipLaunchKernelGGL(k, dim3(c.N / 16), dim3(BN_THREADS), 0, s, (const float*)c.Y, rows, c.N, (const float*)(t->P + c.og),
-                               (const float*)(t->P + c.obe), t->S + c.os, t->S + c.os + c.N, c.mean, c.invstd, c.out, (float)o->bn_momentum, (float)BN_EPS);
+            if (rows <= BN_REGS * BN_GROUPS) {
+                hipLaunchKernelGGL(bn_train_fwd_kernel, dim3(c.N / 16), dim3(BN_THREADS), 0, s, (const float*)c.Y, rows, c.N, (const float*)(t->P + c.og),
+                                   (const float*)(t->P + c.obe), t->S + c.os, t->S + c.os + c.N, c.mean, c.invstd, c.out, (float)o->bn_momentum, (float)BN_EPS);
+            } else {
+                const int nrb = (rows + BNL_ROWS - 1) / BNL_ROWS;
+                hipLaunchKernelGGL(bnl_fwd_stats_kernel, dim3(c.N / 64, nrb), dim3(256), 0, s, (const float*)c.Y, rows, c.N, t->bn_part);
+                GEM_HIP(hipGetLastError());
+                hipLaunchKernelGGL(bnl_fwd_apply_kernel, dim3(c.N / 64, nrb), dim3(256), 0, s, (const float*)c.Y, rows, c.N, (const double*)t->bn_part, nrb,
+                                   (const float*)(t->P + c.og), (const float*)(t->P + c.obe), t->S + c.os, t->S + c.os + c.N, c.mean, c.invstd, c.out,
+                                   (float)o->bn_momentum, (float)BN_EPS);
+            }
             GEM_HIP(hipGetLastError());
         }
         return 0;
@@ -732,21 +845,35 @@ int gem_trainer_step(gem_trainer* t, int B, const float* d_pose, const float* d_
     hipLaunchKernelGGL(recon_loss_kernel, dim3(n_pr), dim3(LOSS_BLOCK), 0, s, X, (const float*)t->pose_p, rows, t->C, (float)(1.0 / n_recon), t->gA, part_recon);
     GEM_HIP(hipGetLastError());
     // ---- backward: decoder
-    auto bn_bwd = rows <= BN_REGS * BN_GROUPS ? bn_train_bwd_kernel<true> : bn_train_bwd_kernel<false>;
+    auto bn_bwd = [&](const float* dOut, const TrainConv& c, float* dY) -> int {
+        if (rows <= BN_REGS * BN_GROUPS) {
+            hipLaunchKernelGGL(bn_train_bwd_kernel, dim3(c.N / 16), dim3(BN_THREADS), 0, s, dOut, (const float*)c.out, (const float*)c.Y, rows, c.N,
+                               (const float*)(t->P + c.og), (const float*)c.mean, (const float*)c.invstd, dY, t->G + c.og, t->G + c.obe, t->G + c.ob);
+        } else {
+            const int nrb = (rows + BNL_ROWS - 1) / BNL_ROWS;
+            hipLaunchKernelGGL(bnl_bwd_stats_kernel, dim3(c.N / 64, nrb), dim3(256), 0, s, dOut, (const float*)c.out, (const float*)c.Y, rows, c.N,
+                               (const float*)c.mean, (const float*)c.invstd, t->bn_part);
+            GEM_HIP(hipGetLastError());
+            hipLaunchKernelGGL(bnl_bwd_apply_kernel, dim3(c.N / 64, nrb), dim3(256), 0, s, dOut, (const float*)c.out, (const float*)c.Y, rows, c.N,
+                               (const double*)t->bn_part, nrb, (const float*)(t->P + c.og), (const float*)c.mean, (const float*)c.invstd, dY,
+                               t->G + c.og, t->G + c.obe, t->G + c.ob);
+        }
+        GEM_HIP(hipGetLastError());
+        return 0;
+    };
     float *g = t->gA, *g2 = t->gB;
     for (int i = (int)t->dec.size() - 1; i >= 0; --i) {
         TrainConv& c = t->dec[i];
         const float* a_in = i > 0 ? t->dec[i - 1].out : t->h0;
         const float* dY = g;
         if (c.bn) {
-            hipLaunchKernelGGL(bn_bwd, dim3(c.N / 16), dim3(BN_THREADS), 0, s, (const float*)g, (const float*)c.out, (const float*)c.Y, rows, c.N,
-                               (const float*)(t->P + c.og), (const float*)c.mean, (const float*)c.invstd, g2, t->G + c.og, t->G + c.obe, t->G + c.ob);
+            if (bn_bwd(g, c, g2)) return 1;
             dY = g2;
         } else {
             hipLaunchKernelGGL(colsum_kernel, dim3(c.N / 16), dim3(BN_THREADS), 0, s, dY, rows, c.N, t->G + c.ob);
         }
         GEM_HIP(hipGetLastError());
-        if (weight_grad<3>(t, dY, c.N, a_in, c.K, rows, c.N, c.K, c.ow, c.slab, TN_ROWS_CONV, s)) return 1;
+        if (weight_grad<3>(t, dY, c.N, a_in, c.K, rows, c.N, c.K, c.ow, c.slab, conv_slab_rows(rows), s)) return 1;
         Layer L; L.taps = 3; L.K = c.N; L.N = c.K; L.w = c.adj; L.bias = nullptr;
         float* dA = (dY == g) ? g2 : g;          // the buffer that does not hold dY
         if (launch_gemm(h, L, EPI_NONE, dY, c.N, nullptr, dA, c.K, rows, T, s, -1)) return 1;
@@ -778,17 +905,15 @@ int gem_trainer_step(gem_trainer* t, int B, const float* d_pose, const float* d_
     for (int i = (int)t->enc.size() - 1; i >= 0; --i) {
         TrainConv& c = t->enc[i];
         const float* a_in = i > 0 ? t->enc[i - 1].out : t->pose_p;
-        hipLaunchKernelGGL(bn_bwd, dim3(c.N / 16), dim3(BN_THREADS), 0, s, (const float*)g, (const float*)c.out, (const float*)c.Y, rows, c.N,
-                           (const float*)(t->P + c.og), (const float*)c.mean, (const float*)c.invstd, g2, t->G + c.og, t->G + c.obe, t->G + c.ob);
-        GEM_HIP(hipGetLastError());
-        if (weight_grad<3>(t, g2, c.N, a_in, c.K, rows, c.N, c.K, c.ow, c.slab, TN_ROWS_CONV, s)) return 1;
+        if (bn_bwd(g, c, g2)) return 1;
+        if (weight_grad<3>(t, g2, c.N, a_in, c.K, rows, c.N, c.K, c.ow, c.slab, conv_slab_rows(rows), s)) return 1;
         if (i > 0) {
             Layer L; L.taps = 3; L.K = c.N; L.N = c.K; L.w = c.adj; L.bias = nullptr;
             if (launch_gemm(h, L, EPI_NONE, g2, c.N, nullptr, g, c.K, rows, T, s, -1)) return 1;
         }
     }
     // the weight-gradient slabs -> the gradient arena (slab order: deterministic)
-    { const int ns_conv = (rows + TN_ROWS_CONV - 1) / TN_ROWS_CONV, ns_lin = (B + TN_ROWS_LINEAR - 1) / TN_ROWS_LINEAR;
+    { const int ns_conv = (rows + conv_slab_rows(rows) - 1) / conv_slab_rows(rows), ns_lin = (B + TN_ROWS_LINEAR - 1) / TN_ROWS_LINEAR;
       // (every conv layer's weight_grad<3> call above cut the same `rows` into slabs of TN_ROWS_CONV rows: ONE slab count serves
       // the whole table; the two linear layers' entries sit behind the conv entries)
       if (ns_conv > 1 && t->n_sum > 0) {
