@@ -30,6 +30,9 @@ run f32_1536/trace      "--kernel-trace --stats" "--steps 3 --warmup 1 --workloa
 mkdir -p $OUT/train
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train/trace -- python tools/train_bench.py 64 50 > $OUT/train/trace.log 2>&1 || { echo "FAILED train"; tail -5 $OUT/train/trace.log; exit 1; }
 grep "^B=" $OUT/train/trace.log
+mkdir -p $OUT/train1024
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train1024/trace -- python tools/train_bench.py 1024 20 > $OUT/train1024/trace.log 2>&1 || { echo "FAILED train1024"; tail -5 $OUT/train1024/trace.log; exit 1; }
+grep "^B=" $OUT/train1024/trace.log
 # keep the summaries small: per-dispatch traces are dropped, the stats / counter tables stay
 find $OUT -name '*_kernel_trace.csv' -delete
 for d in f32 bf16_8192 bf16_1536; do

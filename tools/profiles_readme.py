@@ -41,7 +41,8 @@ for title, sfile, tfile in (
         ("BASELINE configs[3] per-GPU shard: exactly 8192 windows, bf16, one lane", "kernel_stats_%s_bf16_8192_windows.csv" % tag,
          "traffic_%s_bf16_8192_windows.json" % tag),
         ("1536 windows, fp32", "kernel_stats_%s_f32_1536_windows.csv" % tag, None),
-        ("the training step (SURVEY 8 f.4), batch 64", "kernel_stats_%s_train_b64.csv" % tag, "traffic_%s_train_b64.json" % tag)):
+        ("the training step (SURVEY 8 f.4), batch 64", "kernel_stats_%s_train_b64.csv" % tag, "traffic_%s_train_b64.json" % tag),
+        ("the training step, batch 1024", "kernel_stats_%s_train_b1024.csv" % tag, None)):
     head, rows = stats(sfile, KEEP, top=9)
     if head is None:
         continue

@@ -69,17 +69,17 @@ kernel_stats("bf16_1536", "kernel_stats_%s_bf16_1536_windows.csv" % tag)
 kernel_stats("bf16_8192", "kernel_stats_%s_bf16_8192_windows.csv" % tag)
 
 
-def train_stats(out_name):
-    """rocprofv3 --kernel-trace --stats of tools/train_bench.py 64 50, summarised like the others (per-step launch counts)."""
-    f = glob.glob(os.path.join(src, "train", "trace", "*", "*kernel_stats.csv"))
+def train_stats(out_name, sub="train", batch=64, timed=50):
+    """rocprofv3 --kernel-trace --stats of tools/train_bench.py <batch> <timed>, summarised like the others (per-step launch counts)."""
+    f = glob.glob(os.path.join(src, sub, "trace", "*", "*kernel_stats.csv"))
     if not f:
         return
     rows = list(csv.DictReader(open(f[0])))
-    log = [l for l in open(os.path.join(src, "train", "trace.log")) if l.startswith("B=")]
-    steps = 55                                    # 5 warm-up + 50 timed steps of the tool
+    log = [l for l in open(os.path.join(src, sub, "trace.log")) if l.startswith("B=")]
+    steps = 5 + timed                             # 5 warm-up + the timed steps of the tool
     with open(os.path.join(dst, out_name), "w") as o:
-        o.write("# rocprofv3 --kernel-trace --stats of: python tools/train_bench.py 64 50 (%d steps in the trace); this run printed: %s\n"
-                % (steps, log[-1].strip() if log else "?"))
+        o.write("# rocprofv3 --kernel-trace --stats of: python tools/train_bench.py %d %d (%d steps in the trace); this run printed: %s\n"
+                % (batch, timed, steps, log[-1].strip() if log else "?"))
         w = csv.writer(o)
         w.writerow(["kernel", "calls", "calls_per_step", "total_ms", "avg_us", "pct", "min_us", "max_us"])
         for r in rows:
@@ -90,6 +90,7 @@ def train_stats(out_name):
 
 
 train_stats("kernel_stats_%s_train_b64.csv" % tag)
+train_stats("kernel_stats_%s_train_b1024.csv" % tag, "train1024", 1024, 20)
 # the dominant kernel of the headline run = the kernel (all instantiations of a template counted together) with the most time
 def total_ms(sub, substr):
     f = glob.glob(os.path.join(src, sub, "trace", "*", "*kernel_stats.csv"))
