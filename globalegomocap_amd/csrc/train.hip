@@ -134,17 +134,17 @@ __global__ __launch_bounds__(BN_THREADS) void bn_train_fwd_kernel(const float* _
 }
 
 // dOut (w.r.t. the block's output) -> dY (w.r.t. the conv output), dgamma, dbeta, and the conv's bias gradient sum_r dY (zero up
-// to rounding -- the batch mean is subtracted --, computed the way autograd does).  LeakyReLU' from the sign of the output.
+// to rounding -- the batch mean is subtracted).  LeakyReLU' from the sign of the output.
 __global__ __launch_bounds__(BN_THREADS) void bn_train_bwd_kernel(const float* __restrict__ dOut, const float* __restrict__ out,
                                                                   const float* __restrict__ Y, int rows, int N, const float* __restrict__ gamma,
                                                                   const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                   float* __restrict__ dY, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                   float* __restrict__ dbias) {
-    __shared__ double sh[2][16][17];
+    __shared__ double sh[3][16][17];
     const int c = blockIdx.x * 16 + (threadIdx.x & 15), g = threadIdx.x >> 4;
     const float mf = mean[c], is = invstd[c], ga = gamma[c];
     float dzv[BN_REGS], xh[BN_REGS];
-    double v[2] = {0.0, 0.0};
+    double v[3] = {0.0, 0.0, 0.0};
 #pragma unroll
     for (int j = 0; j < BN_REGS; ++j) {
         const int r = g + j * BN_GROUPS;
@@ -155,18 +155,20 @@ __global__ __launch_bounds__(BN_THREADS) void bn_train_bwd_kernel(const float* _
         xh[j] = (yy - mf) * is;
     }
 #pragma unroll
-    for (int j = 0; j < BN_REGS; ++j) { v[0] += dzv[j]; v[1] += (double)dzv[j] * xh[j]; }
-    bn_reduce<2>(v, sh);
+    for (int j = 0; j < BN_REGS; ++j) { v[0] += dzv[j]; v[1] += (double)dzv[j] * xh[j]; v[2] += xh[j]; }
+    bn_reduce<3>(v, sh);
     const float mb = (float)(v[0] / rows), mg = (float)(v[1] / rows);
-    double w[1] = {0.0};
 #pragma unroll
     for (int j = 0; j < BN_REGS; ++j) {
         const int r = g + j * BN_GROUPS;
-        const float d = ga * is * (dzv[j] - mb - xh[j] * mg);
-        if (r < rows) { dY[(size_t)r * N + c] = d; w[0] += d; }
+        if (r < rows) dY[(size_t)r * N + c] = ga * is * (dzv[j] - mb - xh[j] * mg);
     }
-    bn_reduce<1>(w, sh);
-    if (g == 0) { dgamma[c] = (float)v[1]; dbeta[c] = (float)v[0]; dbias[c] = (float)w[0]; }
+    // the conv bias gradient sum_r dY = gamma invstd (sum dz - rows mean_dz - mean_dzx sum xhat): zero up to rounding, from the sums
+    // (round 4: no second reduction; what torch holds there is rounding noise of the same size)
+    if (g == 0) {
+        dgamma[c] = (float)v[1]; dbeta[c] = (float)v[0];
+        dbias[c] = (float)((double)ga * is * (v[0] - (double)rows * mb - (double)mg * v[2]));
+    }
 }
 
 // ---- BatchNorm for MORE rows than a workgroup holds in registers (rows > BN_REGS * BN_GROUPS = 1024: batches above 102 windows) ----
@@ -477,7 +479,10 @@ __global__ __launch_bounds__(256) void slab_sum_all_kernel(const SumDesc* __rest
 
 // dY [B][N] -> dY^T [N][Bp] (columns >= B zero): the row-major operand the rows-contracting kernel wants for the backward-data
 // product of a linear layer, dX[b][k] = sum_n dY[b][n] W[n][k], taken straight from W's own [N][K] layout (linear_bwd_data)
-__global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restrict__ src, int B, int N, int Bp, float* __restrict__ dst) {
+// colsum != nullptr (one row tile only, Bp == 64): also the layer's bias gradient sum_b dY[b][n] (an fp64 sum of at most 64 fp32
+// values: exact, so the same number colsum_kernel writes)
+__global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restrict__ src, int B, int N, int Bp, float* __restrict__ dst,
+                                                            float* __restrict__ colsum) {
     __shared__ float tile[64][65];
     const int n0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -489,6 +494,12 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restr
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 16; ++j) dst[(size_t)(n0 + ty + 4 * j) * Bp + b0 + tx] = tile[tx][ty + 4 * j];
+    if (colsum && ty == 0) {
+        double sum = 0.0;
+#pragma unroll 8
+        for (int b = 0; b < 64; ++b) sum += (double)tile[b][tx];
+        colsum[n0 + tx] = (float)sum;
+    }
 }
 // out[i] = sum over slabs (slab order), i < n_out <= n_slab_elems
 __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slab, int nslab, size_t n_slab_elems, float* __restrict__ out, size_t n_out) {
@@ -561,7 +572,8 @@ __global__ __launch_bounds__(LOSS_BLOCK) void latent_bwd_kernel(const float* __r
 }
 // sums the per-block partials in block order: out = [loss, recon, kld]
 __global__ __launch_bounds__(256) void finish_loss_kernel(const double* __restrict__ part_recon, int n_recon_parts, const double* __restrict__ part_latent,
-                                                          int n_latent_parts, double n_recon, double kld_weight, int B, double* __restrict__ out) {
+                                                          int n_latent_parts, double n_recon, double kld_weight, int B, double* __restrict__ out,
+                                                          double* __restrict__ out2) {
     __shared__ double sh[2][256];
     double a = 0.0, b = 0.0;
     for (int i = threadIdx.x; i < n_recon_parts; i += 256) a += part_recon[i];
@@ -573,6 +585,7 @@ __global__ __launch_bounds__(256) void finish_loss_kernel(const double* __restri
         for (int i = 0; i < 256; ++i) { a += sh[0][i]; b += sh[1][i]; }
         const double recon = a / n_recon, kld = -0.5 * b / B;
         out[0] = recon + kld_weight * kld; out[1] = recon; out[2] = kld;
+        if (out2) { out2[0] = out[0]; out2[1] = recon; out2[2] = kld; }          // (the caller's copy: no copy launch behind the step)
     }
 }
 
@@ -634,9 +647,16 @@ static int linear_gemm(gem_trainer* t, const Layer& L, int epi, const float* A, 
 // of W -- what gemm_tn_kernel does (rows-contracting, both operands row-major) once dY is transposed (1.3 MB at the reference's
 // batch).  The n range is cut into slabs that fill the chip and are summed in slab order.  Replaces the adjoint image of the
 // layer (a 2 x 126 MB transpose of both linear layers' weights per step in round 3) and the few-rows product that read it.
-static int linear_bwd_data(gem_trainer* t, const float* dY, const float* W, float* dX, int B, int N, int K, hipStream_t s) {
+// bias_grad != nullptr: the layer's bias gradient (the column sums of dY) is wanted as well: formed by the transpose when the batch is one
+// row tile, by colsum_kernel otherwise
+static int linear_bwd_data(gem_trainer* t, const float* dY, const float* W, float* dX, int B, int N, int K, hipStream_t s, float* bias_grad) {
     const int Bp = pad64(B);
-    hipLaunchKernelGGL(transpose_pad_kernel, dim3(N / 64, Bp / 64), dim3(256), 0, s, dY, B, N, Bp, t->dYT);
+    const bool fold = bias_grad && Bp == 64;
+    if (bias_grad && !fold) {
+        hipLaunchKernelGGL(colsum_kernel, dim3(N / 16), dim3(BN_THREADS), 0, s, dY, B, N, bias_grad);
+        GEM_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(transpose_pad_kernel, dim3(N / 64, Bp / 64), dim3(256), 0, s, dY, B, N, Bp, t->dYT, fold ? bias_grad : nullptr);
     GEM_HIP(hipGetLastError());
     const int tiles = (Bp / 64) * (K / 64);
     int nslab = (2 * t->h->n_cu + tiles - 1) / tiles;
@@ -881,25 +901,21 @@ int gem_trainer_step(gem_trainer* t, int B, const float* d_pose, const float* d_
     }
     // g = dh0 [B, T*topp]: decoder_input
     { const TrainLinear& l = t->dec_in;
-      hipLaunchKernelGGL(colsum_kernel, dim3(l.N / 16), dim3(BN_THREADS), 0, s, (const float*)g, B, l.N, t->G + l.ob);
-      GEM_HIP(hipGetLastError());
       if (!fused && weight_grad<1>(t, g, l.N, t->z, l.K, B, l.N, l.K, l.ow, l.slab, TN_ROWS_LINEAR, s)) return 1;
-      if (linear_bwd_data(t, g, t->P + l.ow, t->dz, B, l.N, l.K, s)) return 1;
+      if (linear_bwd_data(t, g, t->P + l.ow, t->dz, B, l.N, l.K, s, t->G + l.ob)) return 1;
       if (fused && linear_step(l, g, t->z)) return 1; }          // (behind the backward-data product: it reads the weights)
     hipLaunchKernelGGL(latent_bwd_kernel, dim3(n_pl), dim3(LOSS_BLOCK), 0, s, (const float*)t->mulv, d_eps, (const float*)t->dz, B, t->D, t->Dp,
                        (float)(o->kld_weight / B), t->dmulv, part_latent);
     GEM_HIP(hipGetLastError());
     hipLaunchKernelGGL(finish_loss_kernel, dim3(1), dim3(256), 0, s, (const double*)part_recon, n_pr, (const double*)part_latent, n_pl, n_recon,
-                       o->kld_weight, B, t->red + 4);
+                       o->kld_weight, B, t->red + 4, d_losses);
     GEM_HIP(hipGetLastError());
     // fc_mu | fc_var
     { const TrainLinear& l = t->fc;
       const float* flat = t->enc.back().out;
-      hipLaunchKernelGGL(colsum_kernel, dim3(l.N / 16), dim3(BN_THREADS), 0, s, (const float*)t->dmulv, B, l.N, t->G + l.ob);
-      GEM_HIP(hipGetLastError());
       if (!fused && weight_grad<1>(t, t->dmulv, l.N, flat, l.K, B, l.N, l.K, l.ow, l.slab, TN_ROWS_LINEAR, s)) return 1;
       g = t->gA; g2 = t->gB;
-      if (linear_bwd_data(t, t->dmulv, t->P + l.ow, g, B, l.N, l.K, s)) return 1;
+      if (linear_bwd_data(t, t->dmulv, t->P + l.ow, g, B, l.N, l.K, s, t->G + l.ob)) return 1;
       if (fused && linear_step(l, t->dmulv, flat)) return 1; }
     // encoder
     for (int i = (int)t->enc.size() - 1; i >= 0; --i) {
@@ -923,7 +939,6 @@ int gem_trainer_step(gem_trainer* t, int B, const float* d_pose, const float* d_
       if (ns_lin > 1 && !fused)
           hipLaunchKernelGGL(slab_sum_all_kernel, dim3((unsigned)((t->sum_max / 4 + 255) / 256), 2), dim3(256), 0, s, (const SumDesc*)t->sum_tab + t->n_sum, ns_lin);
       GEM_HIP(hipGetLastError()); }
-    if (d_losses) GEM_HIP(hipMemcpyAsync(d_losses, t->red + 4, 3 * sizeof(double), hipMemcpyDeviceToDevice, s));
     if (update) return apply_adam(t, o, 1.0, s, fused);
     return 0;
 }
