@@ -199,11 +199,12 @@ __device__ __forceinline__ void energy_finish(const EnergyArgs& a, int b, int la
 }
 
 // ---- one WAVEFRONT per window: lane l owns the pairs l, l + 64, ... (NP = ceil(T*J / 64) trips, compile time) -----------------------
-// gd: bf16 gradient rows [T][ldg] of the window in LDS (the caller has zeroed them: the pad columns [J*3, gcols) stay zero).
+// gd: bf16 gradient rows [T][ldg] of the window in LDS; gcols > 0: zeroed here first (the pad columns [J*3, gcols) stay zero; LDS
+// operations of one wave complete in order), gcols = 0: the caller has zeroed them.
 template <int CT, int CJ, int NP>
 __device__ __forceinline__ void energy_pairs(const EnergyArgs& a, int b, int lane, const float* __restrict__ xs,
                                              const float* __restrict__ mbl, const int* __restrict__ par_l, const int* __restrict__ ch_l,
-                                             uint16_t* __restrict__ gd, int ldg, long long* dbg = nullptr) {
+                                             uint16_t* __restrict__ gd, int ldg, int gcols, long long* dbg = nullptr) {
     // (the lane index is re-derived here -- two v_mbcnt -- rather than kept alive, or spilled, across the caller's matrix layers)
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
     const int T = CT ? CT : a.T, J = CJ ? CJ : a.J, TJ = T * J;
@@ -228,6 +229,13 @@ __device__ __forceinline__ void energy_pairs(const EnergyArgs& a, int b, int lan
         }
     }
     const int frame0 = a.wr != 0.f ? a.frame0[b] : 0;
+    if (gcols > 0) {
+        const int per_row = gcols / 4;                       // 8-byte pieces per row
+        for (int i = lane; i < T * per_row; i += 64) {
+            const int t = i / per_row, c4 = (i - t * per_row) * 4;
+            *reinterpret_cast<unsigned long long*>(gd + t * ldg + c4) = 0ull;
+        }
+    }
     float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     float gout[NP][3];
     EP_PROBE();

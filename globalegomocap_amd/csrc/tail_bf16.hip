@@ -357,9 +357,10 @@ __global__ __launch_bounds__(THREADS, DENSE ? 4 : 2) void decoder_tail_bf16_kern
         lds_barrier();
         TB_PROBE();
     }
-    // the bf16 gradient rows w.r.t. the pose (act[NL]'s slot: the buffer of act[NL - 2], dead since the barrier above) are zeroed here
-    // -- their pad columns stay zero, the energy terms write the J*3 value columns behind the next barrier
-    if (!a.forward_only) {
+    // up to three row tiles (the whole workgroup computes the energy terms): the bf16 gradient rows w.r.t. the pose (act[NL]'s slot: the
+    // buffer of act[NL - 2], dead since the barrier above) are zeroed here -- their pad columns stay zero, the energy terms write the
+    // J*3 value columns behind the next barrier; more tiles: the wavefront that owns a window zeroes its rows itself
+    if (NRT <= 3 && !a.forward_only) {
         const int ldg_b = a.ld_act[NL];
         for (int i = tid; i < R * (PAD / 4); i += THREADS) {
             const int r = i / (PAD / 4), c4 = (i - r * (PAD / 4)) * 4;
@@ -404,14 +405,15 @@ __global__ __launch_bounds__(THREADS, DENSE ? 4 : 2) void decoder_tail_bf16_kern
         const float* mbl0 = reinterpret_cast<const float*>(lds + a.off_mb);
         uint16_t* gd0 = reinterpret_cast<uint16_t*>(lds + a.off_act[NL]);
         constexpr int G10 = 16 * NRT / 10 < 8 ? 16 * NRT / 10 : 8;          // windows of ten frames per workgroup
-        if (NRT <= 3 && fast_e && a.off_epair >= 0) {
+        if (NRT <= 3 && fast_e && a.off_epair >= 0) {          // (plan_tail_bf16 reserves off_epair exactly for NRT <= 3)
             energy_pairs_wg<10, 15, (G10 * 150 + THREADS - 1) / THREADS, THREADS>(a.e, reinterpret_cast<const int*>(lds + a.off_bwin), nwin, tid, xs0,
                                                                                 a.escr, mbl0, par, ch, gd0, T * ldg, ldg,
                                                                                 reinterpret_cast<float*>(lds + a.off_epair), [] { lds_barrier(); });
         } else if (wave < nwin) {
-            if (fast_e) energy_pairs<10, 15, 3>(a.e, bwin, lane, xs0 + wave * a.escr, mbl0 + wave * MAXJ, par, ch, gd0 + wave * T * ldg, ldg,
+            const int gz = NRT <= 3 ? 0 : PAD;
+            if (fast_e) energy_pairs<10, 15, 3>(a.e, bwin, lane, xs0 + wave * a.escr, mbl0 + wave * MAXJ, par, ch, gd0 + wave * T * ldg, ldg, gz,
                                                 (PROBE && a.dbg_ts && blockIdx.x == 0 && wave == 0) ? a.dbg_ts + 32 : nullptr);
-            else energy_pairs<0, 0, 4>(a.e, bwin, lane, xs0 + wave * a.escr, mbl0 + wave * MAXJ, par, ch, gd0 + wave * T * ldg, ldg);
+            else energy_pairs<0, 0, 4>(a.e, bwin, lane, xs0 + wave * a.escr, mbl0 + wave * MAXJ, par, ch, gd0 + wave * T * ldg, ldg, gz);
         }
     }
     last_step = a.steps_total - 1;
