@@ -292,8 +292,9 @@ def test_two_rank_data_parallel_steps_equal_the_mean_gradient_step(tmp_path):
 @pytest.mark.parametrize("batch", [4, 130, 300])
 def test_training_step_against_the_port_at_other_batch_sizes(batch):
     """The code paths the golden batches (9, 12) do not reach: 4 windows = 40 rows, a single weight-gradient slab written
-    straight into the gradient arena; 130 windows = 1300 rows, the BatchNorm kernels' looping variant (more rows than a
-    thread keeps in registers); 300 windows, the linear layers' weight gradients in two slabs."""
+    straight into the gradient arena; 130 windows = 1300 rows, the large-batch BatchNorm kernels (more rows than a thread keeps
+    in registers: per-row-block partial sums, two launches); 300 windows, the linear layers' weight gradients in two slabs and
+    the conv layers' in slabs of more than 64 rows."""
     from globalegomocap_amd.vae_train import VAETrainer, initial_state_dict
     from oracle.torch_port import TrainPort
     shape = vae_schema.VAEShape(latent_dim=72, hidden=(24, 40, 96))
@@ -371,5 +372,29 @@ def test_training_loop_mode_steps_like_the_default_mode():
         # gradient entries of this network carry ~1e-3 of rounding noise -- see test_full_size_training_step_against_the_port --
         # which is what separates the moments here after the first step's 1-ulp differences)
         assert a.steps == b.steps == 3
+    finally:
+        a.close(); b.close()
+
+
+def test_training_loop_mode_at_a_large_batch():
+    """update = 2 beyond one slab of rows (300 windows: the fused kernel walks all 300 rows where the two-kernel path sums two
+    slabs) on a small network: the losses of three successive steps against update = 1, and against the port."""
+    from globalegomocap_amd.vae_train import VAETrainer, initial_state_dict
+    from oracle.torch_port import TrainPort
+    shape = vae_schema.VAEShape(latent_dim=72, hidden=(24, 40, 96))
+    batch = 300
+    init = initial_state_dict(shape, 23)
+    poses = synth.make_training_windows(3 * batch, shape.seq_len, 9).reshape(3, batch, shape.seq_len, 45)
+    eps = np.random.default_rng(4).standard_normal((3, batch, shape.latent_dim)).astype(np.float32)
+    port = TrainPort(init, lr=1e-3, weight_decay=1e-4)
+    a = VAETrainer(shape, batch_size=batch, lr=1e-3, weight_decay=1e-4, state_dict=init)
+    b = VAETrainer(shape, batch_size=batch, lr=1e-3, weight_decay=1e-4, state_dict=init)
+    try:
+        for s in range(3):
+            ref = port.step(poses[s], eps[s], 0.02)
+            la = a.step(poses[s], 0.02, eps=eps[s])
+            lb = b.step(poses[s], 0.02, eps=eps[s], keep_gradients=False)
+            np.testing.assert_allclose(lb, la, rtol=2e-6)
+            np.testing.assert_allclose(lb, ref, rtol=1e-4)
     finally:
         a.close(); b.close()
