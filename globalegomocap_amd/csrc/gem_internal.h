@@ -364,12 +364,12 @@ struct TailArgs {
 };
 size_t plan_tail(const std::vector<Layer>& dec, int start, int T, int J, TailArgs* out);
 
-// bf16 multi-window fused tail (tail_bf16.hip): G = min(8, 80 / T) windows = up to 80 rows (five 16-row MFMA tiles) per workgroup,
-// two workgroups per CU (<= 80 KB of LDS, <= 128 VGPRs)
+// bf16 multi-window fused tail (tail_bf16.hip): nrt = 1 .. 5 row tiles of 16 rows = G = min(8, 16 nrt / T) windows per workgroup,
+// up to two workgroups per CU (<= 80 KB of LDS, <= 128 VGPRs)
 constexpr int TB_MAX_LAYERS = 6;
 struct TailB16Layer { int K, N; const float* bias; };
 struct TailB16Args {
-    int n, B, G, nrt, forward_only, mask_first;      // nrt: 16-row tiles per workgroup (5, 4 or 3); G = min(8, 16 nrt / T) windows
+    int n, B, G, nrt, forward_only, mask_first;      // nrt: 16-row tiles per workgroup (1 .. 5); G = min(8, 16 nrt / T) windows
     SlabSrc in_slab;           // the input still lies in fp32 split-K slabs (+ in_bias, LeakyReLU to apply) when in_slab.base != nullptr
     const float* in_bias;      // bias of row r, column c: in_bias[(r % T) * in_bias_ld + c]
     int in_bias_ld;

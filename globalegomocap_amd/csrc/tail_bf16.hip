@@ -1,14 +1,16 @@
 // bf16 multi-window fused decoder tail (gfx950): the narrow temporal convs of the decoder, the energy terms and the matching
-// backward-data convs of EIGHT windows in one workgroup -- the "bf16 VAE decoder / fp32 energy" mode of BASELINE configs[2..4].
+// backward-data convs of ONE to EIGHT windows in one workgroup -- the "bf16 VAE decoder / fp32 energy" mode of BASELINE configs[2..4].
 //
 // The fp32 tail (tail.hip) gives one workgroup to one window (10 of 16 tile rows used) and streams 1.3 MB of fp32 weights per
 // window from L2; beyond ~1300 windows the narrow layers therefore ran as ~12 batched bf16 GEMM launches of 7-27 us plus the
-// stand-alone energy kernel per evaluation round.  Here one workgroup (8 waves) owns G = min(8, 80 / T) windows = up to 80 rows
-// = FIVE full 16-row MFMA tiles:
+// stand-alone energy kernel per evaluation round.  Here one workgroup (8 waves) owns NRT = 1 .. 5 row tiles of 16 rows =
+// G = min(8, 16 NRT / T) windows (T = 10: 1, 3, 4, 6, 8): the fewest tiles that keep the launch inside one round of two workgroups per
+// CU (tail_bf16_row_tiles; round 4: smaller workgroups use more CUs and a second workgroup on a CU fills the first one's gaps):
 //
 //   input rows (bf16 matrix, or the producer GEMM's fp32 split-K slabs: summed + bias + LeakyReLU on the way in) -> LDS (bf16)
 //   for each fused layer:  act[i+1] = lrelu(conv3(act[i]) + b)      v_mfma_f32_16x16x32_bf16, fp32 accumulate, bf16 in LDS
-//   X = act[n] (fp32) -> energy terms + dE/dX per window, one wavefront per window, fp32 (energy_pairs.h)
+//   X = act[n] (fp32) -> energy terms + dE/dX per window, fp32 (energy_pairs.h): up to three tiles the whole workgroup on the windows'
+//       (frame, joint) pairs, beyond that one wavefront per window -- the same bits either way
 //   backward-data through the same layers, LeakyReLU' from one sign bit per activation element
 //   -> gradient w.r.t. the input's pre-activation, bf16, staged through LDS and written out as whole rows.
 //
@@ -55,7 +57,7 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int WAVES = 8, THREADS = WAVES * 64;
-constexpr int NRT_MAX = 5;                     // row tiles (of 16 rows) per workgroup: 5 (8 windows of 10 frames), 4 (6) or 3 (4)
+constexpr int NRT_MAX = 5;                     // row tiles (of 16 rows) per workgroup: 1 .. 5 (1, 3, 4, 6, 8 windows of 10 frames)
 constexpr int ZERO_BYTES = 1024 + 64;          // the zero line covers the K walk of the widest layer (K = 512: 1024 bytes)
 
 __device__ __forceinline__ unsigned int pack2(float lo, float hi) {      // round-to-nearest-even (v_cvt_pk_bf16_f32)
@@ -263,9 +265,8 @@ __device__ __forceinline__ void stage_input(const StageIn si, unsigned char* lds
 // otherwise for one (launches of at most one workgroup per CU, where nothing but the wave's own run-ahead covers a latency: ring of
 // six, double-buffered activation fragments).  Same LDS plan, same arithmetic in the same order: bitwise the same results.
 // PROBE: per-phase timestamps of workgroup 0 into a.dbg_ts (tools/tail16_bench); the product launches the probe-free instances.
-// NRT: row tiles per workgroup (5 / 4 / 3 = 8 / 6 / 4 windows of 10 frames): launches that would leave CUs idle with 8 windows per
-// workgroup take fewer windows per workgroup -- 1536 windows are 192 workgroups of 8 (a quarter of the chip idle, five tiles
-// each) or 256 of 6 (every CU, four tiles each).
+// NRT: row tiles per workgroup (1 .. 5 = 1, 3, 4, 6, 8 windows of 10 frames): see tail_bf16_row_tiles -- 1536 windows are 192
+// workgroups of 8 (a quarter of the chip idle), 256 of 6 (every CU) or 512 of 3 (two per CU: the fastest).
 template <bool DENSE, int NRT, bool PROBE>
 __global__ __launch_bounds__(THREADS, DENSE ? 4 : 2) void decoder_tail_bf16_kernel(TailB16Args a) {
     constexpr int RING = DENSE ? 3 : 6, AFD = DENSE ? 1 : 2;
