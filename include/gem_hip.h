@@ -91,7 +91,7 @@ void gem_destroy(gem_handle* h);
  * device with the matrix-bound kernels of the other (windows are independent: optimizer.py:370).  Results are bitwise those of
  * one lane wherever no product is cut along K (any threshold >= 4352 windows guarantees it); outputs, statistics and
  * gem_read_trace are assembled in window order.  0 = always one lane = the DEFAULT since round 4: the bf16 tail now keeps two
- * workgroups per CU busy by itself and one lane measures faster (8192 windows: 264 k vs 256 k windows/s); the call stays for
+ * workgroups per CU busy by itself and one lane measures faster (8192 windows: 289 k vs 247-259 k windows/s); the call stays for
  * devices / batch shapes where the split pays.  Costs a second workspace (half the size of the first) when switched on. */
 int gem_set_lanes(gem_handle* h, int min_windows);
 
@@ -100,9 +100,9 @@ int gem_set_lanes(gem_handle* h, int min_windows);
  *   1 = "bf16x3": operands of the wide products split into bf16 hi+lo, three bf16 MFMAs per product, fp32 accumulate
  *       (error ~2^-16 relative, i.e. fp32-grade, at ~1.5x the fp32 rate); the narrow tail layers stay fp32;
  *   2 = bf16 operands, fp32 accumulate (BASELINE configs[2..4] "bf16 VAE decoder / fp32 energy"): the wide products always; the
- *       narrow tail layers too from 256 windows per call on (csrc/tail_bf16.hip: bf16 weights and bf16 activations between the
- *       layers; below 256 windows the fp32 one-window tail runs them).  A window's bf16 result therefore depends on which side of
- *       that threshold its batch falls; either way it is the fp32 result plus zero-mean noise of the order of 2^-9 per decoded
+ *       narrow tail layers too, at every batch size (csrc/tail_bf16.hip: bf16 weights and bf16 activations between the layers;
+ *       1..8 windows per workgroup, chosen from the batch size, every choice bitwise the same -- so a window's bf16 result does
+ *       not depend on the size of the batch it arrives in).  It is the fp32 result plus zero-mean noise of the order of 2^-9 per decoded
  *       coordinate (tests/test_hip_full_size.py::test_bf16_on_fitted_vae_against_the_oracle: ~1.3 mm per window on fitted
  *       weights, 0.06 mm on a sequence's MPJPE).
  * May be switched at any time between calls. */
