@@ -28,8 +28,10 @@ e0.record()
 for _ in range(steps):
     tr.step(data, 0.01, eps=eps, sync=False, keep_gradients=keep)
 e1.record()
+enq = (time.perf_counter() - t0) / steps          # host time to enqueue a step (no wait for the device)
 torch.cuda.synchronize()
 wall = (time.perf_counter() - t0) / steps
 ms = e0.elapsed_time(e1) / steps
-print("B=%d (%s): %.3f ms/step on the device (%.3f ms wall), %.0f windows/s, %d parameters" % (B, "gradients kept" if keep else "training-loop mode", ms, wall * 1e3, B / (ms * 1e-3), tr.n_params))
+print("B=%d (%s): %.3f ms/step on the device (%.3f ms wall, %.3f ms host enqueue), %.0f windows/s, %d parameters"
+      % (B, "gradients kept" if keep else "training-loop mode", ms, wall * 1e3, enq * 1e3, B / (ms * 1e-3), tr.n_params))
 tr.close()
