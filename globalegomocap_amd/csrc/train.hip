@@ -65,6 +65,7 @@ struct gem_trainer {
     float *pose_p = nullptr, *mulv = nullptr, *z = nullptr, *h0 = nullptr, *Xp = nullptr;
     float *gA = nullptr, *gB = nullptr, *dmulv = nullptr, *dz = nullptr;
     float *dYT = nullptr, *lin_slab = nullptr; int lin_slab_cap = 8;      // linear_bwd_data: transposed gradient [N][pad64(B)], K-slabs of dX
+    float* dx_slab = nullptr; int dx_slab_cap = 64;                       // linear_fused_backward: one [64][K] slab of dX per strip of n tiles
     double* bn_part = nullptr; int bn_nrb_cap = 0;      // large-batch BatchNorm (bnl_*_kernel): [nrb][N][3] partial sums
     double* red = nullptr;         // [8 + partial sums]: [4..6] loss, recon, kld; [8..) per-block partials of the two loss kernels
     gem::AdjDesc* adj_tab = nullptr; int n_adj = 0, adj_tiles = 0;
@@ -467,6 +468,163 @@ __global__ __launch_bounds__(256) void gemm_tn_adam_kernel(const float* __restri
         *reinterpret_cast<f32x4*>(M2 + i) = vo;
     }
 }
+// ---- a linear layer's WHOLE backward at batches of at most 64 windows: weight gradient + Adam step + backward-data product -----
+// gemm_tn_adam_kernel reads every weight once (with its moments); the layer's backward-data product dX[b][k] = sum_n dY[b][n] W[n][k]
+// read all of them once more (linear_bwd_data: 84 / 42 MB per layer and step) plus a transposed copy of dY.  Here a workgroup owns
+// one 64-wide k tile and a STRIP of `tps` 64-wide n tiles; it walks the strip, and while a tile's parameters sit in registers for
+// their Adam step they also pass through LDS as the B operand of the tile's share of dX, which accumulates in registers across the
+// strip and leaves as one slab per strip (summed in strip order by slab_sum_kernel).  The next tile's parameters and dY tile (and the
+// current tile's moments) are requested before the current tile's products, unconditionally (a clamped index on the last tile: loads behind a branch
+// would turn every later wait into a full drain).  The weight-gradient products and the Adam arithmetic are gemm_tn_adam_kernel's,
+// in the same order: parameters and moments after the step are bitwise the same.  dX is formed from the weights BEFORE their step.
+// bias_grad: the column sums of dY (an fp64 sum of at most 64 fp32 values: exact), written by the workgroups of the first k tile.
+// Eight waves: four form the weight-gradient tile (gemm_tn_adam_kernel's quadrants), four the backward-data share, side by side on
+// the matrix pipes; all 512 threads then take 8 parameters each through the Adam step.
+constexpr int DX_THREADS = 512;
+__global__ __launch_bounds__(DX_THREADS, 4) void gemm_tn_adam_dx_kernel(const float* __restrict__ dC, const float* __restrict__ A, int rows, int N, int K,
+                                                                        int tps, float* __restrict__ P, float* __restrict__ M1, float* __restrict__ M2,
+                                                                        AdamScalars ad, float* __restrict__ dx_slab, float* __restrict__ bias_grad) {
+    __shared__ __attribute__((aligned(16))) float smem[3 * 64 * 68];
+    float (*As)[68] = reinterpret_cast<float (*)[68]>(smem);                   // the layer's input, rows b (zero beyond `rows`), this k tile
+    float (*Cs)[68] = reinterpret_cast<float (*)[68]>(smem + 64 * 68);         // dY, rows b, the current n tile
+    float (*Ws)[68] = reinterpret_cast<float (*)[68]>(smem + 2 * 64 * 68);     // the current weight tile [n][k]; then the gradient tile
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nkt = K / 64;
+    const int strip = blockIdx.x / nkt, kt = blockIdx.x - strip * nkt;
+    const int k0 = kt * 64, nt_begin = strip * tps, nt_last = nt_begin + tps - 1;
+    const bool dx_wave = wave >= 4;
+    const int wm = (wave & 3) >> 1, wn = wave & 1;
+    const int fi = lane & 15, fq = lane >> 4;
+    const int lr = tid >> 4, lc4 = (tid & 15) * 4;          // this thread's rows lr + 32 q, columns lc4 .. lc4 + 3 of a 64 x 64 tile
+    auto load_p = [&](f32x4 (&r)[2], int nt) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) r[q] = *reinterpret_cast<const f32x4*>(P + (size_t)(nt * 64 + q * 32 + lr) * K + k0 + lc4);
+    };
+    auto load_c = [&](f32x4 (&vc)[2], int nt) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int b = min(q * 32 + lr, rows - 1);          // (rows beyond the batch: loaded, zeroed on the way into LDS)
+            vc[q] = *reinterpret_cast<const f32x4*>(dC + (size_t)b * N + nt * 64 + lc4);
+        }
+    };
+    f32x4 r0[2], r1[2], c0[2], c1[2];
+    load_p(r0, nt_begin);
+    load_c(c0, nt_begin);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int b = q * 32 + lr;
+        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (b < rows) a = *reinterpret_cast<const f32x4*>(A + (size_t)b * K + k0 + lc4);
+        *reinterpret_cast<f32x4*>(&As[b][lc4]) = a;
+    }
+    f32x4 accx[2][2];          // (the backward-data waves' accumulators, kept across the strip)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) accx[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto tile = [&](int nt, const f32x4 (&cur)[2], const f32x4 (&ccur)[2], f32x4 (&nxt)[2], f32x4 (&cnxt)[2]) {
+        __syncthreads();          // the previous tile's Adam phase has read the gradient tile (Ws); first tile: nothing pending
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int r = q * 32 + lr;
+            *reinterpret_cast<f32x4*>(&Cs[r][lc4]) = r < rows ? ccur[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(&Ws[r][lc4]) = cur[q];
+        }
+        __syncthreads();
+        // this tile's moments (wanted at the end of the tile), the next tile's parameters and dY
+        f32x4 m4[2], v4[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const size_t i = (size_t)(nt * 64 + q * 32 + lr) * K + k0 + lc4;
+            m4[q] = *reinterpret_cast<const f32x4*>(M1 + i);
+            v4[q] = *reinterpret_cast<const f32x4*>(M2 + i);
+        }
+        const int nn = min(nt + 1, nt_last);
+        load_p(nxt, nn);
+        load_c(cnxt, nn);
+        f32x4 acc[2][2];
+        if (!dx_wave) {
+            // weight gradient of the tile: dW[n][k] = sum_b dY[b][n] A[b][k]  (gemm_tn_kernel<1>'s products, b ascending)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+            for (int kk = 0; kk < 64; kk += 4) {
+                float a[2], b[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) { a[q] = Cs[kk + fq][wm * 32 + q * 16 + fi]; b[q] = As[kk + fq][wn * 32 + q * 16 + fi]; }
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                    for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[x], b[y], acc[x][y], 0, 0, 0);
+            }
+            if (bias_grad && kt == 0 && tid < 64) {
+                double sum = 0.0;
+#pragma unroll 8
+                for (int b = 0; b < 64; ++b) sum += (double)Cs[b][tid];
+                bias_grad[nt * 64 + tid] = (float)sum;
+            }
+        } else {
+            // the tile's share of the backward-data product: dX[b][k] += sum_{n in tile} dY[b][n] W[n][k]
+#pragma unroll 4
+            for (int kk = 0; kk < 64; kk += 4) {
+                float a[2], b[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) { a[q] = Cs[wm * 32 + q * 16 + fi][kk + fq]; b[q] = Ws[kk + fq][wn * 32 + q * 16 + fi]; }
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                    for (int y = 0; y < 2; ++y) accx[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[x], b[y], accx[x][y], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        if (!dx_wave) {
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) Ws[wm * 32 + x * 16 + 4 * fq + e][wn * 32 + y * 16 + fi] = acc[x][y][e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int r = q * 32 + lr;
+            const f32x4 g4 = *reinterpret_cast<const f32x4*>(&Ws[r][lc4]);
+            f32x4 po, mo, vo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float gg = g4[e] + ad.wd * cur[q][e];
+                const float mm = ad.b1 * m4[q][e] + (1.f - ad.b1) * gg;
+                const float vv = ad.b2 * v4[q][e] + (1.f - ad.b2) * gg * gg;
+                mo[e] = mm; vo[e] = vv;
+                po[e] = cur[q][e] - ad.lr_bc1 * mm / (sqrtf(vv) / ad.bc2_sqrt + ad.eps);
+            }
+            const size_t i = (size_t)(nt * 64 + r) * K + k0 + lc4;
+            *reinterpret_cast<f32x4*>(P + i) = po;
+            *reinterpret_cast<f32x4*>(M1 + i) = mo;
+            *reinterpret_cast<f32x4*>(M2 + i) = vo;
+        }
+    };
+    for (int nt = nt_begin; nt < nt_begin + tps; nt += 2) {          // (tps is even: the two register sets swap roles)
+        tile(nt, r0, c0, r1, c1);
+        tile(nt + 1, r1, c1, r0, c0);
+    }
+    if (dx_wave) {
+        float* out = dx_slab + (size_t)strip * 64 * K;
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int b = wm * 32 + x * 16 + 4 * fq + e, k = k0 + wn * 32 + y * 16 + fi;
+                    out[(size_t)b * K + k] = accx[x][y][e];
+                }
+    }
+}
 // G = sum over slabs, in slab order; blockIdx.y = layer (table), blockIdx.x = 1024-element chunk
 __global__ __launch_bounds__(256) void slab_sum_all_kernel(const SumDesc* __restrict__ tab, int nslab) {
     const SumDesc d = tab[blockIdx.y];
@@ -675,6 +833,36 @@ static int linear_bwd_data(gem_trainer* t, const float* dY, const float* W, floa
     return 0;
 }
 
+// Strip length (n tiles per workgroup) of gemm_tn_adam_dx_kernel; 0 = the layer / batch does not fit the kernel (more than 64
+// windows, an odd number of n tiles, more strips than slabs): the separate kernels run.
+static int fused_backward_strip(const gem_trainer* t, const TrainLinear& l, int B) {
+    if (B > 64 || dev_env("GEM_TRAIN_NO_FUSED_DX")) return 0;
+    const int nt = l.N / 64, nkt = l.K / 64;
+    if (const char* f = dev_env("GEM_TRAIN_TPS")) { const char* c = strchr(f, ','); const int tps = (&l == &t->dec_in && c) ? atoi(c + 1) : atoi(f); return (tps >= 2 && tps % 2 == 0 && nt % tps == 0 && nt / tps <= t->dx_slab_cap) ? tps : 0; }
+    // The kernel is bound by what one CU gets through (two products and the Adam arithmetic per tile), not by HBM: the strip length that
+    // leaves every CU the same number of tiles wins -- tiles per CU = ceil(workgroups / CUs) x tps (reference VAE on 256 CUs:
+    // fc 80 k tiles x 16 strips of 4 = 1280 workgroups, decoder_input 32 x 8 strips of 10 = 256; measured 0.721 ms per step
+    // against 0.731-0.770 for the other divisors); ties go to the longer strip (fewer dX slabs).
+    int best = 0; long best_cost = 0;
+    for (int tps = 2; tps <= nt; tps += 2) {
+        if (nt % tps || nt / tps > t->dx_slab_cap) continue;
+        const long wgs = (long)nkt * (nt / tps), cost = (wgs + t->h->n_cu - 1) / t->h->n_cu * tps;
+        if (best == 0 || cost <= best_cost) { best = tps; best_cost = cost; }
+    }
+    return best;
+}
+static int linear_fused_backward(gem_trainer* t, const TrainLinear& l, int tps, const float* dY, const float* A, float* dX, int B, const AdamScalars& ad,
+                                 hipStream_t s) {
+    const int nstrip = l.N / 64 / tps;
+    hipLaunchKernelGGL(gemm_tn_adam_dx_kernel, dim3((l.K / 64) * nstrip), dim3(DX_THREADS), 0, s, dY, A, B, l.N, l.K, tps, t->P + l.ow, t->M1 + l.ow, t->M2 + l.ow, ad,
+                       t->dx_slab, t->G + l.ob);
+    GEM_HIP(hipGetLastError());
+    const size_t n_out = (size_t)B * l.K;
+    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((n_out / 4 + 255) / 256)), dim3(256), 0, s, (const float*)t->dx_slab, nstrip, (size_t)64 * l.K, dX, n_out);
+    GEM_HIP(hipGetLastError());
+    return 0;
+}
+
 }  // namespace gem
 
 using namespace gem;
@@ -748,6 +936,7 @@ int gem_trainer_create(const gem_config* cfg, gem_trainer** out) {
         talloc(p, &p->dmulv, (size_t)p->Bmax * 2 * p->Dp) || talloc(p, &p->dz, (size_t)p->Bmax * p->Dp) ||
         talloc(p, &p->dYT, (size_t)std::max(p->fc.N, p->dec_in.N) * pad64(p->Bmax)) ||
         talloc(p, &p->lin_slab, (size_t)p->lin_slab_cap * pad64(p->Bmax) * std::max(p->fc.K, p->dec_in.K)) ||
+        talloc(p, &p->dx_slab, (size_t)p->dx_slab_cap * 64 * std::max(p->fc.K, p->dec_in.K)) ||
         talloc(p, &p->red, (size_t)8 + p->part_recon + p->part_latent))
         return 1;
     *out = t.release();
@@ -901,9 +1090,13 @@ int gem_trainer_step(gem_trainer* t, int B, const float* d_pose, const float* d_
     }
     // g = dh0 [B, T*topp]: decoder_input
     { const TrainLinear& l = t->dec_in;
-      if (!fused && weight_grad<1>(t, g, l.N, t->z, l.K, B, l.N, l.K, l.ow, l.slab, TN_ROWS_LINEAR, s)) return 1;
-      if (linear_bwd_data(t, g, t->P + l.ow, t->dz, B, l.N, l.K, s, t->G + l.ob)) return 1;
-      if (fused && linear_step(l, g, t->z)) return 1; }          // (behind the backward-data product: it reads the weights)
+      const int tps = fused ? fused_backward_strip(t, l, B) : 0;
+      if (tps) { if (linear_fused_backward(t, l, tps, g, t->z, t->dz, B, ad, s)) return 1; }
+      else {
+          if (!fused && weight_grad<1>(t, g, l.N, t->z, l.K, B, l.N, l.K, l.ow, l.slab, TN_ROWS_LINEAR, s)) return 1;
+          if (linear_bwd_data(t, g, t->P + l.ow, t->dz, B, l.N, l.K, s, t->G + l.ob)) return 1;
+          if (fused && linear_step(l, g, t->z)) return 1;          // (behind the backward-data product: it reads the weights)
+      } }
     hipLaunchKernelGGL(latent_bwd_kernel, dim3(n_pl), dim3(LOSS_BLOCK), 0, s, (const float*)t->mulv, d_eps, (const float*)t->dz, B, t->D, t->Dp,
                        (float)(o->kld_weight / B), t->dmulv, part_latent);
     GEM_HIP(hipGetLastError());
@@ -913,10 +1106,14 @@ int gem_trainer_step(gem_trainer* t, int B, const float* d_pose, const float* d_
     // fc_mu | fc_var
     { const TrainLinear& l = t->fc;
       const float* flat = t->enc.back().out;
-      if (!fused && weight_grad<1>(t, t->dmulv, l.N, flat, l.K, B, l.N, l.K, l.ow, l.slab, TN_ROWS_LINEAR, s)) return 1;
       g = t->gA; g2 = t->gB;
-      if (linear_bwd_data(t, t->dmulv, t->P + l.ow, g, B, l.N, l.K, s, t->G + l.ob)) return 1;
-      if (fused && linear_step(l, t->dmulv, flat)) return 1; }
+      const int tps = fused ? fused_backward_strip(t, l, B) : 0;
+      if (tps) { if (linear_fused_backward(t, l, tps, t->dmulv, flat, g, B, ad, s)) return 1; }
+      else {
+          if (!fused && weight_grad<1>(t, t->dmulv, l.N, flat, l.K, B, l.N, l.K, l.ow, l.slab, TN_ROWS_LINEAR, s)) return 1;
+          if (linear_bwd_data(t, t->dmulv, t->P + l.ow, g, B, l.N, l.K, s, t->G + l.ob)) return 1;
+          if (fused && linear_step(l, t->dmulv, flat)) return 1;
+      } }
     // encoder
     for (int i = (int)t->enc.size() - 1; i >= 0; --i) {
         TrainConv& c = t->enc[i];

@@ -339,39 +339,52 @@ def test_device_fit_reaches_the_accuracy_of_the_autograd_fit():
     assert e_d < 1.5 * e_t + 2e-3 and e_d < 0.03, (e_d, e_t)
 
 
-def test_training_loop_mode_steps_like_the_default_mode():
+@pytest.mark.parametrize("adam_eps", [1e-8, 1e-6])
+def test_training_loop_mode_steps_like_the_default_mode(adam_eps):
     """gem_trainer_step update = 2 (the linear layers' weight gradient formed inside their Adam step, never written to the gradient
-    arena) against update = 1 on the same batches at full size: losses, parameters, both Adam moments, running statistics."""
+    arena; at this batch their backward-data products too: gemm_tn_adam_dx_kernel) against update = 1 on the same batches at full size.
+
+    The two modes sum the backward-data products in a different order (strips of n tiles against slabs), so their gradients differ in
+    the last bits.  With the reference's eps = 1e-8 Adam turns such bits into parameter differences: an entry whose gradient is of the
+    order of eps (8 % of the fc weights at the first step) moves by lr g / (|g| + eps), and rounding noise is percent-level relative to
+    such a g.  Hence two runs: eps = 1e-8 pins the FUNCTION (losses of three successive steps; the first step's gradients, which have
+    passed through both backward-data products, to 1e-5), eps = 1e-6 -- the amplification switched off -- pins parameters, moments and
+    running statistics after three steps as tightly as when the modes shared their backward-data kernels."""
     from globalegomocap_amd.vae_train import VAETrainer, initial_state_dict
     B = 64
     init = initial_state_dict(FULL, 5)
     poses = synth.make_training_windows(3 * B, FULL.seq_len, 4).reshape(3, B, FULL.seq_len, 45)
     eps = np.random.default_rng(3).standard_normal((3, B, FULL.latent_dim)).astype(np.float32)
-    a = VAETrainer(FULL, batch_size=B, lr=1e-3, weight_decay=1e-5, state_dict=init)
-    b = VAETrainer(FULL, batch_size=B, lr=1e-3, weight_decay=1e-5, state_dict=init)
+    a = VAETrainer(FULL, batch_size=B, lr=1e-3, weight_decay=1e-5, eps=adam_eps, state_dict=init)
+    b = VAETrainer(FULL, batch_size=B, lr=1e-3, weight_decay=1e-5, eps=adam_eps, state_dict=init)
+    amplified = adam_eps < 1e-7
     try:
         for s in range(3):
             la = a.step(poses[s], 0.01, eps=eps[s])
             lb = b.step(poses[s], 0.01, eps=eps[s], keep_gradients=False)
-            np.testing.assert_allclose(lb, la, rtol=1e-6)
+            # (first step: the same forward on the same parameters; eps = 1e-8, third step: measured 7e-5 -- the gate is twice the one
+            # the device step is held to against the CPU port over successive steps)
+            np.testing.assert_allclose(lb, la, rtol=1e-7 if s == 0 else 2e-4 if amplified else 1e-6)
+            if s == 0:
+                ga, gb = a.gradients(), b.gradients()
+                for k in ga:
+                    if k.endswith(".0.bias") or k.split(".")[0] in ("fc_mu", "fc_var", "decoder_input") and k.endswith("weight"):
+                        continue          # (rounding noise around an exact zero; not left in the arena by this mode)
+                    assert np.abs(ga[k] - gb[k]).max() <= 1e-5 * np.abs(ga[k]).max(), k
+        assert a.steps == b.steps == 3
+        if amplified:
+            return
         from globalegomocap_amd.vae_train import unpack_arena
         for what in (0, 3, 4):
             ua, ub = unpack_arena(a._down(what), FULL), unpack_arena(b._down(what), FULL)
             for k in ua:
-                # (".0.bias": a conv bias in front of a BatchNorm -- its exact gradient is zero, both runs hold rounding noise, and
-                # Adam moves such an entry by ~lr in the direction of the noise's sign; the fused kernel contracts g + wd * p into
-                # one fma, one rounding less than the two-kernel path, which is enough to flip such signs after the first step)
+                # (".0.bias": a conv bias in front of a BatchNorm -- its exact gradient is zero, both runs hold rounding noise there)
                 if k.endswith(".0.bias"):
                     continue
                 x, y = np.asarray(ua[k], np.float64), np.asarray(ub[k], np.float64)
-                # (moments: moving averages of gradients that, from the second step on, are taken at parameters ~lr apart in the noise entries)
                 assert np.linalg.norm(x - y) <= (1e-3 if what == 0 else 5e-3) * max(1e-30, np.linalg.norm(x)), (what, k)
         sa, sb = a._down(2).astype(np.float64), b._down(2).astype(np.float64)
         assert np.abs(sa - sb).max() <= 1e-3 * np.abs(sa).max()
-        # (what the two modes agree on to rounding is the FUNCTION: the losses of three successive steps above, to 1e-6; single
-        # gradient entries of this network carry ~1e-3 of rounding noise -- see test_full_size_training_step_against_the_port --
-        # which is what separates the moments here after the first step's 1-ulp differences)
-        assert a.steps == b.steps == 3
     finally:
         a.close(); b.close()
 
