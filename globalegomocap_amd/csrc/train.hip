@@ -22,6 +22,7 @@
 #include <memory>
 
 #include "gem_internal.h"
+#include "conv_rows.h"
 
 namespace gem {
 
@@ -306,6 +307,10 @@ __global__ __launch_bounds__(BN_THREADS) void colsum_kernel(const float* __restr
     bn_reduce<1>(v, sh);
     if (g == 0) out[c] = (float)v[0];
 }
+
+constexpr int CONV_ROWS_MAX = 1024;          // rows up to which conv_rows_kernel runs the training step's convs (beyond: launch_gemm)
+// 0 = launched; 1 = error; -1 = not applicable (the caller falls back to launch_gemm)
+static int conv_rows(gem_trainer* t, const float* W, const float* bias, const float* A, int lda, float* C, int ldc, int rows, int N, int K, hipStream_t s);
 
 // ---- weight gradient: dW[tap][n][k] = sum_r dC[r][n] * A[r + tap - 1][k], slab z = rows [z * rps, (z + 1) * rps) --------------
 template <int TAPS>
@@ -786,6 +791,33 @@ static int weight_grad(gem_trainer* t, const float* dC, int ldc, const float* A,
     return 0;
 }
 
+template <int KW, int D>
+static int launch_conv_rows(const dim3& grid, const float* W, const float* bias, const float* A, int lda, float* C, int ldc, int rows, int N, int K, int T,
+                            hipStream_t s) {
+    auto k = conv_rows_lds_kernel<KW, D>;
+    constexpr size_t smem = (size_t)KW * D * 8192;
+    static bool attr_set = false;          // (the trainer is driven from one host thread)
+    if (smem > 64 * 1024 && !attr_set) {
+        GEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k, grid, dim3(64 * KW), smem, s, A, lda, W, bias, C, ldc, rows, N, K, T);
+    GEM_HIP(hipGetLastError());
+    return 0;
+}
+static int conv_rows(gem_trainer* t, const float* W, const float* bias, const float* A, int lda, float* C, int ldc, int rows, int N, int K, hipStream_t s) {
+    static const int rows_max = dev_env("GEM_CONV_ROWS_MAX") ? atoi(dev_env("GEM_CONV_ROWS_MAX")) : CONV_ROWS_MAX;
+    if (rows > rows_max || K % 64 || N % 32 || dev_env("GEM_TRAIN_NO_CONV_ROWS")) return -1;
+    const dim3 grid((rows + 31) / 32, N / 32);
+    // waves per workgroup = K cuts of whole 32-wide chunks (K = 64: two waves, 128: four); eight waves when the tiles alone
+    // do not fill the chip.  One ring slot per wave (the refill of the slot just read runs under the sixteen MFMAs: a second slot
+    // measured the same).  tools/conv_rows_bench: 4.8 us (K <= 128), 7 (N 128, K 256),
+    // 11 (N 512, K 256 and N 256, K 512) at 640 rows, against 9 + 4.5 and 13.5 + 4.9 for the tiled kernel and its split-K reduce
+    if (K % 256 == 0 && (long)grid.x * grid.y <= t->h->n_cu) return launch_conv_rows<8, 1>(grid, W, bias, A, lda, C, ldc, rows, N, K, t->T, s);
+    if (K % 128 == 0) return launch_conv_rows<4, 1>(grid, W, bias, A, lda, C, ldc, rows, N, K, t->T, s);
+    return launch_conv_rows<2, 1>(grid, W, bias, A, lda, C, ldc, rows, N, K, t->T, s);
+}
+
 // A linear layer over B rows (64 at the reference's batch): pure weight streaming.  The few-rows kernel (gemm_rows.h) fills the chip
 // at so few rows only when it may cut K; letting it "defer" the reduction gives it that freedom, and the slabs are summed (+ bias)
 // right behind it.
@@ -1019,7 +1051,8 @@ int gem_trainer_step(gem_trainer* t, int B, const float* d_pose, const float* d_
     if (launch_pack_pose(d_pose, t->pose_p, rows, t->C, s)) return 1;
     auto conv_fwd = [&](TrainConv& c, const float* in) -> int {
         Layer L; L.taps = 3; L.K = c.K; L.N = c.N; L.w = t->P + c.ow; L.bias = t->P + c.ob;
-        if (launch_gemm(h, L, EPI_BIAS, in, c.K, nullptr, c.bn ? c.Y : c.out, c.N, rows, T, s, -1)) return 1;
+        { const int rc = conv_rows(t, L.w, L.bias, in, c.K, c.bn ? c.Y : c.out, c.N, rows, c.N, c.K, s);
+          if (rc > 0 || (rc < 0 && launch_gemm(h, L, EPI_BIAS, in, c.K, nullptr, c.bn ? c.Y : c.out, c.N, rows, T, s, -1))) return 1; }
         if (c.bn) {
             if (rows <= BN_REGS * BN_GROUPS) {
                 hipLaunchKernelGGL(bn_train_fwd_kernel, dim3(c.N / 16), dim3(BN_THREADS), 0, s, (const float*)c.Y, rows, c.N, (const float*)(t->P + c.og),
@@ -1085,7 +1118,8 @@ int gem_trainer_step(gem_trainer* t, int B, const float* d_pose, const float* d_
         if (weight_grad<3>(t, dY, c.N, a_in, c.K, rows, c.N, c.K, c.ow, c.slab, conv_slab_rows(rows), s)) return 1;
         Layer L; L.taps = 3; L.K = c.N; L.N = c.K; L.w = c.adj; L.bias = nullptr;
         float* dA = (dY == g) ? g2 : g;          // the buffer that does not hold dY
-        if (launch_gemm(h, L, EPI_NONE, dY, c.N, nullptr, dA, c.K, rows, T, s, -1)) return 1;
+        { const int rc = conv_rows(t, L.w, nullptr, dY, c.N, dA, c.K, rows, c.K, c.N, s);
+          if (rc > 0 || (rc < 0 && launch_gemm(h, L, EPI_NONE, dY, c.N, nullptr, dA, c.K, rows, T, s, -1))) return 1; }
         if (dA != g) { float* tmp = g; g = dA; g2 = tmp; }
     }
     // g = dh0 [B, T*topp]: decoder_input
@@ -1122,7 +1156,8 @@ int gem_trainer_step(gem_trainer* t, int B, const float* d_pose, const float* d_
         if (weight_grad<3>(t, g2, c.N, a_in, c.K, rows, c.N, c.K, c.ow, c.slab, conv_slab_rows(rows), s)) return 1;
         if (i > 0) {
             Layer L; L.taps = 3; L.K = c.N; L.N = c.K; L.w = c.adj; L.bias = nullptr;
-            if (launch_gemm(h, L, EPI_NONE, g2, c.N, nullptr, g, c.K, rows, T, s, -1)) return 1;
+            { const int rc = conv_rows(t, L.w, nullptr, g2, c.N, g, c.K, rows, c.K, c.N, s);
+              if (rc > 0 || (rc < 0 && launch_gemm(h, L, EPI_NONE, g2, c.N, nullptr, g, c.K, rows, T, s, -1))) return 1; }
         }
     }
     // the weight-gradient slabs -> the gradient arena (slab order: deterministic)

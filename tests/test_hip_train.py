@@ -345,46 +345,45 @@ def test_training_loop_mode_steps_like_the_default_mode(adam_eps):
     arena; at this batch their backward-data products too: gemm_tn_adam_dx_kernel) against update = 1 on the same batches at full size.
 
     The two modes sum the backward-data products in a different order (strips of n tiles against slabs), so their gradients differ in
-    the last bits.  With the reference's eps = 1e-8 Adam turns such bits into parameter differences: an entry whose gradient is of the
-    order of eps (8 % of the fc weights at the first step) moves by lr g / (|g| + eps), and rounding noise is percent-level relative to
-    such a g.  Hence two runs: eps = 1e-8 pins the FUNCTION (losses of three successive steps; the first step's gradients, which have
-    passed through both backward-data products, to 1e-5), eps = 1e-6 -- the amplification switched off -- pins parameters, moments and
-    running statistics after three steps as tightly as when the modes shared their backward-data kernels."""
-    from globalegomocap_amd.vae_train import VAETrainer, initial_state_dict
+    the last bits, and what becomes of such bits is a property of the optimiser, not of the kernels (each mode by itself is bitwise
+    reproducible: tools/train_dbg.py same / same2).  With the reference's eps = 1e-8 Adam's first step moves an entry whose gradient is
+    of the order of eps (8 % of the fc weights) by lr g / (|g| + eps), and rounding noise is percent-level relative to such a g.  So:
+    the first step's gradients (they have passed through both backward-data products) to 1e-5 of each tensor's maximum; with eps = 1e-6
+    -- that amplification switched off -- parameters, moments and running statistics after the FIRST update as tightly as when the modes
+    shared their backward-data kernels; and the losses of three successive steps at the gate the device step is held to against the CPU
+    port over successive steps (trajectories separate from the third step on: measured 7e-5 / 8e-6 for eps = 1e-8 / 1e-6)."""
+    from globalegomocap_amd.vae_train import VAETrainer, initial_state_dict, unpack_arena
     B = 64
     init = initial_state_dict(FULL, 5)
     poses = synth.make_training_windows(3 * B, FULL.seq_len, 4).reshape(3, B, FULL.seq_len, 45)
     eps = np.random.default_rng(3).standard_normal((3, B, FULL.latent_dim)).astype(np.float32)
     a = VAETrainer(FULL, batch_size=B, lr=1e-3, weight_decay=1e-5, eps=adam_eps, state_dict=init)
     b = VAETrainer(FULL, batch_size=B, lr=1e-3, weight_decay=1e-5, eps=adam_eps, state_dict=init)
-    amplified = adam_eps < 1e-7
     try:
         for s in range(3):
             la = a.step(poses[s], 0.01, eps=eps[s])
             lb = b.step(poses[s], 0.01, eps=eps[s], keep_gradients=False)
-            # (first step: the same forward on the same parameters; eps = 1e-8, third step: measured 7e-5 -- the gate is twice the one
-            # the device step is held to against the CPU port over successive steps)
-            np.testing.assert_allclose(lb, la, rtol=1e-7 if s == 0 else 2e-4 if amplified else 1e-6)
-            if s == 0:
-                ga, gb = a.gradients(), b.gradients()
-                for k in ga:
-                    if k.endswith(".0.bias") or k.split(".")[0] in ("fc_mu", "fc_var", "decoder_input") and k.endswith("weight"):
-                        continue          # (rounding noise around an exact zero; not left in the arena by this mode)
-                    assert np.abs(ga[k] - gb[k]).max() <= 1e-5 * np.abs(ga[k]).max(), k
+            np.testing.assert_allclose(lb, la, rtol=1e-7 if s == 0 else 2e-4)          # (first step: the same forward on the same parameters)
+            if s > 0:
+                continue
+            ga, gb = a.gradients(), b.gradients()
+            for k in ga:
+                if k.endswith(".0.bias") or k.split(".")[0] in ("fc_mu", "fc_var", "decoder_input") and k.endswith("weight"):
+                    continue          # (rounding noise around an exact zero; not left in the arena by this mode)
+                assert np.abs(ga[k] - gb[k]).max() <= 1e-5 * np.abs(ga[k]).max(), k
+            if adam_eps < 1e-7:
+                continue
+            for what in (0, 3, 4):
+                ua, ub = unpack_arena(a._down(what), FULL), unpack_arena(b._down(what), FULL)
+                for k in ua:
+                    # (".0.bias": a conv bias in front of a BatchNorm -- its exact gradient is zero, both runs hold rounding noise there)
+                    if k.endswith(".0.bias"):
+                        continue
+                    x, y = np.asarray(ua[k], np.float64), np.asarray(ub[k], np.float64)
+                    assert np.linalg.norm(x - y) <= (1e-5 if what == 0 else 1e-4) * max(1e-30, np.linalg.norm(x)), (what, k)
+            sa, sb = a._down(2).astype(np.float64), b._down(2).astype(np.float64)
+            assert np.abs(sa - sb).max() <= 1e-6 * np.abs(sa).max()
         assert a.steps == b.steps == 3
-        if amplified:
-            return
-        from globalegomocap_amd.vae_train import unpack_arena
-        for what in (0, 3, 4):
-            ua, ub = unpack_arena(a._down(what), FULL), unpack_arena(b._down(what), FULL)
-            for k in ua:
-                # (".0.bias": a conv bias in front of a BatchNorm -- its exact gradient is zero, both runs hold rounding noise there)
-                if k.endswith(".0.bias"):
-                    continue
-                x, y = np.asarray(ua[k], np.float64), np.asarray(ub[k], np.float64)
-                assert np.linalg.norm(x - y) <= (1e-3 if what == 0 else 5e-3) * max(1e-30, np.linalg.norm(x)), (what, k)
-        sa, sb = a._down(2).astype(np.float64), b._down(2).astype(np.float64)
-        assert np.abs(sa - sb).max() <= 1e-3 * np.abs(sa).max()
     finally:
         a.close(); b.close()
 

@@ -22,8 +22,9 @@ if mode == "noisy":          # the same mode twice, the second from parameters o
 a = VAETrainer(FULL, batch_size=B, lr=1e-3, weight_decay=1e-5, eps=adam_eps, state_dict=init)
 b = VAETrainer(FULL, batch_size=B, lr=1e-3, weight_decay=1e-5, eps=adam_eps, state_dict=init_b)
 for s in range(3):
-    la = a.step(poses[s], 0.01, eps=eps[s])
-    lb = b.step(poses[s], 0.01, eps=eps[s], keep_gradients=(mode == "noisy"))
+    la = a.step(poses[s], 0.01, eps=eps[s], keep_gradients=(mode != "same2"))
+    la2 = None
+    lb = b.step(poses[s], 0.01, eps=eps[s], keep_gradients=(mode in ("noisy", "same")))
     print("step", s, "losses rel diff", [abs(x - y) / abs(x) for x, y in zip(la, lb)])
 for what in (0, 3, 4):
     ua, ub = unpack_arena(a._down(what), FULL), unpack_arena(b._down(what), FULL)
