@@ -35,6 +35,8 @@ struct TrainConv {
     size_t os = 0;                 // statistics arena: running_mean [N], running_var [N]
     float *Y = nullptr, *out = nullptr, *mean = nullptr, *invstd = nullptr;
     float *adj = nullptr, *slab = nullptr;      // adjoint image [3][K][N]; weight-gradient slabs [nslab][3][N][K]
+    float* dY = nullptr;           // BatchNorm layers: gradient w.r.t. the conv's own output [rows][N], kept until the step's ONE
+                                   // weight-gradient launch (gemm_tn3_all_kernel) has read it
 };
 struct TrainLinear {
     int K = 0, N = 0;
@@ -71,6 +73,7 @@ struct gem_trainer {
     double* red = nullptr;         // [8 + partial sums]: [4..6] loss, recon, kld; [8..) per-block partials of the two loss kernels
     gem::AdjDesc* adj_tab = nullptr; int n_adj = 0, adj_tiles = 0;
     gem::SumDesc* sum_tab = nullptr; int n_sum = 0; size_t sum_max = 0;
+    void* tn_tab = nullptr; int n_tn = 0, tn_tiles = 0;      // gemm_tn3_all_kernel's layer table (TnDesc)
     int part_recon = 0, part_latent = 0;       // capacity of the partial-sum regions
     long step = 0;
     std::vector<void*> allocs;
@@ -314,13 +317,12 @@ static int conv_rows(gem_trainer* t, const float* W, const float* bias, const fl
 
 // ---- weight gradient: dW[tap][n][k] = sum_r dC[r][n] * A[r + tap - 1][k], slab z = rows [z * rps, (z + 1) * rps) --------------
 template <int TAPS>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ dC, int ldc, const float* __restrict__ A, int lda,
-                                                      float* __restrict__ slab, int rows, int N, int K, int T, int rps) {
+__device__ __forceinline__ void gemm_tn_tile(const float* __restrict__ dC, int ldc, const float* __restrict__ A, int lda, float* __restrict__ slab, int rows, int N,
+                                             int K, int T, int rps, int tile, int tap, int z) {
     __shared__ __attribute__((aligned(16))) float Cs[32][68];
     __shared__ __attribute__((aligned(16))) float As[32][68];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nt = blockIdx.x / (K / 64), kt = blockIdx.x - nt * (K / 64);
-    const int tap = blockIdx.y, z = blockIdx.z;
+    const int nt = tile / (K / 64), kt = tile - nt * (K / 64);
     const int n0 = nt * 64, k0 = kt * 64;
     const int wm = wave >> 1, wn = wave & 1;
     const int fi = lane & 15, fq = lane >> 4;
@@ -379,6 +381,21 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
                 out[(size_t)n * K + k] = acc[x][y][e];
             }
 }
+template <int TAPS>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ dC, int ldc, const float* __restrict__ A, int lda,
+                                                      float* __restrict__ slab, int rows, int N, int K, int T, int rps) {
+    gemm_tn_tile<TAPS>(dC, ldc, A, lda, slab, rows, N, K, T, rps, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+// every conv layer's weight gradient in ONE launch (they wait for nothing but their layer's dY, and nothing but Adam waits for
+// them: eleven launches of ~6 us at the reference's batch otherwise): blockIdx.x walks the layers' tiles (table), y = tap, z = slab
+struct TnDesc { const float* dC; const float* A; float* slab; float* g; int N, K, tile0; };
+__global__ __launch_bounds__(256) void gemm_tn3_all_kernel(const TnDesc* __restrict__ tab, int n_layers, int rows, int T, int rps, int nslab) {
+    int l = 0;
+    while (l + 1 < n_layers && (int)blockIdx.x >= tab[l + 1].tile0) ++l;
+    const TnDesc d = tab[l];
+    gemm_tn_tile<3>(d.dC, d.N, d.A, d.K, nslab > 1 ? d.slab : d.g, rows, d.N, d.K, T, rps, (int)blockIdx.x - d.tile0, blockIdx.y, blockIdx.z);
+}
+
 // ---- a LINEAR layer's weight gradient and its Adam step in one kernel (gem_trainer_step, update = 2) ---------------------------
 // The two linear layers hold 97 % of the parameters and their gradient has rank <= batch: dW[n][k] = sum_b dC[b][n] A[b][k] is
 // a 64 x 64 x batch product per tile -- nothing next to the 3 x 16 KB of parameter and moment traffic of the tile.  Forming it
@@ -935,6 +952,7 @@ int gem_trainer_create(const gem_config* cfg, gem_trainer** out) {
         for (auto& c : *v) {
             const size_t nw = (size_t)3 * c.N * c.K;
             if (talloc(p, &c.Y, rows * c.N) || talloc(p, &c.out, rows * c.N) || talloc(p, &c.mean, (size_t)c.N) || talloc(p, &c.invstd, (size_t)c.N)) return 1;
+            if (c.bn && talloc(p, &c.dY, rows * c.N)) return 1;
             if (&c != &p->enc.front()) {          // (nothing flows back through the first encoder conv)
                 if (talloc(p, &c.adj, nw)) return 1;
                 adj.push_back(AdjDesc{p->P + c.ow, c.adj, 3, c.N, c.K, 3 * (c.N / 64) * (c.K / 64)});
@@ -971,6 +989,19 @@ int gem_trainer_create(const gem_config* cfg, gem_trainer** out) {
         talloc(p, &p->dx_slab, (size_t)p->dx_slab_cap * 64 * std::max(p->fc.K, p->dec_in.K)) ||
         talloc(p, &p->red, (size_t)8 + p->part_recon + p->part_latent))
         return 1;
+    { std::vector<TnDesc> tn;
+      int tile0 = 0;
+      for (auto* v : {&p->enc, &p->dec})
+          for (size_t i = 0; i < v->size(); ++i) {
+              TrainConv& c = (*v)[i];
+              const float* a_in = i > 0 ? (*v)[i - 1].out : (v == &p->enc ? p->pose_p : p->h0);
+              tn.push_back(TnDesc{c.bn ? c.dY : p->gA, a_in, c.slab, p->G + c.ow, c.N, c.K, tile0});      // (no BatchNorm: the loss gradient itself, in gA)
+              tile0 += (c.N / 64) * (c.K / 64);
+          }
+      TnDesc* dev = nullptr;
+      if (talloc(p, &dev, tn.size())) return 1;
+      GEM_HIP(hipMemcpy(dev, tn.data(), tn.size() * sizeof(TnDesc), hipMemcpyHostToDevice));
+      p->tn_tab = dev; p->n_tn = (int)tn.size(); p->tn_tiles = tile0; }
     *out = t.release();
     return 0;
 }
@@ -1103,25 +1134,27 @@ int gem_trainer_step(gem_trainer* t, int B, const float* d_pose, const float* d_
         GEM_HIP(hipGetLastError());
         return 0;
     };
-    float *g = t->gA, *g2 = t->gB;
+    // The chain: dOut (gradient w.r.t. a layer's output) -> BatchNorm backward -> the layer's own dY buffer -> backward-data conv ->
+    // `run` = the next layer's dOut.  The layers' dY buffers (and gA, the loss gradient = the last conv's dY) stay untouched until
+    // the ONE weight-gradient launch behind the chain.
+    const float* dOut = t->gA;
+    float* run = t->gB;
     for (int i = (int)t->dec.size() - 1; i >= 0; --i) {
         TrainConv& c = t->dec[i];
-        const float* a_in = i > 0 ? t->dec[i - 1].out : t->h0;
-        const float* dY = g;
+        const float* dY = dOut;
         if (c.bn) {
-            if (bn_bwd(g, c, g2)) return 1;
-            dY = g2;
+            if (bn_bwd(dOut, c, c.dY)) return 1;
+            dY = c.dY;
         } else {
             hipLaunchKernelGGL(colsum_kernel, dim3(c.N / 16), dim3(BN_THREADS), 0, s, dY, rows, c.N, t->G + c.ob);
         }
         GEM_HIP(hipGetLastError());
-        if (weight_grad<3>(t, dY, c.N, a_in, c.K, rows, c.N, c.K, c.ow, c.slab, conv_slab_rows(rows), s)) return 1;
         Layer L; L.taps = 3; L.K = c.N; L.N = c.K; L.w = c.adj; L.bias = nullptr;
-        float* dA = (dY == g) ? g2 : g;          // the buffer that does not hold dY
-        { const int rc = conv_rows(t, L.w, nullptr, dY, c.N, dA, c.K, rows, c.K, c.N, s);
-          if (rc > 0 || (rc < 0 && launch_gemm(h, L, EPI_NONE, dY, c.N, nullptr, dA, c.K, rows, T, s, -1))) return 1; }
-        if (dA != g) { float* tmp = g; g = dA; g2 = tmp; }
+        { const int rc = conv_rows(t, L.w, nullptr, dY, c.N, run, c.K, rows, c.K, c.N, s);
+          if (rc > 0 || (rc < 0 && launch_gemm(h, L, EPI_NONE, dY, c.N, nullptr, run, c.K, rows, T, s, -1))) return 1; }
+        dOut = run;
     }
+    float* g = run;
     // g = dh0 [B, T*topp]: decoder_input
     { const TrainLinear& l = t->dec_in;
       const int tps = fused ? fused_backward_strip(t, l, B) : 0;
@@ -1140,7 +1173,7 @@ int gem_trainer_step(gem_trainer* t, int B, const float* d_pose, const float* d_
     // fc_mu | fc_var
     { const TrainLinear& l = t->fc;
       const float* flat = t->enc.back().out;
-      g = t->gA; g2 = t->gB;
+      // (g = gB again: decoder_input's backward above has consumed dh0; gA still holds the last conv's dY)
       const int tps = fused ? fused_backward_strip(t, l, B) : 0;
       if (tps) { if (linear_fused_backward(t, l, tps, t->dmulv, flat, g, B, ad, s)) return 1; }
       else {
@@ -1151,15 +1184,18 @@ int gem_trainer_step(gem_trainer* t, int B, const float* d_pose, const float* d_
     // encoder
     for (int i = (int)t->enc.size() - 1; i >= 0; --i) {
         TrainConv& c = t->enc[i];
-        const float* a_in = i > 0 ? t->enc[i - 1].out : t->pose_p;
-        if (bn_bwd(g, c, g2)) return 1;
-        if (weight_grad<3>(t, g2, c.N, a_in, c.K, rows, c.N, c.K, c.ow, c.slab, conv_slab_rows(rows), s)) return 1;
+        if (bn_bwd(g, c, c.dY)) return 1;
         if (i > 0) {
             Layer L; L.taps = 3; L.K = c.N; L.N = c.K; L.w = c.adj; L.bias = nullptr;
-            { const int rc = conv_rows(t, L.w, nullptr, g2, c.N, g, c.K, rows, c.K, c.N, s);
-              if (rc > 0 || (rc < 0 && launch_gemm(h, L, EPI_NONE, g2, c.N, nullptr, g, c.K, rows, T, s, -1))) return 1; }
+            { const int rc = conv_rows(t, L.w, nullptr, c.dY, c.N, g, c.K, rows, c.K, c.N, s);
+              if (rc > 0 || (rc < 0 && launch_gemm(h, L, EPI_NONE, c.dY, c.N, nullptr, g, c.K, rows, T, s, -1))) return 1; }
         }
     }
+    // every conv layer's weight gradient (slabs of conv_slab_rows(rows) rows, or straight into the gradient arena)
+    { const int rps = conv_slab_rows(rows), nslab = (rows + rps - 1) / rps;
+      if (nslab > 1 && t->n_sum != t->n_tn) { set_error("train: weight-gradient slabs missing"); return 1; }
+      hipLaunchKernelGGL(gemm_tn3_all_kernel, dim3(t->tn_tiles, 3, nslab), dim3(256), 0, s, (const TnDesc*)t->tn_tab, t->n_tn, rows, T, rps, nslab);
+      GEM_HIP(hipGetLastError()); }
     // the weight-gradient slabs -> the gradient arena (slab order: deterministic)
     { const int ns_conv = (rows + conv_slab_rows(rows) - 1) / conv_slab_rows(rows), ns_lin = (B + TN_ROWS_LINEAR - 1) / TN_ROWS_LINEAR;
       // (every conv layer's weight_grad<3> call above cut the same `rows` into slabs of TN_ROWS_CONV rows: ONE slab count serves
