@@ -386,10 +386,56 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
                                                       float* __restrict__ slab, int rows, int N, int K, int T, int rps) {
     gemm_tn_tile<TAPS>(dC, ldc, A, lda, slab, rows, N, K, T, rps, blockIdx.x, blockIdx.y, blockIdx.z);
 }
+// Two small jobs that nothing but the end of the step waits for ride along with the weight-gradient launch as extra workgroups
+// (blockIdx.x past the tiles; tap 0 / slab 0 only): the loss scalars from the per-block partials (block order: out = [loss, recon,
+// kld]) and the bias gradient of the last decoder conv (no BatchNorm behind it: the column sums of the loss gradient).
+struct StepTail {
+    const double* part_recon; const double* part_latent; double* out; double* out2;
+    double n_recon, kld_weight;
+    int n_recon_parts, n_latent_parts, B;
+    const float* cs_src; float* cs_out; int cs_N;          // column sums over `rows` rows of cs_src [rows][cs_N]
+};
+__device__ __forceinline__ void finish_loss(const StepTail& t) {
+    __shared__ double sh[2][256];
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < t.n_recon_parts; i += 256) a += t.part_recon[i];
+    for (int i = threadIdx.x; i < t.n_latent_parts; i += 256) b += t.part_latent[i];
+    sh[0][threadIdx.x] = a; sh[1][threadIdx.x] = b;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a = 0.0; b = 0.0;
+        for (int i = 0; i < 256; ++i) { a += sh[0][i]; b += sh[1][i]; }
+        const double recon = a / t.n_recon, kld = -0.5 * b / t.B;
+        t.out[0] = recon + t.kld_weight * kld; t.out[1] = recon; t.out[2] = kld;
+        if (t.out2) { t.out2[0] = t.out[0]; t.out2[1] = recon; t.out2[2] = kld; }          // (the caller's copy: no copy launch behind the step)
+    }
+}
+__device__ __forceinline__ void colsum16(const StepTail& t, int group, int rows) {          // 16 channels, 16 row groups, fp64 sums
+    __shared__ double sh[16][17];
+    const int c = group * 16 + (threadIdx.x & 15), g = threadIdx.x >> 4;
+    double v = 0.0;
+    for (int r = g; r < rows; r += 16) v += t.cs_src[(size_t)r * t.cs_N + c];
+    sh[g][threadIdx.x & 15] = v;
+    __syncthreads();
+    if (g == 0) {
+        double sum = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sum += sh[j][threadIdx.x & 15];
+        t.cs_out[c] = (float)sum;
+    }
+}
 // every conv layer's weight gradient in ONE launch (they wait for nothing but their layer's dY, and nothing but Adam waits for
 // them: eleven launches of ~6 us at the reference's batch otherwise): blockIdx.x walks the layers' tiles (table), y = tap, z = slab
 struct TnDesc { const float* dC; const float* A; float* slab; float* g; int N, K, tile0; };
-__global__ __launch_bounds__(256) void gemm_tn3_all_kernel(const TnDesc* __restrict__ tab, int n_layers, int rows, int T, int rps, int nslab) {
+__global__ __launch_bounds__(256) void gemm_tn3_all_kernel(const TnDesc* __restrict__ tab, int n_layers, int n_tiles, int rows, int T, int rps, int nslab,
+                                                           const StepTail tail) {
+    if ((int)blockIdx.x >= n_tiles) {
+        if (blockIdx.y == 0 && blockIdx.z == 0) {
+            if ((int)blockIdx.x == n_tiles) finish_loss(tail);
+            else colsum16(tail, (int)blockIdx.x - n_tiles - 1, rows);
+        }
+        return;
+    }
     int l = 0;
     while (l + 1 < n_layers && (int)blockIdx.x >= tab[l + 1].tile0) ++l;
     const TnDesc d = tab[l];
@@ -750,25 +796,6 @@ __global__ __launch_bounds__(LOSS_BLOCK) void latent_bwd_kernel(const float* __r
     }
     block_partial(s, part + blockIdx.x);
 }
-// sums the per-block partials in block order: out = [loss, recon, kld]
-__global__ __launch_bounds__(256) void finish_loss_kernel(const double* __restrict__ part_recon, int n_recon_parts, const double* __restrict__ part_latent,
-                                                          int n_latent_parts, double n_recon, double kld_weight, int B, double* __restrict__ out,
-                                                          double* __restrict__ out2) {
-    __shared__ double sh[2][256];
-    double a = 0.0, b = 0.0;
-    for (int i = threadIdx.x; i < n_recon_parts; i += 256) a += part_recon[i];
-    for (int i = threadIdx.x; i < n_latent_parts; i += 256) b += part_latent[i];
-    sh[0][threadIdx.x] = a; sh[1][threadIdx.x] = b;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        a = 0.0; b = 0.0;
-        for (int i = 0; i < 256; ++i) { a += sh[0][i]; b += sh[1][i]; }
-        const double recon = a / n_recon, kld = -0.5 * b / B;
-        out[0] = recon + kld_weight * kld; out[1] = recon; out[2] = kld;
-        if (out2) { out2[0] = out[0]; out2[1] = recon; out2[2] = kld; }          // (the caller's copy: no copy launch behind the step)
-    }
-}
-
 // torch.optim.Adam (amsgrad off): g += wd * p; m, v moments; p -= lr / bc1 * m / (sqrt(v) / sqrt(bc2) + eps)
 // (skip0 / skip1: element ranges, in arena order, that gemm_tn_adam_kernel has already stepped; n counts the elements outside them)
 struct SkipRange { size_t begin, len; };
@@ -835,10 +862,41 @@ static int conv_rows(gem_trainer* t, const float* W, const float* bias, const fl
     return launch_conv_rows<2, 1>(grid, W, bias, A, lda, C, ldc, rows, N, K, t->T, s);
 }
 
+// [mu | logvar] = sum of the fc product's K slabs + bias, and z = mu + eps exp(0.5 logvar) (SeqConvVAE.py:159-169) in the same pass:
+// splitk_reduce_kernel<EPI_BIAS> followed by reparam_kernel, same sums in the same order, one launch
+__global__ __launch_bounds__(256) void fc_reduce_reparam_kernel(const float* __restrict__ slabs, int nslab, size_t slab_stride, const float* __restrict__ bias,
+                                                                const float* __restrict__ eps, float* __restrict__ mulv, float* __restrict__ z, int B, int D,
+                                                                int Dp) {
+    const int n4 = Dp / 4;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * n4) return;
+    const int b = i / n4, c = (i - b * n4) * 4;
+    const size_t off_m = (size_t)b * 2 * Dp + c, off_l = off_m + Dp;
+    f32x4 m = *reinterpret_cast<const f32x4*>(slabs + off_m), lv = *reinterpret_cast<const f32x4*>(slabs + off_l);
+    for (int zz = 1; zz < nslab; ++zz) {
+        m += *reinterpret_cast<const f32x4*>(slabs + (size_t)zz * slab_stride + off_m);
+        lv += *reinterpret_cast<const f32x4*>(slabs + (size_t)zz * slab_stride + off_l);
+    }
+    m += *reinterpret_cast<const f32x4*>(bias + c);
+    lv += *reinterpret_cast<const f32x4*>(bias + Dp + c);
+    *reinterpret_cast<f32x4*>(mulv + off_m) = m;
+    *reinterpret_cast<f32x4*>(mulv + off_l) = lv;
+    f32x4 zv;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int k = c + q;
+        zv[q] = k < D ? eps[(size_t)b * D + k] * expf(0.5f * lv[q]) + m[q] : 0.f;
+    }
+    *reinterpret_cast<f32x4*>(z + (size_t)b * Dp + c) = zv;
+}
+
 // A linear layer over B rows (64 at the reference's batch): pure weight streaming.  The few-rows kernel (gemm_rows.h) fills the chip
 // at so few rows only when it may cut K; letting it "defer" the reduction gives it that freedom, and the slabs are summed (+ bias)
 // right behind it.
-static int linear_gemm(gem_trainer* t, const Layer& L, int epi, const float* A, int lda, float* C, int ldc, int M, hipStream_t s) {
+// reparam_eps != nullptr (the fc layer, C = [mu | logvar]): z = mu + eps exp(0.5 logvar) is formed as well -- by the slab sum itself
+// when there are slabs, by reparam_kernel otherwise
+static int linear_gemm(gem_trainer* t, const Layer& L, int epi, const float* A, int lda, float* C, int ldc, int M, hipStream_t s,
+                       const float* reparam_eps = nullptr) {
     gem_handle* h = t->h;
     h->ws.defer_reduce = true;
     const int rc = launch_gemm(h, L, epi, A, lda, nullptr, C, ldc, M, t->T, s, -1);
@@ -846,7 +904,14 @@ static int linear_gemm(gem_trainer* t, const Layer& L, int epi, const float* A, 
     const SlabSrc d = h->ws.deferred;
     h->ws.deferred = SlabSrc{};
     if (rc) return rc;
-    if (d.base) return launch_splitk_reduce(h, epi, d.nslab, d.stride, L.bias, nullptr, C, M, L.N, ldc, nullptr, s, d.dyn_W, d.n_tiles);
+    if (d.base && reparam_eps && epi == EPI_BIAS && d.dyn_W == 0 && ldc == 2 * t->Dp && !dev_env("GEM_TRAIN_NO_FC_REPARAM")) {
+        hipLaunchKernelGGL(fc_reduce_reparam_kernel, dim3((unsigned)((M * (t->Dp / 4) + 255) / 256)), dim3(256), 0, s, (const float*)d.base, d.nslab, d.stride,
+                           L.bias, reparam_eps, C, t->z, M, t->D, t->Dp);
+        GEM_HIP(hipGetLastError());
+        return 0;
+    }
+    if (d.base && launch_splitk_reduce(h, epi, d.nslab, d.stride, L.bias, nullptr, C, M, L.N, ldc, nullptr, s, d.dyn_W, d.n_tiles)) return 1;
+    if (reparam_eps) return launch_reparam(C, reparam_eps, nullptr, nullptr, nullptr, t->z, M, t->D, t->Dp, s);
     return 0;
 }
 
@@ -1103,8 +1168,7 @@ int gem_trainer_step(gem_trainer* t, int B, const float* d_pose, const float* d_
     const float* in = t->pose_p;
     for (auto& c : t->enc) { if (conv_fwd(c, in)) return 1; in = c.out; }
     { Layer L; L.taps = 1; L.K = t->fc.K; L.N = t->fc.N; L.w = t->P + t->fc.ow; L.bias = t->P + t->fc.ob;
-      if (linear_gemm(t, L, EPI_BIAS, in, L.K, t->mulv, L.N, B, s)) return 1; }
-    if (launch_reparam(t->mulv, d_eps, nullptr, nullptr, nullptr, t->z, B, t->D, t->Dp, s)) return 1;
+      if (linear_gemm(t, L, EPI_BIAS, in, L.K, t->mulv, L.N, B, s, d_eps)) return 1; }
     { Layer L; L.taps = 1; L.K = t->dec_in.K; L.N = t->dec_in.N; L.w = t->P + t->dec_in.ow; L.bias = t->P + t->dec_in.ob;
       if (linear_gemm(t, L, EPI_BIAS, t->z, L.K, t->h0, L.N, B, s)) return 1; }
     in = t->h0;
@@ -1145,10 +1209,7 @@ int gem_trainer_step(gem_trainer* t, int B, const float* d_pose, const float* d_
         if (c.bn) {
             if (bn_bwd(dOut, c, c.dY)) return 1;
             dY = c.dY;
-        } else {
-            hipLaunchKernelGGL(colsum_kernel, dim3(c.N / 16), dim3(BN_THREADS), 0, s, dY, rows, c.N, t->G + c.ob);
-        }
-        GEM_HIP(hipGetLastError());
+        }          // (no BatchNorm -- the last conv: its bias gradient, the column sums of dY, rides with the weight-gradient launch)
         Layer L; L.taps = 3; L.K = c.N; L.N = c.K; L.w = c.adj; L.bias = nullptr;
         { const int rc = conv_rows(t, L.w, nullptr, dY, c.N, run, c.K, rows, c.K, c.N, s);
           if (rc > 0 || (rc < 0 && launch_gemm(h, L, EPI_NONE, dY, c.N, nullptr, run, c.K, rows, T, s, -1))) return 1; }
@@ -1166,9 +1227,6 @@ int gem_trainer_step(gem_trainer* t, int B, const float* d_pose, const float* d_
       } }
     hipLaunchKernelGGL(latent_bwd_kernel, dim3(n_pl), dim3(LOSS_BLOCK), 0, s, (const float*)t->mulv, d_eps, (const float*)t->dz, B, t->D, t->Dp,
                        (float)(o->kld_weight / B), t->dmulv, part_latent);
-    GEM_HIP(hipGetLastError());
-    hipLaunchKernelGGL(finish_loss_kernel, dim3(1), dim3(256), 0, s, (const double*)part_recon, n_pr, (const double*)part_latent, n_pl, n_recon,
-                       o->kld_weight, B, t->red + 4, d_losses);
     GEM_HIP(hipGetLastError());
     // fc_mu | fc_var
     { const TrainLinear& l = t->fc;
@@ -1194,7 +1252,10 @@ int gem_trainer_step(gem_trainer* t, int B, const float* d_pose, const float* d_
     // every conv layer's weight gradient (slabs of conv_slab_rows(rows) rows, or straight into the gradient arena)
     { const int rps = conv_slab_rows(rows), nslab = (rows + rps - 1) / rps;
       if (nslab > 1 && t->n_sum != t->n_tn) { set_error("train: weight-gradient slabs missing"); return 1; }
-      hipLaunchKernelGGL(gemm_tn3_all_kernel, dim3(t->tn_tiles, 3, nslab), dim3(256), 0, s, (const TnDesc*)t->tn_tab, t->n_tn, rows, T, rps, nslab);
+      const TrainConv& last = t->dec.back();
+      StepTail tail{part_recon, part_latent, t->red + 4, d_losses, n_recon, o->kld_weight, n_pr, n_pl, B, t->gA, t->G + last.ob, last.N};
+      hipLaunchKernelGGL(gemm_tn3_all_kernel, dim3(t->tn_tiles + 1 + last.N / 16, 3, nslab), dim3(256), 0, s, (const TnDesc*)t->tn_tab, t->n_tn, t->tn_tiles,
+                         rows, T, rps, nslab, tail);
       GEM_HIP(hipGetLastError()); }
     // the weight-gradient slabs -> the gradient arena (slab order: deterministic)
     { const int ns_conv = (rows + conv_slab_rows(rows) - 1) / conv_slab_rows(rows), ns_lin = (B + TN_ROWS_LINEAR - 1) / TN_ROWS_LINEAR;
