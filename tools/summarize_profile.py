@@ -9,6 +9,11 @@ import json
 import os
 import sys
 
+
+def newest(files):
+    """gpurun merges a call's files into what earlier calls left behind: only the most recent run of a directory counts"""
+    return sorted(files, key=os.path.getmtime, reverse=True)[:1]
+
 src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
 os.makedirs(dst, exist_ok=True)
 
@@ -18,7 +23,7 @@ def short(name):
 
 
 def kernel_stats(sub, out_name):
-    f = glob.glob(os.path.join(src, sub, "trace", "*", "*kernel_stats.csv"))
+    f = newest(glob.glob(os.path.join(src, sub, "trace", "*", "*kernel_stats.csv")))
     if not f:
         return
     rows = list(csv.DictReader(open(f[0])))
@@ -38,7 +43,7 @@ def kernel_stats(sub, out_name):
 def traffic(sub, dominant_substr, out_name, note_cmd, windows, precision):
     t = {}
     for key, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-        f = glob.glob(os.path.join(src, sub, "pmc_" + key, "*", "*counter_summary.csv"))
+        f = newest(glob.glob(os.path.join(src, sub, "pmc_" + key, "*", "*counter_summary.csv")))
         if not f:
             return None
         t[key] = {short(r["kernel"]): (float(r["mean_value"]), int(r["dispatches"])) for r in csv.DictReader(open(f[0])) if r["counter"] == counter}
@@ -71,7 +76,7 @@ kernel_stats("bf16_8192", "kernel_stats_%s_bf16_8192_windows.csv" % tag)
 
 def train_stats(out_name, sub="train", batch=64, timed=50):
     """rocprofv3 --kernel-trace --stats of tools/train_bench.py <batch> <timed>, summarised like the others (per-step launch counts)."""
-    f = glob.glob(os.path.join(src, sub, "trace", "*", "*kernel_stats.csv"))
+    f = newest(glob.glob(os.path.join(src, sub, "trace", "*", "*kernel_stats.csv")))
     if not f:
         return
     rows = list(csv.DictReader(open(f[0])))
@@ -93,7 +98,7 @@ train_stats("kernel_stats_%s_train_b64.csv" % tag)
 train_stats("kernel_stats_%s_train_b1024.csv" % tag, "train1024", 1024, 20)
 # the dominant kernel of the headline run = the kernel (all instantiations of a template counted together) with the most time
 def total_ms(sub, substr):
-    f = glob.glob(os.path.join(src, sub, "trace", "*", "*kernel_stats.csv"))
+    f = newest(glob.glob(os.path.join(src, sub, "trace", "*", "*kernel_stats.csv")))
     if not f:
         return 0.0
     return sum(float(r["TotalDurationNs"]) for r in csv.DictReader(open(f[0])) if substr in r["Name"]) / 1e6
