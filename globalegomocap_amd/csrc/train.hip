@@ -8,12 +8,16 @@
 // Conv1d taps [3][N][K], k contiguous; fc_mu | fc_var stacked; decoder_input time-major), with same-shaped arenas for gradient
 // and the two Adam moments; the reference's checkpoint schema is a permutation of that arena (host side: vae_train.py).  Padded
 // entries are zero and stay zero (their gradients are sums over zero activations).
-//   forward / backward-DATA products: the fp32 MFMA kernels of the optimiser (launch_gemm); the adjoint weight images of the CONV
-//     layers (3 % of the parameters) are re-packed from the arena by ONE launch at the start of a step (adjoint_all_kernel); the
-//     two linear layers' backward-data products contract over the rows of the weights' own layout (linear_bwd_data, round 4)
-//   weight gradients: gemm_tn_kernel, dW[tap][n][k] = sum_r dC[r][n] * A[r + tap - 1][k] (contraction over the ROWS, both
-//     operands row-major: staged through LDS, v_mfma_f32_16x16x4_f32), row range cut into slabs of 64 rows (conv layers: small
-//     tensors, many rows) that ONE launch sums in slab order for all layers before Adam (slab_sum_all_kernel)
+//   conv products, forward and backward-data: conv_rows.h (one launch per product at every batch size: 32 x 32 tiles, the waves of
+//     a workgroup split K, operands staged through wave-private LDS by LDS-DMA); the adjoint weight images of the CONV layers (3 %
+//     of the parameters) are re-packed from the arena by ONE launch at the start of a step (adjoint_all_kernel)
+//   the two linear layers (97 % of the parameters): forward through the optimiser's few-rows kernel (launch_gemm; K slabs summed by
+//     the next kernel, which for fc also forms z); backward at batches up to 64 windows in the training-loop mode = ONE pass over the
+//     weights (gemm_tn_adam_dx_kernel: weight gradient, Adam step and backward-data product per tile), otherwise backward-data
+//     from the weights' own layout (linear_bwd_data) + weight gradient (+ Adam step: gemm_tn_adam_kernel)
+//   conv weight gradients: dW[tap][n][k] = sum_r dC[r][n] * A[r + tap - 1][k] (contraction over the ROWS, both operands row-major:
+//     staged through LDS, v_mfma_f32_16x16x4_f32), all layers in ONE launch behind the backward chain (gemm_tn3_all_kernel; every
+//     BatchNorm layer keeps its dY), row range cut into slabs that ONE launch sums in slab order before Adam (slab_sum_all_kernel)
 //   BatchNorm (+ LeakyReLU) forward / backward (incl. the conv bias gradient), the latent / loss gradients, Adam: one kernel each
 // Everything is enqueued on the caller's stream; no host synchronisation inside a step.
 #include <algorithm>

@@ -236,7 +236,9 @@ int gem_profile_kernels(gem_handle* h, int family, char* buf, int buf_len);
  * `update` is non-zero -- one torch.optim.Adam step (train.py:60: lr, betas, eps, L2 weight_decay added to the gradient).
  * update = 1 leaves every gradient in the gradient arena (p.grad after the step).  update = 2 is the training loop's mode: the two
  * linear layers (fc_mu | fc_var, decoder_input: 97 % of the parameters) form their weight gradient INSIDE their Adam step and do
- * not write it to the arena (their arena entries are stale afterwards); parameters, moments, statistics and losses are the same.
+ * not write it to the arena (their arena entries are stale afterwards); parameters, moments, statistics and losses are the same
+ * up to summation order (at batches of at most 64 windows the same pass over the weights also forms the layers' backward-data
+ * products; what Adam's eps makes of last-bit differences: tests/test_hip_train.py::test_training_loop_mode_steps_like_the_default_mode).
  *
  * Parameters, gradients and both Adam moments are fp32 arenas of `n_params` floats in the packed device layout; running
  * statistics an arena of `n_stats` floats.  Arena order (every width padded to a multiple of 64, padding zero):
