@@ -6,6 +6,18 @@ namespace gem {
 
 typedef float cr_f32x4 __attribute__((ext_vector_type(4)));
 
+// BatchNorm statistics formed by the conv's epilogue (training step, conv_rows_lds_kernel; part == nullptr: none): per 32-row tile and
+// channel three fp64 sums, part[(row tile * N + n) * 3 + q], added up in tile order by the BatchNorm apply kernels (train.hip).
+//   forward flavour (out == nullptr): the tile is the conv output y of a BatchNorm block: sums of y, y^2, (unused)
+//   backward flavour: the tile is dOut of a BatchNorm + LeakyReLU block whose output / conv output are out / Y: the epilogue STORES
+//   dz = dOut * LeakyReLU'(out) instead of dOut and leaves the sums of dz, dz * xhat, xhat (xhat = (Y - mean) * invstd)
+struct CrStats {
+    double* part;
+    const float* out; const float* Y; const float* mean; const float* invstd;
+    float slope;
+};
+constexpr int CR_STATS_LDS = 2 * 32 * 32 * 4;          // two staging tiles behind the KW reduction tiles
+
 // ---- a 3-tap conv over FEW rows (the reference's batch: 640 rows), forward and backward-data ----------------------------------------
 // out[r][n] = bias[n] + sum_tap sum_k A[r + tap - 1][k] W[tap][n][k]  (rows of one window only: frame r % T + tap - 1 in [0, T)).
 // The optimiser's 64 x 64-tile kernel needs split-K slabs and a reduce launch to fill the chip at 640 rows (7 + 5 reduce launches per
@@ -96,7 +108,7 @@ __global__ __launch_bounds__(64 * KW) void conv_rows_kernel(const float* __restr
 // served per LDS cycle hit eight different bank groups.  Dynamic LDS: KW x D x 8 KB.
 template <int KW, int D, int ABLATE = 0>
 __global__ __launch_bounds__(64 * KW) void conv_rows_lds_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W, const float* __restrict__ bias,
-                                                               float* __restrict__ C, int ldc, int rows, int N, int K, int T) {
+                                                               float* __restrict__ C, int ldc, int rows, int N, int K, int T, const CrStats st) {
     typedef float f32x16 __attribute__((ext_vector_type(16)));
     extern __shared__ __attribute__((aligned(16))) unsigned char cr_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -117,6 +129,15 @@ __global__ __launch_bounds__(64 * KW) void conv_rows_lds_kernel(const float* __r
     int rd_off[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) rd_off[q] = li * 128 + (((4 * hl + q) ^ (li & 7)) << 4);
+    // backward statistics: this thread's pieces of the block's output / conv output (it reduces row tid >> 3, columns 4 (tid & 7) ..
+    // of the tile at the end) are requested now, so that they have arrived when the products are done
+    cr_f32x4 e_o = cr_f32x4{0.f, 0.f, 0.f, 0.f}, e_y = e_o, e_mf = e_o, e_is = e_o;
+    if (st.part && st.out && tid < 256) {
+        const int i = tid >> 3, j4 = (tid & 7) * 4;
+        const size_t at = (size_t)min(m0 + i, rows - 1) * ldc + n0 + j4;
+        e_o = *reinterpret_cast<const cr_f32x4*>(st.out + at); e_y = *reinterpret_cast<const cr_f32x4*>(st.Y + at);
+        e_mf = *reinterpret_cast<const cr_f32x4*>(st.mean + n0 + j4); e_is = *reinterpret_cast<const cr_f32x4*>(st.invstd + n0 + j4);
+    }
     int tap_n = 0, c_n = 0;          // the next request (wave-uniform)
     auto issue = [&](int slot) {
         const int koff = c_n * 32;
@@ -184,7 +205,44 @@ __global__ __launch_bounds__(64 * KW) void conv_rows_lds_kernel(const float* __r
 #pragma unroll
         for (int w = 1; w < KW; ++w) sum += *reinterpret_cast<const cr_f32x4*>(&red[w][i][j4]);
         if (bias) sum += *reinterpret_cast<const cr_f32x4*>(bias + n0 + j4);
-        if (m0 + i < rows) *reinterpret_cast<cr_f32x4*>(C + (size_t)(m0 + i) * ldc + n0 + j4) = sum;
+        const bool in = m0 + i < rows;
+        if (st.part) {
+            float (*sv)[32][32] = reinterpret_cast<float (*)[32][32]>(cr_smem + KW * 4096);
+            cr_f32x4 v0 = in ? sum : cr_f32x4{0.f, 0.f, 0.f, 0.f}, v1 = cr_f32x4{0.f, 0.f, 0.f, 0.f};
+            if (st.out) {          // (KW >= 4: one pass of this loop per thread, o == tid -- the pieces requested at the start)
+                cr_f32x4 o4 = e_o, y4 = e_y, mf = e_mf, is = e_is;
+                if (KW < 4) {
+                    const size_t at = (size_t)(in ? m0 + i : 0) * ldc + n0 + j4;
+                    o4 = *reinterpret_cast<const cr_f32x4*>(st.out + at); y4 = *reinterpret_cast<const cr_f32x4*>(st.Y + at);
+                    mf = *reinterpret_cast<const cr_f32x4*>(st.mean + n0 + j4); is = *reinterpret_cast<const cr_f32x4*>(st.invstd + n0 + j4);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v0[q] = in ? sum[q] * (o4[q] > 0.f ? 1.f : st.slope) : 0.f;
+                    v1[q] = in ? (y4[q] - mf[q]) * is[q] : 0.f;
+                }
+                sum = v0;
+            }
+            *reinterpret_cast<cr_f32x4*>(&sv[0][i][j4]) = v0;
+            *reinterpret_cast<cr_f32x4*>(&sv[1][i][j4]) = v1;
+        }
+        if (in) *reinterpret_cast<cr_f32x4*>(C + (size_t)(m0 + i) * ldc + n0 + j4) = sum;
+    }
+    if (st.part) {
+        __syncthreads();
+        if (tid < 32) {
+            const float (*sv)[32][32] = reinterpret_cast<const float (*)[32][32]>(cr_smem + KW * 4096);
+            double a = 0.0, b = 0.0, c = 0.0;
+            if (st.out) {
+#pragma unroll 8
+                for (int i = 0; i < 32; ++i) { const float dz = sv[0][i][tid], xh = sv[1][i][tid]; a += dz; b += (double)dz * xh; c += xh; }
+            } else {
+#pragma unroll 8
+                for (int i = 0; i < 32; ++i) { const float y = sv[0][i][tid]; a += (double)y; b += (double)y * y; }
+            }
+            double* p = st.part + ((size_t)blockIdx.x * N + n0 + tid) * 3;
+            p[0] = a; p[1] = b; p[2] = c;
+        }
     }
 }
 

@@ -180,6 +180,100 @@ __global__ __launch_bounds__(BN_THREADS) void bn_train_bwd_kernel(const float* _
     }
 }
 
+// ---- BatchNorm whose statistics come out of the producing conv's epilogue (conv_rows.h: CrStats; rows <= BNF_ROWS_MAX) ------------
+// The register-resident kernels above put a whole column block (all rows x 16 channels) through ONE CU: 2560 half-used lines through
+// one L1 = ~4.3 us plus the reduction, 6 / 10 us per launch.  With the per-tile sums already there (fp64, one triple per 32-row tile
+// and channel, added here in tile order: the same bits in every workgroup) the rest is elementwise: 64 channels x 64 rows per
+// workgroup, 10-80 workgroups at the reference's batch.  Same formulas as bn_train_fwd_kernel / bn_train_bwd_kernel.
+constexpr int BNF_ROWS_MAX = 1024;
+template <int NV>
+__device__ __forceinline__ void bnf_totals(const double* __restrict__ part, int nrt, int N, int c0, double (*tot)[64]) {
+    if (threadIdx.x < 64 * NV) {
+        const int ch = threadIdx.x & 63, q = threadIdx.x >> 6;
+        double v[BNF_ROWS_MAX / 32];          // every tile's value requested at once (a loop of nrt dependent round trips cost 10+ us), added in tile order
+#pragma unroll
+        for (int t = 0; t < BNF_ROWS_MAX / 32; ++t) v[t] = t < nrt ? part[((size_t)t * N + c0 + ch) * 3 + q] : 0.0;
+        double sum = 0.0;
+#pragma unroll
+        for (int t = 0; t < BNF_ROWS_MAX / 32; ++t) sum += v[t];
+        tot[q][ch] = sum;
+    }
+    __syncthreads();
+}
+__global__ __launch_bounds__(256) void bnf_fwd_apply_kernel(const float* __restrict__ Y, int rows, int N, const double* __restrict__ part, int nrt,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ rmean,
+                                                            float* __restrict__ rvar, float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                                            float* __restrict__ out, float momentum, float eps) {
+    __shared__ double tot[2][64];
+    __shared__ float mfs[64], iss[64];
+    const int c0 = blockIdx.x * 64, tid = threadIdx.x;
+    bnf_totals<2>(part, nrt, N, c0, tot);
+    if (tid < 64) {
+        const double mean = tot[0][tid] / rows;
+        double var = tot[1][tid] / rows - mean * mean;                 // biased (what normalises the batch)
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps)), mf = (float)mean;
+        mfs[tid] = mf; iss[tid] = invstd;
+        if (blockIdx.y == 0) {
+            const int c = c0 + tid;
+            mean_out[c] = mf; invstd_out[c] = invstd;
+            const double unbiased = rows > 1 ? var * rows / (rows - 1) : var;
+            rmean[c] = (1.f - momentum) * rmean[c] + momentum * mf;
+            rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+        }
+    }
+    __syncthreads();
+    const int cl = (tid & 15) * 4, c = c0 + cl;
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c), be = *reinterpret_cast<const f32x4*>(beta + c);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int r = blockIdx.y * 64 + (tid >> 4) + 16 * p;
+        if (r >= rows) continue;
+        const f32x4 y = *reinterpret_cast<const f32x4*>(Y + (size_t)r * N + c);
+        f32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float v = ga[q] * ((y[q] - mfs[cl + q]) * iss[cl + q]) + be[q];
+            o[q] = v > 0.f ? v : v * LEAKY_SLOPE;
+        }
+        *reinterpret_cast<f32x4*>(out + (size_t)r * N + c) = o;
+    }
+}
+// dz (the producing conv stored dOut * LeakyReLU'(out)) -> dY, dgamma, dbeta, and the conv's bias gradient from the sums
+__global__ __launch_bounds__(256) void bnf_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ Y, int rows, int N,
+                                                            const double* __restrict__ part, int nrt, const float* __restrict__ gamma,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ dY,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dbias) {
+    __shared__ double tot[3][64];
+    const int c0 = blockIdx.x * 64, tid = threadIdx.x;
+    bnf_totals<3>(part, nrt, N, c0, tot);
+    const int cl = (tid & 15) * 4, c = c0 + cl;
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c), mf = *reinterpret_cast<const f32x4*>(mean + c), is = *reinterpret_cast<const f32x4*>(invstd + c);
+    float mb[4], mg[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { mb[q] = (float)(tot[0][cl + q] / rows); mg[q] = (float)(tot[1][cl + q] / rows); }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int r = blockIdx.y * 64 + (tid >> 4) + 16 * p;
+        if (r >= rows) continue;
+        const f32x4 d = *reinterpret_cast<const f32x4*>(dz + (size_t)r * N + c), y = *reinterpret_cast<const f32x4*>(Y + (size_t)r * N + c);
+        f32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float xh = (y[q] - mf[q]) * is[q];
+            o[q] = ga[q] * is[q] * (d[q] - mb[q] - xh * mg[q]);
+        }
+        *reinterpret_cast<f32x4*>(dY + (size_t)r * N + c) = o;
+    }
+    if (blockIdx.y == 0 && tid < 64) {
+        const int ch = c0 + tid;
+        const double v0 = tot[0][tid], v1 = tot[1][tid], v2 = tot[2][tid];
+        const float mbs = (float)(v0 / rows), mgs = (float)(v1 / rows);
+        dgamma[ch] = (float)v1; dbeta[ch] = (float)v0;
+        dbias[ch] = (float)((double)gamma[ch] * invstd[ch] * (v0 - (double)rows * mbs - (double)mgs * v2));
+    }
+}
+
 // ---- BatchNorm for MORE rows than a workgroup holds in registers (rows > BN_REGS * BN_GROUPS = 1024: batches above 102 windows) ----
 // The one-workgroup-per-16-channels kernels above are built for the reference's batch of 64 (640 rows): at 10 240 rows (batch 1024)
 // their 4-32 workgroups read the layer two or three times at a few percent of the chip's bandwidth -- 2.1 of that step's 5.2 ms
@@ -317,7 +411,8 @@ __global__ __launch_bounds__(BN_THREADS) void colsum_kernel(const float* __restr
 
 constexpr int CONV_ROWS_MAX = 1 << 30;          // every batch: 1.18 -> 1.11 ms per step at batch 128, 2.17 -> 2.11 at 512, 3.48 -> 3.44 at 1024 (dev switch: GEM_CONV_ROWS_MAX)
 // 0 = launched; 1 = error; -1 = not applicable (the caller falls back to launch_gemm)
-static int conv_rows(gem_trainer* t, const float* W, const float* bias, const float* A, int lda, float* C, int ldc, int rows, int N, int K, hipStream_t s);
+static int conv_rows(gem_trainer* t, const float* W, const float* bias, const float* A, int lda, float* C, int ldc, int rows, int N, int K, hipStream_t s,
+                     const CrStats& st = CrStats{});
 
 // ---- weight gradient: dW[tap][n][k] = sum_r dC[r][n] * A[r + tap - 1][k], slab z = rows [z * rps, (z + 1) * rps) --------------
 template <int TAPS>
@@ -841,19 +936,20 @@ static int weight_grad(gem_trainer* t, const float* dC, int ldc, const float* A,
 
 template <int KW, int D>
 static int launch_conv_rows(const dim3& grid, const float* W, const float* bias, const float* A, int lda, float* C, int ldc, int rows, int N, int K, int T,
-                            hipStream_t s) {
+                            hipStream_t s, const CrStats& st) {
     auto k = conv_rows_lds_kernel<KW, D>;
-    constexpr size_t smem = (size_t)KW * D * 8192;
+    constexpr size_t smem = std::max((size_t)KW * D * 8192, (size_t)KW * 4096 + CR_STATS_LDS);
     static bool attr_set = false;          // (the trainer is driven from one host thread)
     if (smem > 64 * 1024 && !attr_set) {
         GEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k, grid, dim3(64 * KW), smem, s, A, lda, W, bias, C, ldc, rows, N, K, T);
+    hipLaunchKernelGGL(k, grid, dim3(64 * KW), smem, s, A, lda, W, bias, C, ldc, rows, N, K, T, st);
     GEM_HIP(hipGetLastError());
     return 0;
 }
-static int conv_rows(gem_trainer* t, const float* W, const float* bias, const float* A, int lda, float* C, int ldc, int rows, int N, int K, hipStream_t s) {
+static int conv_rows(gem_trainer* t, const float* W, const float* bias, const float* A, int lda, float* C, int ldc, int rows, int N, int K, hipStream_t s,
+                     const CrStats& st) {
     static const int rows_max = dev_env("GEM_CONV_ROWS_MAX") ? atoi(dev_env("GEM_CONV_ROWS_MAX")) : CONV_ROWS_MAX;
     if (rows > rows_max || K % 64 || N % 32 || dev_env("GEM_TRAIN_NO_CONV_ROWS")) return -1;
     const dim3 grid((rows + 31) / 32, N / 32);
@@ -861,9 +957,9 @@ static int conv_rows(gem_trainer* t, const float* W, const float* bias, const fl
     // do not fill the chip.  One ring slot per wave (the refill of the slot just read runs under the sixteen MFMAs: a second slot
     // measured the same).  tools/conv_rows_bench: 4.8 us (K <= 128), 7 (N 128, K 256),
     // 11 (N 512, K 256 and N 256, K 512) at 640 rows, against 9 + 4.5 and 13.5 + 4.9 for the tiled kernel and its split-K reduce
-    if (K % 256 == 0 && (long)grid.x * grid.y <= t->h->n_cu) return launch_conv_rows<8, 1>(grid, W, bias, A, lda, C, ldc, rows, N, K, t->T, s);
-    if (K % 128 == 0) return launch_conv_rows<4, 1>(grid, W, bias, A, lda, C, ldc, rows, N, K, t->T, s);
-    return launch_conv_rows<2, 1>(grid, W, bias, A, lda, C, ldc, rows, N, K, t->T, s);
+    if (K % 256 == 0 && (long)grid.x * grid.y <= t->h->n_cu) return launch_conv_rows<8, 1>(grid, W, bias, A, lda, C, ldc, rows, N, K, t->T, s, st);
+    if (K % 128 == 0) return launch_conv_rows<4, 1>(grid, W, bias, A, lda, C, ldc, rows, N, K, t->T, s, st);
+    return launch_conv_rows<2, 1>(grid, W, bias, A, lda, C, ldc, rows, N, K, t->T, s, st);
 }
 
 // [mu | logvar] = sum of the fc product's K slabs + bias, and z = mu + eps exp(0.5 logvar) (SeqConvVAE.py:159-169) in the same pass:
@@ -1048,7 +1144,7 @@ int gem_trainer_create(const gem_config* cfg, gem_trainer** out) {
     if (!sums.empty()) GEM_HIP(hipMemcpy(p->sum_tab, sums.data(), sums.size() * sizeof(SumDesc), hipMemcpyHostToDevice));
     p->part_recon = (int)((rows * PAD + LOSS_BLOCK - 1) / LOSS_BLOCK);
     p->part_latent = (int)(((size_t)p->Bmax * p->Dp + LOSS_BLOCK - 1) / LOSS_BLOCK);
-    p->bn_nrb_cap = (int)((rows + BNL_ROWS - 1) / BNL_ROWS);
+    p->bn_nrb_cap = std::max((int)((rows + BNL_ROWS - 1) / BNL_ROWS), BNF_ROWS_MAX / 32);          // (bnl_*: 128-row blocks; bnf_*: 32-row conv tiles)
     if (talloc(p, &p->bn_part, (size_t)p->bn_nrb_cap * max_width * 3)) return 1;
     if (talloc(p, &p->pose_p, rows * PAD) || talloc(p, &p->mulv, (size_t)p->Bmax * 2 * p->Dp) || talloc(p, &p->z, (size_t)p->Bmax * p->Dp) ||
         talloc(p, &p->h0, rows * p->topp) || talloc(p, &p->Xp, rows * PAD) || talloc(p, &p->gA, rows * max_width) || talloc(p, &p->gB, rows * max_width) ||
@@ -1149,12 +1245,20 @@ int gem_trainer_step(gem_trainer* t, int B, const float* d_pose, const float* d_
     GEM_HIP(hipGetLastError());
     // ---- forward (train mode)
     if (launch_pack_pose(d_pose, t->pose_p, rows, t->C, s)) return 1;
+    const bool bn_fused = rows <= BNF_ROWS_MAX && !dev_env("GEM_TRAIN_NO_BN_FUSE");
     auto conv_fwd = [&](TrainConv& c, const float* in) -> int {
         Layer L; L.taps = 3; L.K = c.K; L.N = c.N; L.w = t->P + c.ow; L.bias = t->P + c.ob;
-        { const int rc = conv_rows(t, L.w, L.bias, in, c.K, c.bn ? c.Y : c.out, c.N, rows, c.N, c.K, s);
-          if (rc > 0 || (rc < 0 && launch_gemm(h, L, EPI_BIAS, in, c.K, nullptr, c.bn ? c.Y : c.out, c.N, rows, T, s, -1))) return 1; }
+        // (bn_fused: the conv's epilogue leaves the BatchNorm sums per 32-row tile; the apply kernels are elementwise)
+        CrStats st{};
+        if (c.bn && bn_fused) st.part = t->bn_part;
+        const int rc = conv_rows(t, L.w, L.bias, in, c.K, c.bn ? c.Y : c.out, c.N, rows, c.N, c.K, s, st);
+        if (rc > 0 || (rc < 0 && launch_gemm(h, L, EPI_BIAS, in, c.K, nullptr, c.bn ? c.Y : c.out, c.N, rows, T, s, -1))) return 1;
         if (c.bn) {
-            if (rows <= BN_REGS * BN_GROUPS) {
+            if (rc == 0 && st.part) {
+                hipLaunchKernelGGL(bnf_fwd_apply_kernel, dim3(c.N / 64, (rows + 63) / 64), dim3(256), 0, s, (const float*)c.Y, rows, c.N,
+                                   (const double*)t->bn_part, (rows + 31) / 32, (const float*)(t->P + c.og), (const float*)(t->P + c.obe), t->S + c.os,
+                                   t->S + c.os + c.N, c.mean, c.invstd, c.out, (float)o->bn_momentum, (float)BN_EPS);
+            } else if (rows <= BN_REGS * BN_GROUPS) {
                 hipLaunchKernelGGL(bn_train_fwd_kernel, dim3(c.N / 16), dim3(BN_THREADS), 0, s, (const float*)c.Y, rows, c.N, (const float*)(t->P + c.og),
                                    (const float*)(t->P + c.obe), t->S + c.os, t->S + c.os + c.N, c.mean, c.invstd, c.out, (float)o->bn_momentum, (float)BN_EPS);
             } else {
@@ -1205,18 +1309,36 @@ int gem_trainer_step(gem_trainer* t, int B, const float* d_pose, const float* d_
     // The chain: dOut (gradient w.r.t. a layer's output) -> BatchNorm backward -> the layer's own dY buffer -> backward-data conv ->
     // `run` = the next layer's dOut.  The layers' dY buffers (and gA, the loss gradient = the last conv's dY) stay untouched until
     // the ONE weight-gradient launch behind the chain.
+    // bn_fused: the backward-data conv of a layer forms, in its epilogue, the BatchNorm-backward sums of the layer BELOW (whose dOut it
+    // produces) and stores dz = dOut * LeakyReLU'(out) in dOut's place; that layer's BatchNorm backward is then elementwise
+    auto bwd_conv = [&](const TrainConv& c, const float* dY, float* dst, const TrainConv* below, bool* have_dz) -> int {
+        Layer L; L.taps = 3; L.K = c.N; L.N = c.K; L.w = c.adj; L.bias = nullptr;
+        CrStats st{};
+        if (below && below->bn && bn_fused) st = CrStats{t->bn_part, below->out, below->Y, below->mean, below->invstd, LEAKY_SLOPE};
+        const int rc = conv_rows(t, L.w, nullptr, dY, c.N, dst, c.K, rows, c.K, c.N, s, st);
+        if (rc > 0 || (rc < 0 && launch_gemm(h, L, EPI_NONE, dY, c.N, nullptr, dst, c.K, rows, T, s, -1))) return 1;
+        *have_dz = rc == 0 && st.part != nullptr;
+        return 0;
+    };
+    auto bn_bwd_any = [&](const float* dOut_or_dz, bool is_dz, const TrainConv& c) -> int {
+        if (!is_dz) return bn_bwd(dOut_or_dz, c, c.dY);
+        hipLaunchKernelGGL(bnf_bwd_apply_kernel, dim3(c.N / 64, (rows + 63) / 64), dim3(256), 0, s, dOut_or_dz, (const float*)c.Y, rows, c.N,
+                           (const double*)t->bn_part, (rows + 31) / 32, (const float*)(t->P + c.og), (const float*)c.mean, (const float*)c.invstd, c.dY,
+                           t->G + c.og, t->G + c.obe, t->G + c.ob);
+        GEM_HIP(hipGetLastError());
+        return 0;
+    };
     const float* dOut = t->gA;
     float* run = t->gB;
+    bool have_dz = false;
     for (int i = (int)t->dec.size() - 1; i >= 0; --i) {
         TrainConv& c = t->dec[i];
         const float* dY = dOut;
         if (c.bn) {
-            if (bn_bwd(dOut, c, c.dY)) return 1;
+            if (bn_bwd_any(dOut, have_dz, c)) return 1;
             dY = c.dY;
         }          // (no BatchNorm -- the last conv: its bias gradient, the column sums of dY, rides with the weight-gradient launch)
-        Layer L; L.taps = 3; L.K = c.N; L.N = c.K; L.w = c.adj; L.bias = nullptr;
-        { const int rc = conv_rows(t, L.w, nullptr, dY, c.N, run, c.K, rows, c.K, c.N, s);
-          if (rc > 0 || (rc < 0 && launch_gemm(h, L, EPI_NONE, dY, c.N, nullptr, run, c.K, rows, T, s, -1))) return 1; }
+        if (bwd_conv(c, dY, run, i > 0 ? &t->dec[i - 1] : nullptr, &have_dz)) return 1;
         dOut = run;
     }
     float* g = run;
@@ -1244,14 +1366,11 @@ int gem_trainer_step(gem_trainer* t, int B, const float* d_pose, const float* d_
           if (fused && linear_step(l, t->dmulv, flat)) return 1;
       } }
     // encoder
+    have_dz = false;          // (the top of the encoder chain comes out of the fc layer's backward: plain dOut)
     for (int i = (int)t->enc.size() - 1; i >= 0; --i) {
         TrainConv& c = t->enc[i];
-        if (bn_bwd(g, c, c.dY)) return 1;
-        if (i > 0) {
-            Layer L; L.taps = 3; L.K = c.N; L.N = c.K; L.w = c.adj; L.bias = nullptr;
-            { const int rc = conv_rows(t, L.w, nullptr, c.dY, c.N, g, c.K, rows, c.K, c.N, s);
-              if (rc > 0 || (rc < 0 && launch_gemm(h, L, EPI_NONE, c.dY, c.N, nullptr, g, c.K, rows, T, s, -1))) return 1; }
-        }
+        if (bn_bwd_any(g, have_dz, c)) return 1;
+        if (i > 0 && bwd_conv(c, c.dY, g, &t->enc[i - 1], &have_dz)) return 1;
     }
     // every conv layer's weight gradient (slabs of conv_slab_rows(rows) rows, or straight into the gradient arena)
     { const int rps = conv_slab_rows(rows), nslab = (rows + rps - 1) / rps;

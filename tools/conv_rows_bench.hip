@@ -45,9 +45,9 @@ static float time_lds(const float* A, const float* W, const float* b, float* C, 
     const size_t smem = (size_t)KW * D * 8192;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, grid, dim3(64 * KW), smem, 0, A, K, W, b, C, N, rows, N, K, T);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, grid, dim3(64 * KW), smem, 0, A, K, W, b, C, N, rows, N, K, T, CrStats{});
     CK(hipEventRecord(e0));
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k, grid, dim3(64 * KW), smem, 0, A, K, W, b, C, N, rows, N, K, T);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k, grid, dim3(64 * KW), smem, 0, A, K, W, b, C, N, rows, N, K, T, CrStats{});
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     return ms * 1e3f / reps;
