@@ -87,7 +87,7 @@ namespace gem {
 
 // ---- BatchNorm1d (training mode) + LeakyReLU over [rows, N]: one workgroup per 16 channels, BN_GROUPS row groups -------------
 // A thread owns channel c = lane & 15 of the rows g, g + 64, ...; BN_REGS of them live in registers, so that the statistics
-// and the normalisation need ONE trip to memory (rows <= 1024, i.e. batches up to 102 windows); longer inputs: bnl_*_kernel below.
+// and the normalisation need ONE trip to memory (rows <= 2560); longer inputs: bnl_*_kernel below.
 constexpr int BN_GROUPS = 64, BN_THREADS = 16 * BN_GROUPS, BN_REGS = 16;
 // column sums of NV per-thread values over the row groups of a workgroup: lanes of a wave that share a channel first (4 row
 // groups per wave), then the 16 waves through LDS; every thread returns the totals of its channel
@@ -185,18 +185,30 @@ __global__ __launch_bounds__(BN_THREADS) void bn_train_bwd_kernel(const float* _
 // one L1 = ~4.3 us plus the reduction, 6 / 10 us per launch.  With the per-tile sums already there (fp64, one triple per 32-row tile
 // and channel, added here in tile order: the same bits in every workgroup) the rest is elementwise: 64 channels x 64 rows per
 // workgroup, 10-80 workgroups at the reference's batch.  Same formulas as bn_train_fwd_kernel / bn_train_bwd_kernel.
-constexpr int BNF_ROWS_MAX = 1024;
+constexpr int BNF_ROWS_MAX = 2560, BNF_TILES_PER_PART = BNF_ROWS_MAX / 32 / 4;
+// totals over the row tiles for the workgroup's 64 channels: four thread groups take a quarter of the tiles each (all of a group's
+// values requested at once: as a loop of dependent round trips the same sum cost 10+ us), added in tile order, the quarters in order
 template <int NV>
 __device__ __forceinline__ void bnf_totals(const double* __restrict__ part, int nrt, int N, int c0, double (*tot)[64]) {
-    if (threadIdx.x < 64 * NV) {
-        const int ch = threadIdx.x & 63, q = threadIdx.x >> 6;
-        double v[BNF_ROWS_MAX / 32];          // every tile's value requested at once (a loop of nrt dependent round trips cost 10+ us), added in tile order
+    __shared__ double sh[NV][4][64];
+    const int ch = threadIdx.x & 63, pt = threadIdx.x >> 6;
+    const int per = (nrt + 3) / 4, t0 = pt * per, t1 = min(nrt, t0 + per);
+    double v[NV][BNF_TILES_PER_PART];          // (one round trip for everything this thread adds)
 #pragma unroll
-        for (int t = 0; t < BNF_ROWS_MAX / 32; ++t) v[t] = t < nrt ? part[((size_t)t * N + c0 + ch) * 3 + q] : 0.0;
+    for (int j = 0; j < BNF_TILES_PER_PART; ++j)
+#pragma unroll
+        for (int q = 0; q < NV; ++q) v[q][j] = t0 + j < t1 ? part[((size_t)(t0 + j) * N + c0 + ch) * 3 + q] : 0.0;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
         double sum = 0.0;
 #pragma unroll
-        for (int t = 0; t < BNF_ROWS_MAX / 32; ++t) sum += v[t];
-        tot[q][ch] = sum;
+        for (int j = 0; j < BNF_TILES_PER_PART; ++j) sum += v[q][j];
+        sh[q][pt][ch] = sum;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64 * NV) {
+        const int q = threadIdx.x >> 6;
+        tot[q][ch] = ((sh[q][0][ch] + sh[q][1][ch]) + sh[q][2][ch]) + sh[q][3][ch];
     }
     __syncthreads();
 }
