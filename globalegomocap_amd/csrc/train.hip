@@ -804,14 +804,25 @@ __global__ __launch_bounds__(DX_THREADS, 4) void gemm_tn_adam_dx_kernel(const fl
                 }
     }
 }
+// sum over slabs in slab order, eight requests in flight at a time (a plain `s += load` loop waits for every load in turn: ten
+// dependent round trips for ten slabs)
+__device__ __forceinline__ f32x4 sum_slabs(const float* __restrict__ p, int nslab, size_t stride) {
+    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int z0 = 0; z0 < nslab; z0 += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const f32x4*>(p + (size_t)min(z0 + j, nslab - 1) * stride);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (z0 + j < nslab) s = (z0 + j == 0) ? v[j] : s + v[j];
+    }
+    return s;
+}
 // G = sum over slabs, in slab order; blockIdx.y = layer (table), blockIdx.x = 1024-element chunk
 __global__ __launch_bounds__(256) void slab_sum_all_kernel(const SumDesc* __restrict__ tab, int nslab) {
     const SumDesc d = tab[blockIdx.y];
     const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= d.n) return;
-    f32x4 s = *reinterpret_cast<const f32x4*>(d.slab + i);
-    for (int zz = 1; zz < nslab; ++zz) s += *reinterpret_cast<const f32x4*>(d.slab + (size_t)zz * d.n + i);
-    *reinterpret_cast<f32x4*>(d.out + i) = s;
+    *reinterpret_cast<f32x4*>(d.out + i) = sum_slabs(d.slab + i, nslab, d.n);
 }
 
 // dY [B][N] -> dY^T [N][Bp] (columns >= B zero): the row-major operand the rows-contracting kernel wants for the backward-data
@@ -842,9 +853,7 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restr
 __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slab, int nslab, size_t n_slab_elems, float* __restrict__ out, size_t n_out) {
     const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= n_out) return;
-    f32x4 s = *reinterpret_cast<const f32x4*>(slab + i);
-    for (int z = 1; z < nslab; ++z) s += *reinterpret_cast<const f32x4*>(slab + (size_t)z * n_slab_elems + i);
-    *reinterpret_cast<f32x4*>(out + i) = s;
+    *reinterpret_cast<f32x4*>(out + i) = sum_slabs(slab + i, nslab, n_slab_elems);
 }
 
 // adjoint images for the backward-data products of every CONV layer in one launch (the two linear layers -- 97 % of the parameters
