@@ -499,13 +499,15 @@ def fit_vae_device(shape, windows, steps=2000, batch=128, lr=2e-3, kl_weight=0.0
         g = torch.Generator(device="cpu").manual_seed(seed)
         # torch.optim.lr_scheduler.OneCycleLR defaults: 30 % cosine warm-up from max_lr / 25, cosine decay to max_lr / 25e4
         up = float(int(0.3 * steps) - 1)
+        # (every step's batch indices in ONE upload: a per-step host-to-device copy is a synchronisation point that keeps the host from
+        # enqueueing ahead of the 0.8 ms steps)
+        idx_all = torch.randint(0, data.shape[0], (steps, batch), generator=g).to(tr.device)
         for it in range(steps):
             if it <= up:
                 tr.opts.lr = lr / 25 + (lr - lr / 25) * 0.5 * (1 - math.cos(math.pi * it / max(up, 1.0)))
             else:
                 tr.opts.lr = lr / 25e4 + (lr - lr / 25e4) * 0.5 * (1 + math.cos(math.pi * (it - up) / max(steps - 1 - up, 1.0)))
-            idx = torch.randint(0, data.shape[0], (batch,), generator=g).to(tr.device)
-            tr.step(data[idx], kl_weight, sync=False)
+            tr.step(data[idx_all[it]], kl_weight, sync=False, keep_gradients=False)
         sd = tr.state_dict()
         from .engine import WindowEngine
         eng = WindowEngine(shape, max_windows=256, device=tr.device.index)
