@@ -103,6 +103,7 @@ int main(int argc, char** argv) {
         run<4>(640, sh[0], sh[1], 10, reps);
         run<8>(640, sh[0], sh[1], 10, reps);
     }
-    run<4>(230, 128, 192, 10, reps);          // ragged rows
+    run<2>(230, 128, 192, 10, reps);          // ragged rows, three chunks per tap and wave
+    run<4>(1270, 64, 384, 10, reps);          // ragged rows, three chunks per tap and wave, four waves
     return 0;
 }
