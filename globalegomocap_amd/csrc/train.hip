@@ -960,11 +960,7 @@ static int launch_conv_rows(const dim3& grid, const float* W, const float* bias,
                             hipStream_t s, const CrStats& st) {
     auto k = conv_rows_lds_kernel<KW, D>;
     constexpr size_t smem = std::max((size_t)KW * D * 8192, (size_t)KW * 4096 + CR_STATS_LDS);
-    static bool attr_set = false;          // (the trainer is driven from one host thread)
-    if (smem > 64 * 1024 && !attr_set) {
-        GEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_set = true;
-    }
+    static_assert(smem <= 64 * 1024, "beyond 64 KB of dynamic LDS the kernel needs hipFuncAttributeMaxDynamicSharedMemorySize");
     hipLaunchKernelGGL(k, grid, dim3(64 * KW), smem, s, A, lda, W, bias, C, ldc, rows, N, K, T, st);
     GEM_HIP(hipGetLastError());
     return 0;
