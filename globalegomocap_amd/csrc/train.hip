@@ -77,7 +77,7 @@ struct gem_trainer {
     double* red = nullptr;         // [8 + partial sums]: [4..6] loss, recon, kld; [8..) per-block partials of the two loss kernels
     gem::AdjDesc* adj_tab = nullptr; int n_adj = 0, adj_tiles = 0;
     gem::SumDesc* sum_tab = nullptr; int n_sum = 0; size_t sum_max = 0;
-    void* tn_tab = nullptr; int n_tn = 0, tn_tiles = 0;      // gemm_tn3_all_kernel's layer table (TnDesc)
+    void* tn_tab = nullptr; int n_tn = 0, tn_tiles = 0;      // the weight-gradient launch's layer table (TnTable, host copy: passed by value)
     int part_recon = 0, part_latent = 0;       // capacity of the partial-sum regions
     long step = 0;
     std::vector<void*> allocs;
@@ -509,9 +509,11 @@ struct StepTail {
 __device__ __forceinline__ void finish_loss(const StepTail& t) {
     __shared__ double sh[2][256];
     double a = 0.0, b = 0.0;
-    for (int i = threadIdx.x; i < t.n_recon_parts; i += 256) a += t.part_recon[i];
-    for (int i = threadIdx.x; i < t.n_latent_parts; i += 256) b += t.part_latent[i];
-    sh[0][threadIdx.x] = a; sh[1][threadIdx.x] = b;
+    if (threadIdx.x < 256) {          // (the first 256 threads of the workgroup; the others only join the barrier)
+        for (int i = threadIdx.x; i < t.n_recon_parts; i += 256) a += t.part_recon[i];
+        for (int i = threadIdx.x; i < t.n_latent_parts; i += 256) b += t.part_latent[i];
+        sh[0][threadIdx.x] = a; sh[1][threadIdx.x] = b;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         a = 0.0; b = 0.0;
@@ -525,8 +527,18 @@ __device__ __forceinline__ void colsum16(const StepTail& t, int group, int rows)
     __shared__ double sh[16][17];
     const int c = group * 16 + (threadIdx.x & 15), g = threadIdx.x >> 4;
     double v = 0.0;
-    for (int r = g; r < rows; r += 16) v += t.cs_src[(size_t)r * t.cs_N + c];
-    sh[g][threadIdx.x & 15] = v;
+    if (g < 16) {
+        // eight rows requested at a time (as `v += load` this loop is a chain of rows / 16 dependent round trips: 40 at the
+        // reference's batch = 30 us, which WAS the duration of the whole weight-gradient launch)
+        for (int r0 = g; r0 < rows; r0 += 128) {
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = t.cs_src[(size_t)min(r0 + 16 * j, rows - 1) * t.cs_N + c];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (r0 + 16 * j < rows) v += x[j];
+        }
+        sh[g][threadIdx.x & 15] = v;
+    }
     __syncthreads();
     if (g == 0) {
         double sum = 0.0;
@@ -538,8 +550,12 @@ __device__ __forceinline__ void colsum16(const StepTail& t, int group, int rows)
 // every conv layer's weight gradient in ONE launch (they wait for nothing but their layer's dY, and nothing but Adam waits for
 // them: eleven launches of ~6 us at the reference's batch otherwise): blockIdx.x walks the layers' tiles (table), y = tap, z = slab
 struct TnDesc { const float* dC; const float* A; float* slab; float* g; int N, K, tile0; };
-__global__ __launch_bounds__(256) void gemm_tn3_all_kernel(const TnDesc* __restrict__ tab, int n_layers, int n_tiles, int rows, int T, int rps, int nslab,
-                                                           const StepTail tail) {
+// (the table travels BY VALUE in the kernel arguments: found through global memory, the walk to a workgroup's layer was a chain of up
+// to eleven dependent loads, ~10 us in front of the last layers' workgroups)
+constexpr int TN_MAX_LAYERS = 16;
+struct TnTable { TnDesc d[TN_MAX_LAYERS]; int n; };
+__global__ __launch_bounds__(256) void gemm_tn3_all_kernel(const TnTable tabv, int n_tiles, int rows, int T, int rps, int nslab, const StepTail tail) {
+    const TnDesc* tab = tabv.d; const int n_layers = tabv.n;
     if ((int)blockIdx.x >= n_tiles) {
         if (blockIdx.y == 0 && blockIdx.z == 0) {
             if ((int)blockIdx.x == n_tiles) finish_loss(tail);
@@ -1180,10 +1196,11 @@ int gem_trainer_create(const gem_config* cfg, gem_trainer** out) {
               tn.push_back(TnDesc{c.bn ? c.dY : p->gA, a_in, c.slab, p->G + c.ow, c.N, c.K, tile0});      // (no BatchNorm: the loss gradient itself, in gA)
               tile0 += (c.N / 64) * (c.K / 64);
           }
-      TnDesc* dev = nullptr;
-      if (talloc(p, &dev, tn.size())) return 1;
-      GEM_HIP(hipMemcpy(dev, tn.data(), tn.size() * sizeof(TnDesc), hipMemcpyHostToDevice));
-      p->tn_tab = dev; p->n_tn = (int)tn.size(); p->tn_tiles = tile0; }
+      if (tn.size() > (size_t)TN_MAX_LAYERS) { set_error("train: more conv layers than the weight-gradient table holds"); return 1; }
+      TnTable* tv = new TnTable();
+      for (size_t i = 0; i < tn.size(); ++i) tv->d[i] = tn[i];
+      tv->n = (int)tn.size();
+      p->tn_tab = tv; p->n_tn = (int)tn.size(); p->tn_tiles = tile0; }
     *out = t.release();
     return 0;
 }
@@ -1192,6 +1209,7 @@ void gem_trainer_destroy(gem_trainer* t) {
     if (!t) return;
     if (t->h) { (void)hipSetDevice(t->h->cfg.device); (void)hipDeviceSynchronize(); }
     for (void* p : t->allocs) (void)hipFree(p);
+    delete static_cast<gem::TnTable*>(t->tn_tab);
     if (t->h) gem_destroy(t->h);
     delete t;
 }
@@ -1389,18 +1407,21 @@ int gem_trainer_step(gem_trainer* t, int B, const float* d_pose, const float* d_
         if (bn_bwd_any(g, have_dz, c)) return 1;
         if (i > 0 && bwd_conv(c, c.dY, g, &t->enc[i - 1], &have_dz)) return 1;
     }
-    // every conv layer's weight gradient (slabs of conv_slab_rows(rows) rows, or straight into the gradient arena)
-    { const int rps = conv_slab_rows(rows), nslab = (rows + rps - 1) / rps;
-      if (nslab > 1 && t->n_sum != t->n_tn) { set_error("train: weight-gradient slabs missing"); return 1; }
-      const TrainConv& last = t->dec.back();
+    // every conv layer's weight gradient (slabs of conv_slab_rows(rows) rows, or straight into the gradient arena).  Measured and not
+    // kept: the same tiles with the rows split over the eight waves of a 512-thread workgroup instead of over the grid (wave-private
+    // LDS-DMA staging, no slabs, no slab sum): 267 workgroups on 256 CUs -- a CU that gets two of them takes twice as long, 31 us
+    // against 25 + 10.6 for this launch and its slab sum at batch 64, 3.34 against 3.21 ms per step at batch 1024
+    { const TrainConv& last = t->dec.back();
       StepTail tail{part_recon, part_latent, t->red + 4, d_losses, n_recon, o->kld_weight, n_pr, n_pl, B, t->gA, t->G + last.ob, last.N};
-      hipLaunchKernelGGL(gemm_tn3_all_kernel, dim3(t->tn_tiles + 1 + last.N / 16, 3, nslab), dim3(256), 0, s, (const TnDesc*)t->tn_tab, t->n_tn, t->tn_tiles,
+      const int rps = conv_slab_rows(rows), nslab = (rows + rps - 1) / rps;
+      if (nslab > 1 && t->n_sum != t->n_tn) { set_error("train: weight-gradient slabs missing"); return 1; }
+      hipLaunchKernelGGL(gemm_tn3_all_kernel, dim3(t->tn_tiles + 1 + last.N / 16, 3, nslab), dim3(256), 0, s, *static_cast<const TnTable*>(t->tn_tab), t->tn_tiles,
                          rows, T, rps, nslab, tail);
       GEM_HIP(hipGetLastError()); }
-    // the weight-gradient slabs -> the gradient arena (slab order: deterministic)
+    // weight-gradient slabs -> the gradient arena (slab order: deterministic)
     { const int ns_conv = (rows + conv_slab_rows(rows) - 1) / conv_slab_rows(rows), ns_lin = (B + TN_ROWS_LINEAR - 1) / TN_ROWS_LINEAR;
-      // (every conv layer's weight_grad<3> call above cut the same `rows` into slabs of TN_ROWS_CONV rows: ONE slab count serves
-      // the whole table; the two linear layers' entries sit behind the conv entries)
+      // (every conv layer's entry was cut into the same slabs of conv_slab_rows(rows) rows: ONE slab count serves the whole table; the two
+      // linear layers' entries sit behind the conv entries)
       if (ns_conv > 1 && t->n_sum > 0) {
           hipLaunchKernelGGL(slab_sum_all_kernel, dim3((unsigned)((t->sum_max / 4 + 255) / 256), t->n_sum), dim3(256), 0, s, (const SumDesc*)t->sum_tab, ns_conv);
           GEM_HIP(hipGetLastError());
