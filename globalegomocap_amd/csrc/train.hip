@@ -841,6 +841,39 @@ __global__ __launch_bounds__(256) void slab_sum_all_kernel(const SumDesc* __rest
     *reinterpret_cast<f32x4*>(d.out + i) = sum_slabs(d.slab + i, nslab, d.n);
 }
 
+// The fc layer's dX (= dOut of the encoder's last block, [rows][N] with N = the block's channels) summed from the strips' slabs of
+// gemm_tn_adam_dx_kernel in 32 x 32 tiles, with that block's BatchNorm-backward sums formed on the way exactly as a backward-data
+// conv's epilogue forms them (conv_rows.h, CrStats backward flavour: dz stored, sums of dz, dz xhat, xhat per tile and channel):
+// slab_sum_kernel and the statistics half of bn_train_bwd_kernel in one launch.
+__global__ __launch_bounds__(256) void dx_sum_stats_kernel(const float* __restrict__ slab, int nslab, size_t stride, float* __restrict__ dz_out, int rows, int N,
+                                                           const CrStats st) {
+    __shared__ __attribute__((aligned(16))) float sv[2][32][32];
+    const int tid = threadIdx.x, m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int i = tid >> 3, j4 = (tid & 7) * 4;
+    const bool in = m0 + i < rows;
+    const size_t at = (size_t)(in ? m0 + i : 0) * N + n0 + j4;
+    const f32x4 sum = sum_slabs(slab + at, nslab, stride);
+    const f32x4 o4 = *reinterpret_cast<const f32x4*>(st.out + at), y4 = *reinterpret_cast<const f32x4*>(st.Y + at);
+    const f32x4 mf = *reinterpret_cast<const f32x4*>(st.mean + n0 + j4), is = *reinterpret_cast<const f32x4*>(st.invstd + n0 + j4);
+    f32x4 dz, xh;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        dz[q] = in ? sum[q] * (o4[q] > 0.f ? 1.f : st.slope) : 0.f;
+        xh[q] = in ? (y4[q] - mf[q]) * is[q] : 0.f;
+    }
+    if (in) *reinterpret_cast<f32x4*>(dz_out + at) = dz;
+    *reinterpret_cast<f32x4*>(&sv[0][i][j4]) = dz;
+    *reinterpret_cast<f32x4*>(&sv[1][i][j4]) = xh;
+    __syncthreads();
+    if (tid < 32) {
+        double a = 0.0, b = 0.0, c = 0.0;
+#pragma unroll 8
+        for (int r = 0; r < 32; ++r) { const float d = sv[0][r][tid], x = sv[1][r][tid]; a += d; b += (double)d * x; c += x; }
+        double* p = st.part + ((size_t)blockIdx.x * N + n0 + tid) * 3;
+        p[0] = a; p[1] = b; p[2] = c;
+    }
+}
+
 // dY [B][N] -> dY^T [N][Bp] (columns >= B zero): the row-major operand the rows-contracting kernel wants for the backward-data
 // product of a linear layer, dX[b][k] = sum_n dY[b][n] W[n][k], taken straight from W's own [N][K] layout (linear_bwd_data)
 // colsum != nullptr (one row tile only, Bp == 64): also the layer's bias gradient sum_b dY[b][n] (an fp64 sum of at most 64 fp32
@@ -913,8 +946,11 @@ __global__ __launch_bounds__(LOSS_BLOCK) void recon_loss_kernel(const float* __r
 }
 
 // latent: KL term and the gradient w.r.t. [mu | logvar] from dz (decoder side) + the KL term (SeqConvVAE.py:159-169, 206-213)
+// (nslab > 0: dz arrives as the strips' slabs of gemm_tn_adam_dx_kernel, [nslab][64][Dp], and is summed here in slab order -- what
+// slab_sum_kernel would do in a launch of its own)
 __global__ __launch_bounds__(LOSS_BLOCK) void latent_bwd_kernel(const float* __restrict__ mulv, const float* __restrict__ eps, const float* __restrict__ dz,
-                                                                int B, int D, int Dp, float kw_over_B, float* __restrict__ dmulv, double* __restrict__ part) {
+                                                                int B, int D, int Dp, float kw_over_B, float* __restrict__ dmulv, double* __restrict__ part,
+                                                                int nslab, size_t slab_stride) {
     const size_t i = (size_t)blockIdx.x * LOSS_BLOCK + threadIdx.x;
     double s = 0.0;
     if (i < (size_t)B * Dp) {
@@ -922,7 +958,18 @@ __global__ __launch_bounds__(LOSS_BLOCK) void latent_bwd_kernel(const float* __r
         float dmu = 0.f, dlv = 0.f;
         if (d < D) {
             const float mu = mulv[(size_t)b * 2 * Dp + d], lv = mulv[(size_t)b * 2 * Dp + Dp + d];
-            const float ev = expf(lv), g = dz[i];
+            float g;
+            if (nslab > 0) {
+                g = 0.f;
+                for (int z0 = 0; z0 < nslab; z0 += 8) {          // (eight slab requests in flight; slab order)
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = dz[(size_t)min(z0 + j, nslab - 1) * slab_stride + i];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) if (z0 + j < nslab) g = (z0 + j == 0) ? v[j] : g + v[j];
+                }
+            } else g = dz[i];
+            const float ev = expf(lv);
             s = (double)(1.f + lv - mu * mu - ev);
             dmu = g + kw_over_B * mu;
             dlv = g * eps[(size_t)b * D + d] * 0.5f * expf(0.5f * lv) + kw_over_B * 0.5f * (ev - 1.f);
@@ -1104,6 +1151,7 @@ static int linear_fused_backward(gem_trainer* t, const TrainLinear& l, int tps, 
     hipLaunchKernelGGL(gemm_tn_adam_dx_kernel, dim3((l.K / 64) * nstrip), dim3(DX_THREADS), 0, s, dY, A, B, l.N, l.K, tps, t->P + l.ow, t->M1 + l.ow, t->M2 + l.ow, ad,
                        t->dx_slab, t->G + l.ob);
     GEM_HIP(hipGetLastError());
+    if (!dX) return 0;          // (the consumer sums the nstrip slabs itself: latent_bwd_kernel)
     const size_t n_out = (size_t)B * l.K;
     hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((n_out / 4 + 255) / 256)), dim3(256), 0, s, (const float*)t->dx_slab, nstrip, (size_t)64 * l.K, dX, n_out);
     GEM_HIP(hipGetLastError());
@@ -1378,30 +1426,41 @@ int gem_trainer_step(gem_trainer* t, int B, const float* d_pose, const float* d_
     }
     float* g = run;
     // g = dh0 [B, T*topp]: decoder_input
+    int dz_slabs = 0;          // > 0: dz is left as that many slabs for latent_bwd_kernel
+    bool enc_top_dz = false;
     { const TrainLinear& l = t->dec_in;
       const int tps = fused ? fused_backward_strip(t, l, B) : 0;
-      if (tps) { if (linear_fused_backward(t, l, tps, g, t->z, t->dz, B, ad, s)) return 1; }
+      if (tps) { if (linear_fused_backward(t, l, tps, g, t->z, nullptr, B, ad, s)) return 1; dz_slabs = l.N / 64 / tps; }
       else {
           if (!fused && weight_grad<1>(t, g, l.N, t->z, l.K, B, l.N, l.K, l.ow, l.slab, TN_ROWS_LINEAR, s)) return 1;
           if (linear_bwd_data(t, g, t->P + l.ow, t->dz, B, l.N, l.K, s, t->G + l.ob)) return 1;
           if (fused && linear_step(l, g, t->z)) return 1;          // (behind the backward-data product: it reads the weights)
       } }
-    hipLaunchKernelGGL(latent_bwd_kernel, dim3(n_pl), dim3(LOSS_BLOCK), 0, s, (const float*)t->mulv, d_eps, (const float*)t->dz, B, t->D, t->Dp,
-                       (float)(o->kld_weight / B), t->dmulv, part_latent);
+    hipLaunchKernelGGL(latent_bwd_kernel, dim3(n_pl), dim3(LOSS_BLOCK), 0, s, (const float*)t->mulv, d_eps, dz_slabs ? (const float*)t->dx_slab : (const float*)t->dz, B,
+                       t->D, t->Dp, (float)(o->kld_weight / B), t->dmulv, part_latent, dz_slabs, (size_t)64 * t->dec_in.K);
     GEM_HIP(hipGetLastError());
     // fc_mu | fc_var
     { const TrainLinear& l = t->fc;
       const float* flat = t->enc.back().out;
       // (g = gB again: decoder_input's backward above has consumed dh0; gA still holds the last conv's dY)
       const int tps = fused ? fused_backward_strip(t, l, B) : 0;
-      if (tps) { if (linear_fused_backward(t, l, tps, t->dmulv, flat, g, B, ad, s)) return 1; }
+      const TrainConv& top = t->enc.back();
+      if (tps && bn_fused && top.N % 32 == 0 && l.K == T * top.N) {
+          // dX = dOut of the encoder's last block: summed from the slabs together with that block's BatchNorm-backward sums
+          if (linear_fused_backward(t, l, tps, t->dmulv, flat, nullptr, B, ad, s)) return 1;
+          const CrStats st{t->bn_part, top.out, top.Y, top.mean, top.invstd, LEAKY_SLOPE};
+          hipLaunchKernelGGL(dx_sum_stats_kernel, dim3((rows + 31) / 32, top.N / 32), dim3(256), 0, s, (const float*)t->dx_slab, l.N / 64 / tps, (size_t)64 * l.K, g,
+                             rows, top.N, st);
+          GEM_HIP(hipGetLastError());
+          enc_top_dz = true;
+      } else if (tps) { if (linear_fused_backward(t, l, tps, t->dmulv, flat, g, B, ad, s)) return 1; }
       else {
           if (!fused && weight_grad<1>(t, t->dmulv, l.N, flat, l.K, B, l.N, l.K, l.ow, l.slab, TN_ROWS_LINEAR, s)) return 1;
           if (linear_bwd_data(t, t->dmulv, t->P + l.ow, g, B, l.N, l.K, s, t->G + l.ob)) return 1;
           if (fused && linear_step(l, t->dmulv, flat)) return 1;
       } }
     // encoder
-    have_dz = false;          // (the top of the encoder chain comes out of the fc layer's backward: plain dOut)
+    have_dz = enc_top_dz;          // (the top of the encoder chain comes out of the fc layer's backward: dz with the sums, or plain dOut)
     for (int i = (int)t->enc.size() - 1; i >= 0; --i) {
         TrainConv& c = t->enc[i];
         if (bn_bwd_any(g, have_dz, c)) return 1;
