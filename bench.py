@@ -45,13 +45,17 @@ def parse():
     p.add_argument("--lanes", type=int, default=None, help="gem_set_lanes: batches of at least this many windows run as two half-batches "
                    "half a round apart (0 = one lane always = the library default)")
     p.add_argument("--windows", type=int, default=0, help="configs3 / configs4: total number of windows (default 65536 / 12499)")
-    p.add_argument("--block", type=int, default=64, help="configs4: windows per block of the block-cyclic shards")
+    p.add_argument("--block", type=int, default=32, help="configs4: windows per block of the block-cyclic shards")
     p.add_argument("--emulate-ranks", type=int, default=0, help="configs3 / configs4 with --gpus 1: run the shards of N ranks one after "
                    "the other in this process (same shards, same calls, no collective): the reference the multi-rank result must equal bitwise")
     p.add_argument("--dump", default=None, help="configs3 / configs4: rank 0 saves the gathered poses (and the merged sequence) to this .npz")
     p.add_argument("--fit-steps", type=int, default=2000, help="Adam steps to fit the synthetic VAEs (untimed)")
     p.add_argument("--cpu-windows", type=int, default=12, help="windows of the CPU baseline sample (0 = skip)")
     p.add_argument("--no-extra", action="store_true", help="skip the bf16x3 / bf16 side measurements")
+    p.add_argument("--in-flight", action="store_true", help="also measure 1-3 sequences in flight on separate streams, eager and graph replay "
+                   "(`sequences_in_flight`; twelve entries, off by default to keep the line short)")
+    p.add_argument("--no-partition", action="store_true", help="skip the full-size 8-way partitions of configs[3] / configs[4] (`partition8`)")
+    p.add_argument("--full-record", default=None, help="also write the whole JSON line, indented, to this file")
     p.add_argument("--no-profile", action="store_true", help="no HIP-event timing of the dominant kernel")
     p.add_argument("--precision", default=None, choices=["f32", "bf16x3", "bf16"],
                    help="arithmetic of the wide decoder/encoder products (f32 = BASELINE configs[1])")
@@ -115,7 +119,7 @@ def cpu_baseline(sd_local, sd_global, cam, seqd, starts, mean_bone, eps_l, eps_g
     return np.asarray(out), dt, nthreads
 
 
-def committed_traffic(kernel_names, windows, precision):
+def committed_traffic(kernel_names, windows, precision, with_mfma=False):
     """HBM bytes per launch of the named kernels from the committed rocprofv3 --pmc summaries (profiles/traffic_r*.json: FETCH_SIZE x 2
     on gfx950 + WRITE_SIZE, separate passes -- MI355X_MICROARCH.md section HBM), dispatch-weighted over the names.  Only a file
     collected on THIS workload (same window count and precision: its `workload` header, or -- files of rounds 1-3 -- its name)
@@ -149,9 +153,54 @@ def committed_traffic(kernel_names, windows, precision):
         if len(hit) == len(names) and hit:
             disp = sum(h["dispatches"] for h in hit)
             tot = sum((h["read_bytes_corrected"] + h["write_bytes"]) * h["dispatches"] for h in hit)
-            return int(tot / disp), "profiles/%s (committed rocprofv3 --pmc passes of this workload: %d windows, %s; not measured in this run)" % (
-                os.path.basename(path), wn, wp)
-    return None, None
+            src = "profiles/%s (committed --pmc passes, %d windows %s)" % (os.path.basename(path), wn, wp)
+            if with_mfma:
+                mf = None
+                if all("mfma_busy_cycles" in h for h in hit):
+                    dm = sum(h.get("mfma_dispatches", h["dispatches"]) for h in hit)
+                    mf = {"busy": sum(h["mfma_busy_cycles"] * h.get("mfma_dispatches", h["dispatches"]) for h in hit) / dm,
+                          "active": sum(h["gui_active_cycles"] * h.get("mfma_dispatches", h["dispatches"]) for h in hit) / dm}
+                return int(tot / disp), src, mf
+            return int(tot / disp), src
+    return (None, None, None) if with_mfma else (None, None)
+
+
+SIMDS = 1024                                        # 256 CUs x 4
+FLOP_PER_SIMD_CYCLE = {"f32": PEAK_F32_MATRIX_TFLOPS * 1e12 / (SIMDS * 2.4e9), "bf16": PEAK_BF16_MATRIX_TFLOPS * 1e12 / (SIMDS * 2.4e9)}
+
+
+def mfma_busy_record(mf, avg_us, flop_per_launch, operand):
+    """SQ_VALU_MFMA_BUSY_CYCLES of the committed PMC pass (summed over the 1024 SIMDs, per launch) beside this run's timing:
+    `counter_over_flop` = counter / (FLOP per launch / FLOP per SIMD-cycle of the MFMA shape) -- 1.0 means the counter and the FLOP
+    count agree (above 1: padded tiles); `frac_at_peak_clock` = busy cycles per SIMD / (this run's average duration x 2.4 GHz),
+    the counter's version of FLOP / time / peak; `frac_of_active_cycles` = busy / (1024 x GRBM_GUI_ACTIVE / 8) of the same PMC
+    pass: utilisation at the clock the chip really held (the profiled dispatch adds ~15-20 k cycles, so it reads low for launches
+    under ~50 us)."""
+    if not mf:
+        return None
+    exp = flop_per_launch / FLOP_PER_SIMD_CYCLE[operand]
+    return {"busy_simd_cycles_per_launch": round(mf["busy"]), "counter_over_flop": round(mf["busy"] / exp, 3) if exp > 0 else None,
+            "frac_at_peak_clock": round(mf["busy"] / SIMDS / (avg_us * 2400.0), 4),
+            "frac_of_active_cycles": round(mf["busy"] / (SIMDS * mf["active"]), 4)}
+
+
+# SURVEY.md 8d, per stage with E evaluations: encoder + E x (decoder forward + backward-data) + the final decode, dense counts of the
+# reference's layers (decoder 15 978 880 multiply-adds, encoder 26 341 760).  EXECUTED: decoder_input and the first decoder conv run as
+# one composed [2048 -> 10 x 256] layer (2 x 2048 x 2560 flop) in front of the narrow convs (10 x 3 x 52 032 multiply-adds).
+F_ENC, F_DEC = 2 * 26341760, 2 * 15978880
+F_DEC_EXEC = 2 * 2048 * 2560 + 2 * 30 * (256 * 128 + 128 * 64 + 64 * 64 + 64 * 64 + 64 * 45)
+
+
+def path_roofline(windows_per_s, e_local, e_global, precision):
+    """The path-level roofline of SURVEY.md 8d: windows/s x F_window(measured mean evaluations per stage) / matrix peak."""
+    alg = sum(F_ENC + 2 * F_DEC * e + F_DEC for e in (e_local, e_global))
+    exe = sum(F_ENC + 2 * F_DEC_EXEC * e + F_DEC_EXEC for e in (e_local, e_global))
+    peak = PEAK_BF16_MATRIX_TFLOPS if precision == "bf16" else PEAK_F32_MATRIX_TFLOPS
+    return {"evals_per_stage": [round(float(e_local), 2), round(float(e_global), 2)],
+            "flop_per_window_algorithmic": int(alg), "flop_per_window_executed": int(exe),
+            "achieved_tflops": round(windows_per_s * alg / 1e12, 2), "frac": round(windows_per_s * alg / 1e12 / peak, 4),
+            "executed_tflops": round(windows_per_s * exe / 1e12, 2), "frac_executed": round(windows_per_s * exe / 1e12 / peak, 4),
+            "peak": peak, "unit": "TFLOP/s"}
 
 
 def kernel_bound(names):
@@ -190,9 +239,14 @@ def run_sharded(a, world, rank, device, rehearsal, sd_local, sd_global, vae_note
       halo between blocks that went to different ranks); every call after the second is one hipGraph replay;
       `all_gather_indexed` restores window order, then overlap-merge + final smoothing (optimizer.py:425-450) of the gathered
       sequence on the device.
-    The timed step = optimise the shard + the collective (+ merge for configs4); value = n windows / step time.
-    emit=False: rank 0 returns the record instead of printing it (the side records of the default multi-rank line), the process
-    group stays up."""
+    Real ranks (world > 1): the timed step = optimise the shard + the collective (+ merge for configs4); value = n windows / step time.
+    --emulate-ranks N on one card: the N shards are built, warmed, timed and FREED one after the other (one shard of 8192 windows
+      holds 16 GB of heat-maps: only one is resident at a time), every shard exactly as its rank would run it; then the placement by
+      index (what the all-gather does) and the merge are timed.  `value` = n windows / (sum of the shard times + placement + merge):
+      what this ONE card did.  `partition` reports per emulated rank windows, frames held, evaluations and time, the imbalance
+      max/mean of both, and `projected_8gpu_windows_per_s` = n / (max_r t_r + placement + merge) -- a PROJECTION of the N-GPU job
+      from one card's shard times (the RCCL all-gather of 1.8 KB per window is not in it), not a measurement.
+    emit=False: rank 0 returns the record instead of printing it (side records of the default line), the process group stays up."""
     import torch
     import torch.distributed as dist
     from globalegomocap_amd import synth, vae as vae_schema
@@ -203,8 +257,9 @@ def run_sharded(a, world, rank, device, rehearsal, sd_local, sd_global, vae_note
     stream = a.workload == "configs4"
     n_total = a.windows or (12499 if stream else 65536)
     block = a.block if stream else None
-    vworld = a.emulate_ranks if (a.emulate_ranks and world == 1) else world
-    my_ranks = list(range(vworld)) if vworld != world else [rank]
+    emulated = bool(a.emulate_ranks and world == 1)
+    vworld = a.emulate_ranks if emulated else world
+    my_ranks = list(range(vworld)) if emulated else [rank]
     shape = vae_schema.VAEShape()
     cam = FisheyeCamera.from_json(DEFAULT_CALIBRATION)
     T, stride = shape.seq_len, 8
@@ -220,19 +275,20 @@ def run_sharded(a, world, rank, device, rehearsal, sd_local, sd_global, vae_note
     wl = (0.01 / 10000, 0.001 / 100, 0.01, 0.0, 0.01)
     wg = (0.01, 0.001, 0.01, 0.0, 0.0)
     w_local, w_global = energy_weights(*wl), energy_weights(*wg)
-    shards = {}
-    gt_all = None
+    pose_shape = (T, 15, 3)
+    host_stream = None
     if stream:
         n_frames = stride * (n_total - 1) + T
         starts = (stride * np.arange(n_total)).astype(np.int64)
         eps_all = torch.randn(n_total, 2, shape.latent_dim, generator=torch.Generator().manual_seed(654))
-    for r in my_ranks:
+        host_stream = synth.make_sequence(n_frames, 6000, cam, with_heatmaps=False, cam_jitter=CAM_JITTER)    # same stream on every rank
+
+    def build_shard(r):
         idx = idx_of[r]
         nb = len(idx)
         if stream:
             runs, local0 = frame_runs(starts, idx, T)
-            d = synth.make_stream_device(n_frames, 6000, device, runs=runs, camera=cam, cam_jitter=CAM_JITTER)
-            gt_all = d["gt_global"]
+            d = synth.make_stream_device(n_frames, 6000, device, runs=runs, camera=cam, cam_jitter=CAM_JITTER, host=host_stream)
             mbv = eng.mean_bone_length(d["est_all_np"].astype(np.float32))       # one sequence: one mean bone length (all ranks: same stream)
             eps = eps_all[torch.as_tensor(idx, dtype=torch.long)] if nb else eps_all[:0]
         else:
@@ -240,71 +296,156 @@ def run_sharded(a, world, rank, device, rehearsal, sd_local, sd_global, vae_note
             local0 = (stride * np.arange(nb)).astype(np.int32)
             mbv = eng.mean_bone_length(d["est_local"])
             eps = torch.randn(nb, 2, shape.latent_dim, generator=torch.Generator().manual_seed(7000 + r))
-        shards[r] = dict(d=d, idx=idx, f0=torch.as_tensor(local0, dtype=torch.int32, device=device),
-                         mb=mbv.reshape(1, 15).expand(nb, 15).contiguous(), el=eps[:, 0].contiguous().to(device),
-                         eg=eps[:, 1].contiguous().to(device), frames_held=int(d["heat"].shape[0]))
-    del eps
-    pose_shape = (T, 15, 3)
+        return dict(d=d, idx=idx, f0=torch.as_tensor(local0, dtype=torch.int32, device=device),
+                    mb=mbv.reshape(1, 15).expand(nb, 15).contiguous(), el=eps[:, 0].contiguous().to(device),
+                    eg=eps[:, 1].contiguous().to(device), frames_held=int(d["heat"].shape[0]))
 
-    def step():
-        outs = {}
+    def run_shard(sh):
+        if len(sh["idx"]) == 0:
+            return torch.zeros((0,) + pose_shape, dtype=torch.float64, device=device), None
+        _, glob, stats = eng.optimize_windows(sh["d"]["est_local"], sh["d"]["cams"], sh["d"]["heat"], sh["f0"], sh["mb"], sh["el"], sh["eg"],
+                                              w_local, w_global, want_stats=True)
+        return glob, stats
+
+    def place(outs_by_rank, dtype=torch.float64, trailing=pose_shape):
+        """Emulated ranks: the placement by window index that the all-gather performs, without a collective."""
+        full = torch.empty((n_total,) + trailing, dtype=dtype, device=device)
         for r in my_ranks:
-            sh = shards[r]
-            if len(sh["idx"]) == 0:
-                outs[r] = (torch.zeros((0,) + pose_shape, dtype=torch.float64, device=device), None)
-                continue
-            mid, glob, stats = eng.optimize_windows(sh["d"]["est_local"], sh["d"]["cams"], sh["d"]["heat"], sh["f0"], sh["mb"], sh["el"], sh["eg"],
-                                                    w_local, w_global, want_stats=True)
-            outs[r] = (glob.clone() if len(my_ranks) > 1 else glob, stats.clone() if len(my_ranks) > 1 else stats)
-        if world > 1:          # the one collective of the path
-            full = all_gather_indexed(outs[rank][0], n_total, block) if stream else all_gather_windows(outs[rank][0], n_total)
-        elif vworld > 1:       # emulated ranks: the same placement by index, no collective
-            full = torch.empty((n_total,) + pose_shape, dtype=torch.float64, device=device)
-            for r in my_ranks:
-                if len(idx_of[r]):
-                    full[torch.as_tensor(idx_of[r], dtype=torch.long, device=device)] = outs[r][0]
-        else:
-            full = outs[rank][0]
-        merged = eng.merge_windows(full, 1, overlap=T - stride, smooth=True) if stream else None
-        return full, merged, outs
+            if len(idx_of[r]):
+                full[torch.as_tensor(idx_of[r], dtype=torch.long, device=device)] = outs_by_rank[r]
+        return full
 
-    for _ in range(max(a.warmup, 3 if stream else 1)):      # (graphs: eager, capture, first replay)
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        full, merged, outs = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    fin = all(bool(stats_to_numpy(o[1])["finished"].all()) for o in outs.values() if o[1] is not None)
-    # the load-imbalance term of a window shard: evaluations (= rounds a window stays in the batch) summed per rank
-    my_evals = float(sum(float(stats_to_numpy(o[1])["func_evals"].sum()) for o in outs.values() if o[1] is not None))
-    if world > 1:
-        ev = [None] * world
-        dist.all_gather_object(ev, my_evals)
+    def shard_accuracy(sh, glob):
+        """configs3 (every shard is its own stride-8 stream): MPJPE of the merged + smoothed shard and of its input, in mm."""
+        d = sh["d"]
+        m = eng.merge_windows(glob, 1, overlap=T - stride, smooth=True).cpu().numpy()
+        gt = d["gt_global"][:m.shape[0]]
+        homo = np.concatenate([d["est_all_np"][:m.shape[0]], np.ones((m.shape[0], 15, 1))], -1)
+        est_g = np.einsum("nij,nkj->nki", d["cams"][:m.shape[0]].cpu().numpy(), homo)[..., :3]
+        return mpjpe(m, gt) * 1e3, mpjpe(est_g, gt) * 1e3
+
+    n_warm = max(a.warmup, 3 if stream else 1)          # (graphs: eager, capture, first replay)
+    outs, stats_of, per_rank, acc = {}, {}, [], []
+    merged = None
+    if emulated:
+        # ---- one card plays the N ranks one after the other; one shard resident at a time
+        t_shards = []
+        for r in my_ranks:
+            sh = build_shard(r)
+            for _ in range(n_warm):
+                run_shard(sh)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                glob, stats = run_shard(sh)
+            torch.cuda.synchronize()
+            t_r = (time.perf_counter() - t0) / a.steps
+            outs[r] = glob.clone()
+            stats_of[r] = stats_to_numpy(stats) if stats is not None else None
+            if not stream and len(sh["idx"]):
+                acc.append(shard_accuracy(sh, glob))
+            t_shards.append(t_r)
+            per_rank.append({"rank": r, "windows": int(len(sh["idx"])), "frames_held": sh["frames_held"],
+                             "evaluations": int(stats_of[r]["func_evals"].sum()) if stats_of[r] is not None else 0,
+                             "ms_per_step": round(t_r * 1e3, 3)})
+            del sh, glob, stats
+            torch.cuda.empty_cache()
+        for _ in range(2):
+            full = place(outs)
+            merged = eng.merge_windows(full, 1, overlap=T - stride, smooth=True) if stream else None
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            full = place(outs)
+            merged = eng.merge_windows(full, 1, overlap=T - stride, smooth=True) if stream else None
+        torch.cuda.synchronize()
+        t_post = (time.perf_counter() - t0) / a.steps
+        elapsed = (sum(t_shards) + t_post) * a.steps
+        order = place({r: torch.as_tensor(idx_of[r], dtype=torch.int64, device=device) for r in my_ranks}, torch.int64, ())
     else:
-        ev = [float(stats_to_numpy(outs[r][1])["func_evals"].sum()) if outs[r][1] is not None else 0.0 for r in my_ranks]
+        sh = build_shard(rank)
+
+        def step():
+            glob, stats = run_shard(sh)
+            if world > 1:          # the one collective of the path
+                full = all_gather_indexed(glob, n_total, block) if stream else all_gather_windows(glob, n_total)
+            else:
+                full = glob
+            return full, (eng.merge_windows(full, 1, overlap=T - stride, smooth=True) if stream else None), glob, stats
+
+        for _ in range(n_warm):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            full, merged, glob, stats = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        t_mine = elapsed / a.steps
+        if world > 1:
+            t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        outs[rank] = glob
+        stats_of[rank] = stats_to_numpy(stats) if stats is not None else None
+        if not stream and len(sh["idx"]):
+            acc.append(shard_accuracy(sh, glob))
+        mine = {"rank": rank, "windows": int(len(sh["idx"])), "frames_held": sh["frames_held"],
+                "evaluations": int(stats_of[rank]["func_evals"].sum()) if stats_of[rank] is not None else 0,
+                "ms_per_step": round(t_mine * 1e3, 3)}
+        my_idx = torch.as_tensor(idx_of[rank], dtype=torch.int64, device=device)
+        if world > 1:
+            per_rank = [None] * world
+            dist.all_gather_object(per_rank, mine)
+            acc_all = [None] * world
+            dist.all_gather_object(acc_all, acc)
+            acc = [x for part in acc_all for x in part]
+            order = all_gather_indexed(my_idx, n_total, block) if stream else all_gather_windows(my_idx, n_total)
+        else:
+            per_rank = [mine]
+            order = my_idx
+        t_post = None
+    fin = all(bool(s["finished"].all()) for s in stats_of.values() if s is not None)
+    if world > 1:
+        fl = [None] * world
+        dist.all_gather_object(fl, fin)
+        fin = all(fl)
+    order_ok = bool(torch.equal(order.cpu(), torch.arange(n_total, dtype=torch.int64)))
     line = None
     if rank == 0:
-        mp = None
+        mp = mp_in = None
         if stream:
-            mp = round(mpjpe(merged.cpu().numpy(), gt_all[:merged.shape[0]]) * 1e3, 3)
+            gt_all = np.asarray(host_stream["gt_global_skeleton"])
+            nm = merged.shape[0]
+            mp = round(mpjpe(merged.cpu().numpy(), gt_all[:nm]) * 1e3, 3)
+            homo = np.concatenate([np.asarray(host_stream["estimated_local_skeleton"])[:nm], np.ones((nm, 15, 1))], -1)
+            est_g = np.einsum("nij,nkj->nki", np.asarray(host_stream["camera_pose_list"])[:nm], homo)[..., :3]
+            mp_in = round(mpjpe(est_g, gt_all[:nm]) * 1e3, 3)
+        elif acc:
+            mp, mp_in = round(float(np.mean([x[0] for x in acc])), 3), round(float(np.mean([x[1] for x in acc])), 3)
         if a.dump:
-            st0 = stats_to_numpy(outs[my_ranks[0]][1]) if outs[my_ranks[0]][1] is not None else None
+            st0 = stats_of[my_ranks[0]]
             np.savez(a.dump, glob=full.cpu().numpy(), merged=merged.cpu().numpy() if merged is not None else np.zeros(0),
                      **({"stats_" + k: np.asarray(st0[k]) for k in st0.dtype.names} if st0 is not None else {}))
         gs = eng.graph_stats() if stream else None
-        held = [shards[r]["frames_held"] for r in my_ranks]
+        ev = [float(p["evaluations"]) for p in per_rank]
+        tm = [float(p["ms_per_step"]) for p in per_rank]
+        t_max = max(tm) * 1e-3
+        partition = {"per_rank": per_rank,
+                     "evaluations_per_rank": {"max_over_mean": round(max(ev) / max(1e-9, sum(ev) / len(ev)), 4)},
+                     "time_per_rank": {"max_over_mean": round(max(tm) / max(1e-9, sum(tm) / len(tm)), 4)},
+                     "placement_and_merge_ms": round(t_post * 1e3, 3) if t_post is not None else None,
+                     "gathered_order_is_arange": order_ok}
+        if emulated:
+            partition["projected_%dgpu_windows_per_s" % vworld] = round(n_total / (t_max + t_post), 1)
+            partition["projection_note"] = ("PROJECTION, not a measurement: n windows / (slowest emulated rank's step + placement + merge), "
+                                            "each shard run alone on ONE card; the RCCL all-gather (1.8 KB per window) is not included")
         line = {
             "metric": "optimised windows/sec (10-frame, 15-joint)", "value": round(n_total * a.steps / elapsed, 2), "unit": "windows/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
@@ -317,17 +458,18 @@ def run_sharded(a, world, rank, device, rehearsal, sd_local, sd_global, vae_note
                                     % (n_total, stride * (n_total - 1) + T, block, vworld)) if stream else
                                    ("BASELINE configs[3]: %d independent windows in contiguous shards over %d ranks (%d per rank), every rank "
                                     "synthesises its own frames from seed + rank, one all-gather of the refined poses" % (n_total, vworld, cap)),
-                       "windows_total": n_total, "windows_per_rank_max": cap, "ranks": world, "emulated_ranks": vworld if vworld != world else None,
+                       "windows_total": n_total, "windows_per_rank_max": cap, "ranks": world, "emulated_ranks": vworld if emulated else None,
                        "backend": dist.get_backend() if world > 1 else None, "rehearsal_on_one_card": bool(rehearsal),
-                       "frames_held_by_rank0_shards": held, "vae": vae_note, "precision": a.precision,
+                       "vae": vae_note, "precision": a.precision,
                        "collective": None if world == 1 else ("all_gather_indexed" if stream else "all_gather_windows")},
-            "all_finished": fin, "mpjpe_optimised_mm": mp, "graph": gs,
-            "evaluations_per_rank": {"sum": [round(v) for v in ev], "max_over_mean": round(max(ev) / max(1e-9, sum(ev) / len(ev)), 4)},
+            "all_finished": fin, "mpjpe_input_mm": mp_in, "mpjpe_optimised_mm": mp, "graph": gs,
+            "evaluations_per_rank": {"sum": [round(v) for v in ev], "max_over_mean": partition["evaluations_per_rank"]["max_over_mean"]},
+            "partition": partition,
         }
         if emit:
             print(json.dumps(line), flush=True)
     eng.close()
-    del shards
+    outs.clear()
     torch.cuda.empty_cache()
     if world > 1:
         dist.barrier()
@@ -478,7 +620,7 @@ def main():
     # and one HIP stream per sequence, the kernels of different sequences overlap on the device.  Eager launches (the single
     # host thread enqueues ~700 launches per sequence-step) and hipGraph replay (one launch per sequence-step, configs[4]).
     in_flight = None
-    if a.precision == "f32" and not a.no_extra and world == 1 and a.workload == "seq2k":
+    if a.in_flight and a.precision == "f32" and not a.no_extra and world == 1 and a.workload == "seq2k":
         in_flight = {}
         engines = [eng]
         for _ in range(2):
@@ -572,6 +714,7 @@ def main():
                    "evals_per_stage": {"local_mean": round(float(ev2[0].mean()), 2), "global_mean": round(float(ev2[1].mean()), 2)},
                    "mpjpe_optimised_mm": round(mpjpe(opt2, gt2) * 1e3, 3), "all_finished": bool(sn2["finished"].all()),
                    "degenerate_windows": int(sn2["degenerate"].sum())}
+            rec["path"] = path_roofline(rec["windows_per_s"], ev2[0].mean(), ev2[1].mean(), mode)
             if profile:
                 # family 0 = the composed front layer (decoder_input o conv 0), forward + backward-data; family 1 = the fused tail
                 # (fp32: one window per workgroup; bf16: eight windows per workgroup, bf16 MFMA); family 2 = L-BFGS (HBM-bound)
@@ -586,10 +729,11 @@ def main():
                         continue
                     pk = PEAK_BF16_MATRIX_TFLOPS if (mode == "bf16" and "decoder_tail_kernel" not in names) else PEAK_F32_MATRIX_TFLOPS
                     ach = fl_k / (ms_k * 1e-3) / 1e12
-                    tr_b, tr_src = committed_traffic(names, B2, mode)
+                    tr_b, tr_src, mf = committed_traffic(names, B2, mode, with_mfma=True)
                     rec[key] = {"bound": kernel_bound(names), "achieved": round(ach, 2), "peak": pk, "unit": "TFLOP/s", "frac": round(ach / pk, 4),
-                                "kernel": names, "launches": int(n_k), "avg_us": round(ms_k * 1e3 / n_k, 2), "flop_per_launch": fl_k / n_k,
-                                "share_of_step": round(ms_k * 1e-3 / (dt / n2), 3), "traffic": tr_b, "traffic_source": tr_src}
+                                "kernel": names, "launches": int(n_k), "avg_us": round(ms_k * 1e3 / n_k, 2), "flop_per_launch": round(fl_k / n_k),
+                                "share_of_step": round(ms_k * 1e-3 / (dt / n2), 3), "traffic": tr_b, "traffic_source": tr_src,
+                                "mfma_busy": mfma_busy_record(mf, ms_k * 1e3 / n_k, fl_k / n_k, "bf16" if pk == PEAK_BF16_MATRIX_TFLOPS else "f32")}
                 ms_k, n_k, _ = e2.profile_read(2)
                 if n_k:
                     rec["lbfgs_advance"] = lbfgs_record(e2, ms_k, n_k, dt / n2, B2, mode)
@@ -671,6 +815,19 @@ def main():
             strong[wl_name] = run_sharded(a2, world, rank, device, rehearsal, sd_local, sd_global,
                                           "synthetic, fitted %d Adam steps (recon %.1f / %.1f mm)" % (a.fit_steps, err_l * 1e3, err_g * 1e3)
                                           if a.vae != "structured" else "synthetic, structured", emit=False)
+
+    # ---- side records (not `value`): BASELINE configs[3] and configs[4] at their FULL size under the 8-way partition of the
+    # multi-GPU legs, the eight shards run one after the other on this one card (run_sharded, --emulate-ranks 8): per-rank
+    # evaluations / time, their imbalance, and a labelled PROJECTION of the 8-GPU rate
+    partition8 = None
+    if world == 1 and a.workload == "seq2k" and not a.no_extra and not a.no_partition and a.precision == "f32":
+        import copy
+        partition8 = {}
+        for wl_name in ("configs3", "configs4"):
+            a2 = copy.copy(a)
+            a2.workload, a2.precision, a2.dump, a2.emulate_ranks, a2.windows = wl_name, "bf16", None, 8, 0
+            a2.steps, a2.warmup = max(2, min(a.steps, 3)), 1
+            partition8[wl_name] = run_sharded(a2, world, rank, device, rehearsal, sd_local, sd_global, "as the headline", emit=False)
 
     # ---- side record (not `value`): SURVEY 8f.3, the drop-in interface end to end -- `whole_sequence.optimize_directory` on this
     # rank's sequence written as 20 chunk directories of `test_data.pkl` files (page-cached): un-pickling / raw-array cache reads,
@@ -759,10 +916,11 @@ def main():
                 ms, n, fl, names = fam[k]
                 achieved = fl / (ms * 1e-3) / 1e12
                 pk = peak if (k == 0 or "bf16" in names) else PEAK_F32_MATRIX_TFLOPS        # (the one-window tail is fp32 in every mode)
-                tr_b, tr_src = committed_traffic(names, B, a.precision)
+                tr_b, tr_src, mf = committed_traffic(names, B, a.precision, with_mfma=True)
                 return {"bound": kernel_bound(names) if k == 1 else "mfma", "achieved": round(achieved, 3), "peak": round(pk, 1), "unit": "TFLOP/s", "frac": round(achieved / pk, 4),
                         "traffic": tr_b, "traffic_source": tr_src, "kernel": names, "what": what[k], "launches": int(n),
-                        "avg_us": round(ms * 1e3 / n, 2), "flop_per_launch": fl / n,
+                        "avg_us": round(ms * 1e3 / n, 2), "flop_per_launch": round(fl / n),
+                        "mfma_busy": mfma_busy_record(mf, ms * 1e3 / n, fl / n, "bf16" if pk == PEAK_BF16_MATRIX_TFLOPS else "f32"),
                         "share_of_step": round(ms * 1e-3 / min(PROFILE_STEPS, a.steps) / (elapsed / a.steps), 3)}
             ms2, n2k, _ = eng.profile_read(2)
             if n2k:
@@ -910,45 +1068,90 @@ def main():
                                          "sample": "3 steps of the same batch: oracle/torch_port.TrainPort (autograd + torch.optim.Adam), torch %s CPU"
                                                    % torch.__version__}
         total_windows = B * world * a.steps
+        value = total_windows / elapsed
+        if roof is not None:
+            # SURVEY.md 8d's path-level figure for `value` (per GPU), beside the dominant kernel's own
+            roof["path"] = path_roofline(value / world, evals[0].mean(), evals[1].mean(), a.precision)
+            roof["other"], roof["lbfgs"] = roof_other, roof_lbfgs
+
+        def pick(d, *keys):
+            for k in keys:
+                d = d.get(k) if isinstance(d, dict) else None
+            return d
+
+        def part_summary(r):
+            if not r:
+                return None
+            pt = r["partition"]
+            proj = [v for k, v in pt.items() if k.startswith("projected_")]
+            return {"windows": r["config"]["windows_total"], "one_card_wps": r["value"], "eval_imbalance": pt["evaluations_per_rank"]["max_over_mean"],
+                    "time_imbalance": pt["time_per_rank"]["max_over_mean"], "projected_8gpu_wps_NOT_MEASURED": proj[0] if proj else None,
+                    "order_ok": pt["gathered_order_is_arange"], "all_finished": r["all_finished"], "mpjpe_mm": [r["mpjpe_input_mm"], r["mpjpe_optimised_mm"]]}
+
+        def cfg_summary(r, mode):
+            m = pick(r, mode)
+            if not m:
+                return None
+            return {"wps": m["windows_per_s"], "path_frac": pick(m, "path", "frac"), "path_frac_exec": pick(m, "path", "frac_executed"),
+                    "gemm": [pick(m, "roofline", "avg_us"), pick(m, "roofline", "frac"), pick(m, "roofline", "mfma_busy", "frac_of_active_cycles")],
+                    "tail": [pick(m, "roofline_tail", "avg_us"), pick(m, "roofline_tail", "frac")],
+                    "lbfgs": [pick(m, "lbfgs_advance", "avg_us"), pick(m, "lbfgs_advance", "frac")], "mpjpe_mm": m.get("mpjpe_optimised_mm")}
+        # the last ~2 KB of the line are what a truncated log keeps: the headline numbers of every side record, compact
+        summary = {
+            "value": round(value, 1), "path_frac": pick(roof, "path", "frac"), "path_frac_exec": pick(roof, "path", "frac_executed"),
+            "gemm": [pick(roof, "avg_us"), pick(roof, "frac"), pick(roof, "mfma_busy", "frac_of_active_cycles")] if roof else None,
+            "tail": [pick(roof_other, "avg_us"), pick(roof_other, "frac")] if roof_other else None,
+            "lbfgs": [pick(roof_lbfgs, "avg_us"), pick(roof_lbfgs, "frac")] if roof_lbfgs else None,
+            "bf16_240_wps": pick(other_modes, "bf16", "windows_per_s"),
+            "configs2_f32": cfg_summary(configs2, "f32"), "configs2_bf16": cfg_summary(configs2, "bf16"),
+            "configs3_shard_bf16": cfg_summary(configs3, "bf16") if world == 1 else None,
+            "configs4_shard": {m: [pick(configs4, m, "windows_per_s"), pick(configs4, m, "mpjpe_optimised_mm")] for m in ("f32", "bf16")} if (world == 1 and configs4) else None,
+            "partition8_configs3": part_summary(pick(partition8, "configs3")), "partition8_configs4": part_summary(pick(partition8, "configs4")),
+            "train": [pick(train, "ms_per_step"), pick(train, "batch_1024", "ms_per_step"), pick(train, "batch_1024", "roofline", "frac")] if train else None,
+            "lift_GBps": pick(lift, "achieved_GBps"), "post_ms": pick(post, "device_ms"),
+            "host_inclusive_wps": [pick(host_inclusive, "pickles_only", "windows_per_s"), pick(host_inclusive, "raw_array_cache", "windows_per_s")],
+            "cpu_wps": pick(cpu, "value"), "cpu_cores": pick(cpu, "cores"),
+            "legend": "gemm/tail/lbfgs = [avg us per launch, fraction of its roofline(, MFMA busy / active cycles from the committed PMC pass)]",
+        }
         line = {
+            "other_precisions": other_modes or None,
+            "configs2": configs2,
+            # one GPU: the per-GPU shards of configs[3] / configs[4]; several ranks: the whole jobs, sharded (scaling: strong)
+            "configs3": configs3 if world == 1 else strong.get("configs3"),
+            "configs4": configs4 if world == 1 else strong.get("configs4"),
+            "partition8": partition8,
+            "sequences_in_flight": in_flight,
+            "host_inclusive": host_inclusive,
+            "post": post,
+            "lift": lift,
+            "train": train,
+            "evals_per_stage": {"local_mean": float(evals[0].mean()), "global_mean": float(evals[1].mean()),
+                                "min": int(evals.min()), "max": int(evals.max())},
+            "mpjpe_mm": {"input": round(mp_in * 1e3, 3), "optimised": round(mp_opt * 1e3, 3)},
             "metric": "optimised windows/sec (10-frame, 15-joint)",
-            "value": round(total_windows / elapsed, 2),
+            "value": round(value, 2),
             "unit": "windows/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"f32": "f32", "bf16x3": "f32 via 3x bf16 split MFMA (wide products), f32 elsewhere",
                       "bf16": "bf16 wide products / f32 accumulate, tail and energies"}[a.precision], "data": "synthetic",
-            "config": {"workload": "%s: %d-frame sequence per GPU = %d chunks x %d windows = %d windows, %s wide products, "
-                                   "local+global stage, L-BFGS max_iter 25 / max_eval 31; decoder_input and the first decoder conv run as ONE composed linear layer"
-                                   % ({"seq2k": "BASELINE configs[1] (one ~2k-frame sequence, all windows in one batch)",
-                                       "w8192": "BASELINE configs[3] per-GPU shard (8192 windows; 683 chunks = 8196)",
-                                       "w8192x": "BASELINE configs[3] per-GPU shard (exactly 8192 windows: the first 8192 of 683 chunks)"}
-                                      .get(a.workload, "custom workload (--workload %s)" % a.workload),
-                                      n_frames, n_chunks, per, B, a.precision),
+            "config": {"workload": "%s: %d frames = %d chunks x %d = %d windows per GPU, %s, local+global stage, L-BFGS 25 / 31"
+                                   % ({"seq2k": "BASELINE configs[1]", "w8192": "configs[3] shard (683 chunks)", "w8192x": "configs[3] shard (8192 windows)"}
+                                      .get(a.workload, "--workload %s" % a.workload), n_frames, n_chunks, per, B, a.precision),
                        "windows_per_gpu": B, "latent_dim": shape.latent_dim, "parallelism": "window-shards x%d" % world,
                        "ranks": world, "backend": dist.get_backend() if world > 1 else None,
                        "vae": ("synthetic, fitted %d Adam steps (recon %.1f / %.1f mm)" % (a.fit_steps, err_l * 1e3, err_g * 1e3))
                               + (" by the HIP trainer" if a.vae == "fit-device" else "")
-                              if a.vae != "structured" else "synthetic, structured (vae.structured_state_dict seeds 7 / 8)"},
-            "evals_per_stage": {"local_mean": float(evals[0].mean()), "global_mean": float(evals[1].mean()),
-                                "min": int(evals.min()), "max": int(evals.max())},
-            "mpjpe_mm": {"input": round(mp_in * 1e3, 3), "optimised": round(mp_opt * 1e3, 3)},
-            "post": post,
-            "lift": lift,
-            "train": train,
+                              if a.vae != "structured" else "synthetic, structured (vae.structured_state_dict seeds 7 / 8)",
+                       "composed_front_layer": True},
             "roofline": roof,
-            "roofline_other": roof_other,
-            "roofline_lbfgs": roof_lbfgs,
             "cpu_baseline": cpu,
-            "host_inclusive": host_inclusive,
-            "other_precisions": other_modes or None,
-            "configs2": configs2,
-            # one GPU: the per-GPU shards of configs[3] / configs[4]; several ranks: the whole jobs, sharded (scaling: strong)
-            "configs3": configs3 if world == 1 else strong.get("configs3"),
-            "configs4": configs4 if world == 1 else strong.get("configs4"),
-            "sequences_in_flight": in_flight,
+            "summary": summary,
         }
+        if a.full_record:
+            with open(a.full_record, "w") as f:
+                json.dump(line, f, indent=1)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -810,6 +810,7 @@ static int windows_single(WindowsRun& r) {
 static int ensure_lane(gem_handle* h, int B_lane) {
     if (h->lane2 && h->lane2->ws.Bmax >= B_lane) return 0;
     if (h->lane2) { GEM_HIP(hipDeviceSynchronize()); gem_destroy(h->lane2); h->lane2 = nullptr; }
+    h->lane_gen = 0;                            // a fresh lane has mirrored nothing yet: the next sync_lane copies nets, precision, texel cache
     gem_config cfg = h->cfg;
     cfg.max_windows = std::max(B_lane, (h->ws.Bmax + 1) / 2 + 8);
     gem_handle* l = nullptr;

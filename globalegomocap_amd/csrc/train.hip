@@ -80,6 +80,7 @@ struct gem_trainer {
     void* tn_tab = nullptr; int n_tn = 0, tn_tiles = 0;      // the weight-gradient launch's layer table (TnTable, host copy: passed by value)
     int part_recon = 0, part_latent = 0;       // capacity of the partial-sum regions
     long step = 0;
+    bool grads_partial = false;    // the last gem_trainer_step ran with update = 2: the linear layers' ranges of the gradient arena are stale
     std::vector<void*> allocs;
 };
 
@@ -1286,6 +1287,11 @@ int gem_trainer_download(gem_trainer* t, int what, float* dst, int64_t n) {
     const float* src = what == 0 ? t->P : what == 1 ? t->G : what == 2 ? t->S : what == 3 ? t->M1 : what == 4 ? t->M2 : nullptr;
     const size_t want = what == 2 ? t->n_stats : t->n_params;
     if (!src || (size_t)n != want) { set_error("gem_trainer_download: bad selector or size"); return 1; }
+    if (what == 1 && t->grads_partial) {
+        set_error("gem_trainer_download: the last step ran with update = 2 (linear-layer weight gradients formed inside their Adam step): "
+                  "the gradient arena is incomplete; step with update = 0 or 1 to read gradients");
+        return 1;
+    }
     GEM_HIP(hipSetDevice(t->h->cfg.device));
     GEM_HIP(hipDeviceSynchronize());
     GEM_HIP(hipMemcpy(dst, src, want * sizeof(float), hipMemcpyDeviceToHost));
@@ -1303,6 +1309,8 @@ int gem_trainer_step(gem_trainer* t, int B, const float* d_pose, const float* d_
                      void* stream) {
     if (!t || !d_pose || !d_eps || !o) { set_error("gem_trainer_step: null argument"); return 1; }
     if (B < 2 || B > t->Bmax) { set_error("gem_trainer_step: need 2 <= B <= max_windows (BatchNorm statistics)"); return 1; }
+    if (update < 0 || update > 2) { set_error("gem_trainer_step: update must be 0 (gradients only), 1 (Adam from the arena) or 2 (fused linear layers)"); return 1; }
+    t->grads_partial = update == 2;
     gem_handle* h = t->h;
     GEM_HIP(hipSetDevice(h->cfg.device));
     hipStream_t s = (hipStream_t)stream;
@@ -1513,6 +1521,7 @@ static int apply_adam(gem_trainer* t, const gem_train_opts* o, double grad_scale
 
 int gem_trainer_apply(gem_trainer* t, const gem_train_opts* o, double grad_scale, void* stream) {
     if (!t || !o) { set_error("gem_trainer_apply: null argument"); return 1; }
+    if (t->grads_partial) { set_error("gem_trainer_apply: the last step ran with update = 2, the gradient arena is incomplete"); return 1; }
     GEM_HIP(hipSetDevice(t->h->cfg.device));
     return apply_adam(t, o, grad_scale, (hipStream_t)stream, false);
 }
@@ -1521,6 +1530,7 @@ int gem_trainer_arena(gem_trainer* t, int what, void** d_ptr, int64_t* n) {
     if (!t || !d_ptr) { set_error("gem_trainer_arena: null argument"); return 1; }
     float* p = what == 0 ? t->P : what == 1 ? t->G : what == 2 ? t->S : what == 3 ? t->M1 : what == 4 ? t->M2 : nullptr;
     if (!p) { set_error("gem_trainer_arena: bad selector"); return 1; }
+    if (what == 1 && t->grads_partial) { set_error("gem_trainer_arena: the last step ran with update = 2, the gradient arena is incomplete"); return 1; }
     *d_ptr = p;
     if (n) *n = (int64_t)(what == 2 ? t->n_stats : t->n_params);
     return 0;

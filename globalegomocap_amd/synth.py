@@ -142,13 +142,14 @@ def make_sequence_device(n_frames, seed, device, camera=None, noise=0.02, sigma=
     }
 
 
-def make_stream_device(n_frames, seed, device, runs=None, camera=None, noise=0.02, sigma=1.5, block=200, cam_jitter=None):
+def make_stream_device(n_frames, seed, device, runs=None, camera=None, noise=0.02, sigma=1.5, block=200, cam_jitter=None, host=None):
     """One long sequence of which this process holds only the frames of `runs` (list of [f0, f1); None = all) in HBM: the small
     per-frame arrays (poses, cameras, ground truth) are synthesised for the whole stream on the host (they are a function of
     the seed alone, so every rank sees the same stream), the heat-maps -- 99 % of the bytes -- only for the held frames, on the
-    device.  Returns est_local / cams / heat for the held frames (concatenated runs, device) plus gt_global (host, all frames)."""
+    device.  Returns est_local / cams / heat for the held frames (concatenated runs, device) plus gt_global (host, all frames).
+    `host`: the `make_sequence(n_frames, seed, ..., with_heatmaps=False)` dict of this stream when the caller already has it."""
     import torch
-    seq = make_sequence(n_frames, seed, camera, noise, sigma, with_heatmaps=False, cam_jitter=cam_jitter)
+    seq = host if host is not None else make_sequence(n_frames, seed, camera, noise, sigma, with_heatmaps=False, cam_jitter=cam_jitter)
     keep = np.arange(n_frames) if runs is None else np.concatenate([np.arange(f0, f1) for f0, f1 in runs])
     est = np.asarray(seq["estimated_local_skeleton"])[keep]
     cams = np.asarray(seq["camera_pose_list"])[keep]

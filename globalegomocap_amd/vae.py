@@ -349,7 +349,33 @@ def save_checkpoint(path, state_dict):
     torch.save({"epoch": 19, "state_dict": sd}, path)
 
 
-def load_checkpoint(path):
-    """`torch.load(path)['state_dict']` (optimizer.py:59)."""
+def load_checkpoint_file(path, trust=None):
+    """The whole dict of a checkpoint file (networks/train.py:102-108: epoch, args, state_dict, eval_result, optimizer) through
+    torch's restricted unpickler: tensors, containers, primitives and numpy scalars / arrays only -- a downloaded file cannot run
+    code.  A file that needs more (the reference never writes one) is refused unless `trust=True` or GEM_TRUST_CHECKPOINTS=1."""
+    import os
+    import pickle
     import torch
-    return torch.load(path, map_location="cpu", weights_only=False)["state_dict"]
+    if trust is None:
+        trust = os.environ.get("GEM_TRUST_CHECKPOINTS") == "1"
+    allow = [np.dtype, np.ndarray]
+    for name in ("_core", "core"):                       # numpy 2.x / 1.x module layout
+        mod = getattr(np, name, None)
+        ma = getattr(mod, "multiarray", None)
+        for fn in ("scalar", "_reconstruct"):
+            if ma is not None and hasattr(ma, fn):
+                allow.append(getattr(ma, fn))
+    allow += [type(np.dtype(t)) for t in ("float32", "float64", "int64", "int32", "bool")]
+    try:
+        with torch.serialization.safe_globals(allow):
+            return torch.load(path, map_location="cpu", weights_only=True)
+    except pickle.UnpicklingError as e:
+        if not trust:
+            raise pickle.UnpicklingError("%s holds objects the restricted unpickler refuses (%s); pass trust=True / set "
+                                         "GEM_TRUST_CHECKPOINTS=1 only for files you wrote yourself" % (path, str(e).splitlines()[0])) from e
+    return torch.load(path, map_location="cpu", weights_only=False)
+
+
+def load_checkpoint(path, trust=None):
+    """`torch.load(path)['state_dict']` (optimizer.py:59), through the restricted unpickler (load_checkpoint_file)."""
+    return load_checkpoint_file(path, trust)["state_dict"]

@@ -307,11 +307,11 @@ class VAETrainer:
         self.steps = step
         _capi.check(self.lib.gem_trainer_set_step(self._t, step), self.lib)
 
-    def load_checkpoint(self, path):
+    def load_checkpoint(self, path, trust=None):
         """A checkpoint of `fit` (or of the reference's networks/train.py:102-108): weights, statistics, Adam state.  Returns the
-        epoch it was written after."""
-        import torch
-        ck = torch.load(path, map_location="cpu", weights_only=False)
+        epoch it was written after.  Read through torch's restricted unpickler (vae.load_checkpoint_file)."""
+        from .vae import load_checkpoint_file
+        ck = load_checkpoint_file(path, trust)
         self.load_state_dict({k: np.asarray(v) for k, v in ck["state_dict"].items()})
         if ck.get("optimizer"):
             self.load_optimizer_state(ck["optimizer"])

@@ -98,3 +98,39 @@ def test_default_two_rank_line_carries_the_strong_scaling_legs():
         ev = rec["evaluations_per_rank"]
         assert len(ev["sum"]) == 2 and min(ev["sum"]) > 0 and 1.0 <= ev["max_over_mean"] < 1.5, (key, ev)
     assert line["configs4"]["graph"]["replays"] >= 1
+
+
+@pytest.fixture(scope="module")
+def fitted_weights_cache(tmp_path_factory):
+    return str(tmp_path_factory.mktemp("bench_weights") / "vae_cache.pt")
+
+
+@pytest.mark.parametrize("workload,windows,per_rank_max,imbalance", [("configs3", 65536, 8192, 1.1), ("configs4", 12499, 1568, 1.25)])
+def test_full_size_partitions_emulated_8_ranks(fitted_weights_cache, workload, windows, per_rank_max, imbalance):
+    """BASELINE configs[3] (65 536 windows, contiguous shards of 8192) and configs[4] (the 12 499 overlapping windows of ONE
+    100 000-frame stream, block-cyclic shards + halo frames, hipGraph replay, gather by index, merge + smoothing) at their FULL
+    size under the 8-way partition of the multi-GPU legs -- the eight shards run one after the other on the one card of the test
+    box, each exactly as its rank would run it (`bench.py --emulate-ranks 8`; one shard resident at a time).  Windows are
+    independent (/root/reference/optimizer.py:370), the merge is optimizer.py:425-437: every window must finish, the gathered
+    array must be in window order, the optimisation must improve the MPJPE, and the per-rank work (evaluations) and time must be
+    balanced -- the only thing that can cost the 8-GPU scaling."""
+    line = _run_bench(["--gpus", "1", "--workload", workload, "--emulate-ranks", "8", "--steps", "2", "--warmup", "1", "--cpu-windows", "0",
+                       "--weights-cache", fitted_weights_cache], {}, timeout=1500)
+    cfg, part = line["config"], line["partition"]
+    assert cfg["windows_total"] == windows and cfg["emulated_ranks"] == 8 and cfg["ranks"] == 1 and cfg["precision"] == "bf16"
+    assert cfg["windows_per_rank_max"] == per_rank_max
+    assert line["all_finished"] and part["gathered_order_is_arange"]
+    pr = part["per_rank"]
+    assert [p["rank"] for p in pr] == list(range(8)) and sum(p["windows"] for p in pr) == windows
+    assert all(p["evaluations"] > 20 * p["windows"] and p["ms_per_step"] > 0 for p in pr), pr
+    assert 1.0 <= part["evaluations_per_rank"]["max_over_mean"] < imbalance, part
+    assert 1.0 <= part["time_per_rank"]["max_over_mean"] < imbalance, part
+    assert line["mpjpe_optimised_mm"] < 0.6 * line["mpjpe_input_mm"], (line["mpjpe_input_mm"], line["mpjpe_optimised_mm"])
+    proj = part["projected_8gpu_windows_per_s"]
+    assert proj > 5.5 * line["value"] and "PROJECTION" in part["projection_note"]          # (8 x one card, less the imbalance and the merge)
+    if workload == "configs4":
+        held = sum(p["frames_held"] for p in pr)
+        assert 100002 <= held <= 100002 + 2 * (windows // 32 + 1), held         # frames stored once + the 2-frame halos between blocks
+        assert line["graph"]["replays"] >= 8
+    else:
+        assert all(p["frames_held"] == 8 * (p["windows"] - 1) + 10 for p in pr)
