@@ -219,6 +219,18 @@ static int gemm_bf16a(gem_handle* h, const Layer& L, int epi, const uint16_t* A,
     return 0;
 }
 
+// The rounds of a stage need no compact_kernel launch when every kernel of a round addresses its rows through perm / slot_of and
+// nothing depends on the ORDER of the slots: the composed front products (rows gathered through perm) + the fused bf16 tail (windows
+// independent of their position in a workgroup: test_bf16_tail_row_tile_variants_compute_the_same) + lbfgs_advance (slot_of).  The
+// batched narrow layers (taps = 3) read n_active[1] = rows and are not covered.
+bool bf16_rounds_take_slots_atomically(const gem_handle* h, int stage, int B) {
+    const StageNet& net = h->net[stage];
+    if (h->precision != GEM_PRECISION_BF16 || B > ATOMIC_COMPACT_MAX || dev_env("GEM_NO_ATOMIC_COMPACT")) return false;
+    const char* t16_env = dev_env("GEM_TAIL16");
+    if (!net.tb_stream || net.tail_start != 1 || dev_env("GEM_BATCHED_NARROW") || (t16_env && t16_env[0] == '0')) return false;
+    return net.front.wb_hi && net.dec.size() > 1 && !dev_env("GEM_NO_FRONT_BF16");
+}
+
 // One evaluation in the bf16 decoder mode: decodes ws.trial_b, leaves the pose in ws.dec_act.back() (fp32), the energies in
 // ws.f / ws.parts and dE/dz in ws.dz (or in ws.grad_slab for lbfgs_advance, in the rounds).
 int evaluate_bf16(gem_handle* h, int stage, int B, const EnergyArgs& ea_in, hipStream_t s, bool forward_only) {
@@ -241,6 +253,10 @@ int evaluate_bf16(gem_handle* h, int stage, int B, const EnergyArgs& ea_in, hipS
                             (B >= t16_min || (t16_env && t16_env[0] == '1'));
     const bool use_tail = !use_tail16 && !batched_narrow && net.tail_start >= 1 && (tail_wgs <= 5 * h->n_cu || force_tail);
     const int* perm = w.dyn ? w.perm : nullptr;
+    if (w.next_count && !(use_tail16 && net.front.wb_hi && net.tail_start == 1)) {
+        set_error("evaluate_bf16: slots are handed out by lbfgs_advance but this evaluation does not run front products + fused tail");
+        return 1;
+    }
     w.grad_slab = SlabSrc{};
     // decoder_input o conv 0 as ONE product where the weights were composed (compose_front in gem_api.hip), else
     // decoder_input: [B, Dp] x [Dp, T*topp] -> h0 [B*T, topp] bf16 (rows of finished windows are skipped through perm)

@@ -13,6 +13,10 @@
 
 namespace gem {
 
+#ifdef GEM_TB_DEBUG_DUMP
+__device__ float* g_ep_dump = nullptr;       // developer harness only: [B][T*J][8] intermediates of the x component
+#endif
+
 // 1-ulp reciprocal / square root (v_rcp_f32, v_sqrt_f32).  The bf16 decoder mode that uses this header already carries 2^-9 of
 // relative noise on every decoded coordinate; the correctly rounded sequences (about ten instructions each) buy nothing here.
 __device__ __forceinline__ float rcp1(float v) { return __builtin_amdgcn_rcpf(v); }
@@ -169,6 +173,12 @@ __device__ __forceinline__ void pair_terms(const EnergyArgs& a, int b, int p, bo
         const float dvdx = rho * (-xx * y * i3) + uy * drho * dth_dn * ux;
         const float dvdy = rho * (inv - y * y * i3) + uy * drho * dth_dn * uy;
         const float dvdz = uy * drho * dth_dz;
+#ifdef GEM_TB_DEBUG_DUMP
+        if (g_ep_dump && valid) {
+            float* dd = g_ep_dump + ((size_t)b * TJ + p) * 8;
+            dd[0] = inv - xx * xx * i3; dd[1] = ux * drho * dth_dn * ux; dd[2] = inv; dd[3] = dudx; dd[4] = xx * xx; dd[5] = rho; dd[6] = i3; dd[7] = ux;
+        }
+#endif
         gx += gu * dudx + gv * dvdx;
         gy += gu * dudy + gv * dvdy;
         gz += gu * dudz + gv * dvdz;

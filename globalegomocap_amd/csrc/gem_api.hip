@@ -312,8 +312,10 @@ int gem_create(const gem_config* cfg, gem_handle** out) {
     if (dev_alloc(w.allocs, &w.pose_a, rows * h->C)) return 1;
     if (dev_alloc(w.allocs, &w.pose_b, rows * h->C)) return 1;
     if (dev_alloc(w.allocs, &w.n_log, (size_t)N_LOG)) return 1;
+    if (dev_alloc(w.allocs, &w.perm2, (size_t)B) || dev_alloc(w.allocs, &w.slot_of2, (size_t)B)) return 1;
     if (dev_alloc(w.allocs, &w.perm, (size_t)B) || dev_alloc(w.allocs, &w.slot_of, (size_t)B) || dev_alloc(w.allocs, &w.n_active, 2))
         return 1;
+    w.perm_home = w.perm; w.slot_of_home = w.slot_of; w.n_active_home = w.n_active;
     // split-K slabs: only launches with few output tiles cut K; 64 MB, more when mid-size batches need it for the
     // decoder_input backward product (rows x Dp x up to 4 slices)
     w.splitk_elems = std::max((size_t)16 << 20, (size_t)std::min(B, 4096) * h->Dp * 4);
@@ -647,8 +649,16 @@ struct StageRun {
     hipStream_t s = nullptr;
     EnergyArgs ea{};
     bool fuse = false;
+    bool atomic_slots = false;          // lbfgs_advance hands out the next round's slots itself (Workspace::next_*): no compact launch
+    long log0 = 0;                      // ... n_log entry of round 0's count (round k: log0 + k)
     int rounds = 0;
 };
+
+// the workspace's compaction pointers back on their allocations (a stage with atomic slots moves them round by round)
+static void compaction_home(Workspace& w) {
+    w.perm = w.perm_home; w.slot_of = w.slot_of_home; w.n_active = w.n_active_home;
+    w.next_perm = w.next_slot_of = w.next_count = nullptr;
+}
 
 static int stage_begin(StageRun& r) {
     gem_handle* h = r.h;
@@ -668,8 +678,18 @@ static int stage_begin(StageRun& r) {
     // Rounds run on the windows that are still iterating: after every advance they are re-packed to the front
     // (perm / n_active on the device) and the kernels of the next round read their row count from there.
     static const bool no_compact = dev_env("GEM_NO_COMPACT") != nullptr;
+    compaction_home(w);
+    r.atomic_slots = false;
     if (!no_compact) {
-        if (launch_compact(h, B, 1, s)) return 1;
+        r.atomic_slots = bf16_rounds_take_slots_atomically(h, stage, B);
+        if (r.atomic_slots) {
+            // rounds + 2 consecutive n_log entries: round 0's count (written by the compaction below), then one zeroed counter per round
+            if ((w.log_pos % N_LOG) + r.rounds + 2 > N_LOG) w.log_pos += N_LOG - (w.log_pos % N_LOG);
+            r.log0 = w.log_pos;
+            GEM_HIP(hipMemsetAsync(w.n_log + (r.log0 % N_LOG) + 1, 0, (size_t)(r.rounds + 1) * sizeof(int), s));
+        }
+        if (launch_compact(h, B, 1, s)) return 1;          // identity: every window takes part in round 0 (logs B at n_log[log0])
+        if (r.atomic_slots) w.log_pos = r.log0 + r.rounds + 2;
         w.dyn = true;
     }
     // texel-block cache of the reprojection term: valid for this stage's heat-maps / windows only
@@ -698,6 +718,15 @@ static int stage_round(StageRun& r, int k) {
     int rc = 0;
     w.round = k;
     // (dyn / tex state of THIS lane's workspace: another lane may have run in between)
+    if (w.dyn && r.atomic_slots) {
+        // this round's set and the set lbfgs_advance fills for the next one
+        int* cnt = w.n_log + (r.log0 + k) % N_LOG;
+        w.perm = (k & 1) ? w.perm2 : w.perm_home;       w.next_perm = (k & 1) ? w.perm_home : w.perm2;
+        w.slot_of = (k & 1) ? w.slot_of2 : w.slot_of_home; w.next_slot_of = (k & 1) ? w.slot_of_home : w.slot_of2;
+        w.n_active = cnt; w.next_count = cnt + 1;
+        w.cur_log = r.log0 + k;
+        r.ea.n_dev = w.n_active; r.ea.perm = w.perm;
+    } else
     if (k > 0 && w.dyn) {
         if (r.fuse) {
             w.fuse_compact = true;
@@ -722,6 +751,7 @@ static int stage_finish(StageRun& r) {
     Workspace& w = h->ws;
     w.round = -1;
     w.dyn = false;
+    compaction_home(w);
     if (r.B == 0) return 0;
     // every window is finished now: trial == x*; decode it with the same kernels as the rounds (all windows again)
     if (evaluate(h, r.stage, r.B, w.trial, energy_args(h, r.pose_in, r.heat, r.frame0, r.mean_bone, r.wt), r.s, true)) return 1;
@@ -737,10 +767,10 @@ static int optimize_stage_impl(gem_handle* h, int stage, int B, const float* d_p
     StageRun r;
     r.h = h; r.stage = stage; r.B = B; r.pose_in = d_pose_in; r.heat = d_heat; r.frame0 = d_frame0; r.mean_bone = d_mean_bone; r.eps = d_eps;
     r.wt = wt; r.opt = opt; r.pose_out = d_pose_out; r.stats = d_stats; r.s = s;
-    if (stage_begin(r)) { h->ws.dyn = false; return 1; }
+    if (stage_begin(r)) { h->ws.dyn = false; compaction_home(h->ws); return 1; }
     int rc = 0;
     for (int k = 0; k < r.rounds && !rc; ++k) rc = stage_round(r, k);
-    if (rc) { h->ws.round = -1; h->ws.dyn = false; return 1; }
+    if (rc) { h->ws.round = -1; h->ws.dyn = false; compaction_home(h->ws); return 1; }
     return stage_finish(r);
 }
 
@@ -785,7 +815,7 @@ static int windows_end(WindowsRun& r) {
     if (stage_finish(r.st)) return 1;
     return launch_to_global(h->ws.pose_b, r.cams, r.frame0, r.global, r.B, h->T, h->J, r.s);
 }
-static void windows_abort(WindowsRun& r) { r.h->ws.round = -1; r.h->ws.dyn = false; r.h->ws.mid_event = nullptr; }
+static void windows_abort(WindowsRun& r) { r.h->ws.round = -1; r.h->ws.dyn = false; r.h->ws.mid_event = nullptr; compaction_home(r.h->ws); }
 
 static int windows_single(WindowsRun& r) {
     int rc = windows_begin_local(r);
@@ -1070,6 +1100,13 @@ int gem_set_texel_cache(gem_handle* h, int on) {
 
 int gem_graph_enable(gem_handle* h, int on) {
     if (!h) { set_error("gem_graph_enable: null handle"); return 1; }
+    if (!on && !h->graphs.empty()) {
+        // switching replay off drops the captured calls: they hold the ADDRESSES of the caller's tensors, and a caller about to free
+        // those tensors must be able to make sure no graph is ever replayed on whatever is allocated there next (bench.py's shards)
+        GEM_HIP(hipSetDevice(h->cfg.device));
+        GEM_HIP(hipDeviceSynchronize());
+        drop_graphs(h);
+    }
     h->graphs_on = on != 0;
     return 0;
 }

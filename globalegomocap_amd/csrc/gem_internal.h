@@ -1,5 +1,13 @@
 // Internal declarations shared by the HIP translation units of libgem_hip.so (gfx950 only).
 #pragma once
+// gfx950: a packed fp32 VALU instruction whose op_sel takes the high half of its second source for the low result (the SLP vectoriser
+// forms them) returns a wrong low result in lanes 48-63 while another wavefront's bf16 MFMA executes on the same SIMD (DESIGN.md
+// section 4; tools/slp_hazard/pk_mfma_repro.hip reproduces it in isolation).  Every translation unit of this library is therefore
+// compiled with packed fp32 arithmetic switched off; a build that forgets the flag must not compile.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GEM_NO_PACKED_FP32)
+#error "compile with: -Xclang -target-feature -Xclang -packed-fp32-ops -DGEM_NO_PACKED_FP32 (__graft_entry__.NO_PACKED_FP32)"
+#endif
+
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <atomic>
@@ -133,6 +141,12 @@ struct Workspace {
     int* perm = nullptr;                // [B] slot -> window
     int* slot_of = nullptr;             // [B] window -> slot
     int* n_active = nullptr;            // [2] = {n_active, n_active*T}
+    // Slots handed out by lbfgs_advance itself (bf16 decoder mode with the fused tail, up to ATOMIC_COMPACT_MAX windows): a window
+    // that keeps iterating takes the next free slot of the coming round with one atomic add, so the rounds need no compact_kernel
+    // launch.  Two (perm, slot_of) buffer pairs alternate by round; a round's count lives in its n_log entry (zeroed at stage begin).
+    // `perm`, `slot_of`, `n_active` above always point at the CURRENT round's set; *_home are the allocations they return to.
+    int *perm2 = nullptr, *slot_of2 = nullptr, *perm_home = nullptr, *slot_of_home = nullptr, *n_active_home = nullptr;
+    int *next_perm = nullptr, *next_slot_of = nullptr, *next_count = nullptr;      // what lbfgs_advance of this round fills (nullptr: off)
     bool dyn = false;                   // rounds in flight: GEMM / energy launches read their row count from n_active
     int* n_log = nullptr;               // [N_LOG] n_active after every compaction (profiling: true row counts)
     long log_pos = 0, cur_log = -1;
@@ -302,6 +316,8 @@ __device__ inline void slab_layout(const SlabSrc& s, int& nslab, size_t& stride)
     }
 }
 bool rows_can_fuse_compaction(const gem_handle* h, const Layer& L, int lda, int ldc, int B, bool slabs);
+constexpr int ATOMIC_COMPACT_MAX = 4096;      // beyond: compact_kernel's stable scan (~4 us of a ~440 us round; B same-address atomics would not be free)
+bool bf16_rounds_take_slots_atomically(const gem_handle* h, int stage, int B);      // decoder_bf16.hip: fused bf16 tail right behind the composed front layer
 int launch_splitk_reduce(gem_handle* h, int epi, int nslab, size_t slab, const float* bias, const float* aux, float* C, int M, int N,
                          int ldc, const int* m_dev, hipStream_t s, int dyn_W = 0, int n_tiles = 0);
 // bf16-input MFMA variant of launch_gemm (gemm_bf16.hip): nprod = 1 (plain bf16) or 3 (hi/lo split, fp32-grade)

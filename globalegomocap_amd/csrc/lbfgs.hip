@@ -35,6 +35,7 @@ struct AdvArgs {
     uint16_t* trial_b;        // bf16 copy of the trial point for the bf16 decoder mode (nullptr: none)
     int* phase_arr;           // [B] copy of state.phase: what compact_kernel scans (4 bytes per window instead of the 1.2 KB record)
     const int* slot_of;       // window -> slot of its gradient row (nullptr: identity)
+    int *next_perm, *next_slot_of, *next_count;      // != nullptr: a window that keeps iterating takes its slot of the NEXT round here (one atomic add)
     SlabSrc gslab;            // base != nullptr: the gradient rows still lie in split-K slabs (summed here, in slab order)
     unsigned long long* clk;  // developer aid (GEM_LBFGS_CLK, -DGEM_LB_PROBE builds): [32] accumulated 100 MHz ticks per phase, [31] = windows counted
     int Dp, hist_cap;
@@ -602,6 +603,12 @@ __device__ __forceinline__ void lbfgs_advance_body(const AdvArgs& a) {
         ls_evals++;
     }
     if (tid == 0) {
+        if (a.next_count && phase != PH_DONE) {
+            // the next round's compaction, done here: slots in arrival order (no kernel of a round depends on the order)
+            const int slot = atomicAdd(a.next_count, 1);
+            a.next_perm[slot] = b;
+            a.next_slot_of[b] = slot;
+        }
         if (a.phase_arr) a.phase_arr[b] = phase;
         sp->phase = phase; sp->n_iter = n_iter; sp->evals = evals; sp->ls_iter = ls_iter; sp->ls_evals = ls_evals;
         sp->max_ls = max_ls; sp->first_bracket = first_bracket; sp->ls_done = ls_done; sp->insuf = insuf;
@@ -667,6 +674,7 @@ static AdvArgs make_args(gem_handle* h, const gem_lbfgs_opts& o) {
     a.trial_b = h->precision == GEM_PRECISION_BF16 ? w.trial_b : nullptr;
     a.phase_arr = w.phase;
     a.slot_of = w.dyn ? w.slot_of : nullptr;
+    a.next_perm = w.dyn ? w.next_perm : nullptr; a.next_slot_of = w.dyn ? w.next_slot_of : nullptr; a.next_count = w.dyn ? w.next_count : nullptr;
     a.gslab = w.dyn ? w.grad_slab : SlabSrc{};
     a.clk = w.lbfgs_clk;
     a.Dp = h->Dp; a.hist_cap = w.hist_cap; a.o = o;        // hist_cap: power of two (gem_create)

@@ -267,6 +267,9 @@ __device__ __forceinline__ void stage_input(const StageIn si, unsigned char* lds
 // PROBE: per-phase timestamps of workgroup 0 into a.dbg_ts (tools/tail16_bench); the product launches the probe-free instances.
 // NRT: row tiles per workgroup (1 .. 5 = 1, 3, 4, 6, 8 windows of 10 frames): see tail_bf16_row_tiles -- 1536 windows are 192
 // workgroups of 8 (a quarter of the chip idle), 256 of 6 (every CU) or 512 of 3 (two per CU: the fastest).
+#ifdef GEM_TB_DEBUG_DUMP
+__device__ uint16_t* g_tb_dump_gd = nullptr;
+#endif
 template <bool DENSE, int NRT, bool PROBE>
 __global__ __launch_bounds__(THREADS, DENSE ? 4 : 2) void decoder_tail_bf16_kernel(TailB16Args a) {
     constexpr int RING = DENSE ? 3 : 6, AFD = DENSE ? 1 : 2;
@@ -422,6 +425,13 @@ __global__ __launch_bounds__(THREADS, DENSE ? 4 : 2) void decoder_tail_bf16_kern
     for (int i = 0; i < RING; ++i) ring[i] = wp[(size_t)min(consumed + i, last_step) * 64 + lane];
     lds_barrier();
     TB_PROBE();
+#ifdef GEM_TB_DEBUG_DUMP          // developer harness only (tools/tail16_bench): the bf16 gradient rows w.r.t. the pose, as the energy terms left them
+    if (g_tb_dump_gd)
+        for (int i = tid; i < R * PAD; i += THREADS) {
+            const int r = i / PAD, c = i - r * PAD;
+            g_tb_dump_gd[(row0 + r) * PAD + c] = *reinterpret_cast<const uint16_t*>(lds + a.off_act[NL] + r * a.ld_act[NL] + c * 2);
+        }
+#endif
 
     // ---- backward-data layers (adjoint convs): gradient w.r.t. act[j] into the buffer of act[j], masked by LeakyReLU'(act[j])
 #pragma nounroll

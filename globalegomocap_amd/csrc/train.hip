@@ -25,6 +25,8 @@
 #include <cstring>
 #include <memory>
 
+#include <limits>
+
 #include "gem_internal.h"
 #include "conv_rows.h"
 
@@ -1287,14 +1289,17 @@ int gem_trainer_download(gem_trainer* t, int what, float* dst, int64_t n) {
     const float* src = what == 0 ? t->P : what == 1 ? t->G : what == 2 ? t->S : what == 3 ? t->M1 : what == 4 ? t->M2 : nullptr;
     const size_t want = what == 2 ? t->n_stats : t->n_params;
     if (!src || (size_t)n != want) { set_error("gem_trainer_download: bad selector or size"); return 1; }
-    if (what == 1 && t->grads_partial) {
-        set_error("gem_trainer_download: the last step ran with update = 2 (linear-layer weight gradients formed inside their Adam step): "
-                  "the gradient arena is incomplete; step with update = 0 or 1 to read gradients");
-        return 1;
-    }
+
     GEM_HIP(hipSetDevice(t->h->cfg.device));
     GEM_HIP(hipDeviceSynchronize());
     GEM_HIP(hipMemcpy(dst, src, want * sizeof(float), hipMemcpyDeviceToHost));
+    if (what == 1 && t->grads_partial) {
+        // the last step ran with update = 2: the linear layers formed their weight gradients inside their Adam step and left nothing
+        // in the arena -- those ranges read as NaN ("not available"), never as the stale values of an earlier step
+        const float nanv = std::numeric_limits<float>::quiet_NaN();
+        std::fill(dst + t->fc.ow, dst + t->fc.ow + (size_t)t->fc.N * t->fc.K, nanv);
+        std::fill(dst + t->dec_in.ow, dst + t->dec_in.ow + (size_t)t->dec_in.N * t->dec_in.K, nanv);
+    }
     return 0;
 }
 int gem_trainer_set_step(gem_trainer* t, int64_t step) {

@@ -58,6 +58,7 @@ class WindowEngine:
         self.T, self.D = self.shape.seq_len, self.shape.latent_dim
         self.precision = "f32"
         self._graphs, self._gstream, self._bufs = False, None, {}
+        self._pinned = {}          # graph mode: signature (input addresses) -> the caller's input tensors, kept alive (see _pin)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -83,8 +84,32 @@ class WindowEngine:
         tensors from call to call to get replays."""
         _capi.check(self.lib.gem_graph_enable(self._h, 1 if on else 0), self.lib)
         self._graphs = bool(on)
+        if not on:
+            self._pinned.clear()          # (gem_graph_enable(0) dropped the captured calls)
         if on and self._gstream is None:
             self._gstream = torch.cuda.Stream(device=self.device)
+
+    MAX_PINNED = 4
+
+    def drop_graphs(self):
+        """Forget every captured call (gem_graph_enable 0 / 1: synchronises the device) and release the input tensors they pinned."""
+        _capi.check(self.lib.gem_graph_enable(self._h, 0), self.lib)
+        if self._graphs:
+            _capi.check(self.lib.gem_graph_enable(self._h, 1), self.lib)
+        self._pinned.clear()
+
+    def _pin(self, *tensors):
+        """A captured call holds the ADDRESSES of the caller's input tensors.  If the caller freed them, a later tensor could land on
+        the same addresses and the old graph would be replayed on it -- on ROCm 7.2 that ended in a GPU memory fault even for
+        equally sized buffers.  So the engine keeps the inputs of every signature it has seen alive (at most
+        MAX_PINNED distinct input sets; one more drops all graphs and pins).  `drop_graphs()` releases them explicitly."""
+        if not self._graphs:
+            return
+        key = tuple(t.data_ptr() for t in tensors if t is not None)
+        if key not in self._pinned:
+            if len(self._pinned) >= self.MAX_PINNED:
+                self.drop_graphs()
+            self._pinned[key] = tensors
 
     def graph_stats(self):
         c, r = C.c_int64(), C.c_int64()
@@ -224,6 +249,7 @@ class WindowEngine:
         if self._graphs:
             p, mb, eps_t = (self._staged("stage%d_%s" % (stage, k), t) for k, t in (("pose", p), ("mb", mb), ("eps", eps_t)))
             f0 = self._staged("stage%d_f0" % stage, f0) if f0 is not None else None
+            self._pin(heat_t)
         opts = opts or _capi.default_lbfgs_opts()
         out = self._out("stage%d_out" % stage, (B, self.T, N_JOINTS, 3), torch.float32)
         stats = self._out("stage%d_stats" % stage, (B, 4), torch.int32, zero=True) if want_stats else None
@@ -258,6 +284,7 @@ class WindowEngine:
         if F < self.T:
             raise ValueError("optimize_windows: %d frames cannot hold a %d-frame window" % (F, self.T))
         opts = opts or _capi.default_lbfgs_opts()
+        self._pin(local_pose, cams, heat, frame0, mean_bone, eps_local, eps_global)
         mid = self._out("win_mid", (B, self.T, N_JOINTS, 3), torch.float32)
         glob = self._out("win_glob", (B, self.T, N_JOINTS, 3), torch.float64)
         stats = self._out("win_stats", (2 * B, 4), torch.int32, zero=True) if want_stats else None

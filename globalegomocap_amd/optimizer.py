@@ -165,7 +165,8 @@ def main(data_id, camera_model_path, vae_weight, gmm_weight, smoothness_weight, 
          device_metrics=False):
     """pickle in, poses out -- the reference's `main` (optimizer.py:311-507) for one chunk directory.
 
-    Returns (errors OrderedDict[18], final_estimated_seq, mid_local_pose_seq, final_optimized_seq, final_gt_seq).
+    Returns (errors OrderedDict[18], final_estimated_seq, mid_local_pose_seq, final_optimized_seq, final_gt_seq): lists of [15,3]
+    frames like the reference's merge_batches, final_optimized_seq an ndarray [N',15,3] when final_smooth is True (list otherwise).
     device_metrics=True keeps the optimised windows on the device and runs the overlap merge, the Gaussian
     smoothing and `calculate_errors` there (gem_merge_windows / gem_calculate_errors) instead of in numpy.
     """
@@ -213,5 +214,8 @@ def main(data_id, camera_model_path, vae_weight, gmm_weight, smoothness_weight, 
         errors = opt.engine.calculate_errors(final_estimated_seq, mid_estimated_seq, final_optimized_d, final_gt_seq)
     else:
         errors = calculate_errors(final_estimated_seq, mid_estimated_seq, final_optimized_seq, final_gt_seq)
-    res = (errors, list(final_estimated_seq), list(mid_local_pose_seq), final_optimized_seq, list(final_gt_seq))
+    # The reference's merge_batches returns a LIST of [15,3] frames (optimizer.py:425-437); only the final Gaussian smoothing
+    # (optimizer.py:448-450: gaussian_filter1d) turns final_optimized_seq into an ndarray -- same container types here.
+    opt_out = final_optimized_seq if final_smooth is True else list(np.asarray(final_optimized_seq))
+    res = (errors, list(final_estimated_seq), list(mid_local_pose_seq), opt_out, list(final_gt_seq))
     return res + (stats,) if return_stats else res

@@ -217,6 +217,7 @@ class VAETrainer:
                                        recon_sum=1 if recon_reduction == "sum" else 0, reserved=0)
         self.steps = 0
         self.forwards = 0
+        self._fused_last = False         # the last step ran in the training-loop mode (gem_trainer_step update = 2)
         self._grad = None
         self._losses = torch.zeros(3, dtype=torch.float64, device=self.device)
         self._gen = torch.Generator(device=self.device)
@@ -329,8 +330,11 @@ class VAETrainer:
         return out
 
     def gradients(self):
-        """The gradients of the last step, keyed like the parameters (p.grad after loss.backward())."""
-        return unpack_arena(self._down(1), self.shape)
+        """The gradients of the last step, keyed like the parameters (p.grad after loss.backward()).  After a training-loop step
+        (keep_gradients=False) the two linear layers' weight gradients were never written out: those keys are absent (the library
+        hands their arena ranges back as NaN), never the stale values of an earlier step."""
+        g = unpack_arena(self._down(1), self.shape)
+        return OrderedDict((k, v) for k, v in g.items() if not np.isnan(np.asarray(v)).all()) if self._fused_last else g
 
     def optimizer_state(self):
         """Adam's exp_avg / exp_avg_sq per parameter key and the step count (optimizer.state_dict())."""
@@ -361,6 +365,7 @@ class VAETrainer:
         _capi.check(self.lib.gem_trainer_step(self._t, B, x.data_ptr(), e.data_ptr(), C.byref(self.opts),
                                               (1 if keep_gradients else 2) if update else 0, self._losses.data_ptr(), C.c_void_p(s)), self.lib)
         self.forwards += 1               # every train-mode forward updates the running statistics (like torch's BatchNorm)
+        self._fused_last = bool(update) and not keep_gradients
         if update:
             self.steps += 1
         if not sync:

@@ -180,6 +180,10 @@ int gem_set_texel_cache(gem_handle* h, int on);
  * kernel launches per call.  Results are bitwise those of the eager path.  Needs a non-default stream (the legacy default
  * stream cannot be captured: such calls stay eager) and profiling off.  The caller must pass the SAME buffers to get
  * replays; a call with other pointers is a new signature (at most 16 are cached per handle).
+ * A captured call holds the ADDRESSES of the caller's buffers.  A caller that frees buffers a captured call used must call
+ * gem_graph_enable(h, 0) first -- it synchronises the device and drops every cached graph (gem_graph_enable(h, 1) switches replay
+ * on again) -- so that no graph can be replayed on whatever is allocated at those addresses next (ROCm 7.2: such a replay ended in
+ * a GPU memory access fault even with equally sized new buffers at the same addresses).
  * gem_graph_stats: number of captures and replays so far. */
 int gem_graph_enable(gem_handle* h, int on);
 int gem_graph_stats(gem_handle* h, int64_t* n_captures, int64_t* n_replays);
@@ -236,7 +240,8 @@ int gem_profile_kernels(gem_handle* h, int family, char* buf, int buf_len);
  * `update` is non-zero -- one torch.optim.Adam step (train.py:60: lr, betas, eps, L2 weight_decay added to the gradient).
  * update = 1 leaves every gradient in the gradient arena (p.grad after the step).  update = 2 is the training loop's mode: the two
  * linear layers (fc_mu | fc_var, decoder_input: 97 % of the parameters) form their weight gradient INSIDE their Adam step and do
- * not write it to the arena (their arena entries are stale afterwards); parameters, moments, statistics and losses are the same
+ * not write it to the arena (afterwards gem_trainer_download(what = 1) returns NaN in those two ranges, and gem_trainer_arena(what = 1)
+ * / gem_trainer_apply fail until a step with update = 0 or 1 has filled the arena again); parameters, moments, statistics and losses are the same
  * up to summation order (at batches of at most 64 windows the same pass over the weights also forms the layers' backward-data
  * products; what Adam's eps makes of last-bit differences: tests/test_hip_train.py::test_training_loop_mode_steps_like_the_default_mode).
  *
@@ -254,7 +259,7 @@ int gem_profile_kernels(gem_handle* h, int family, char* buf, int buf_len);
  *   d_pose    [B,T,3J] f32 device   the batch (train.py:82 after the float() cast)
  *   d_eps     [B,D]    f32 device   the reparameterisation noise (torch.randn_like at SeqConvVAE.py:167)
  *   d_losses  [3]      f64 device   loss, Reconstruction_Loss, KLD (may be NULL)
- * 2 <= B <= cfg.max_windows.  Everything is enqueued on `stream`; nothing synchronises. */
+ * 2 <= B <= cfg.max_windows; update must be 0, 1 or 2.  Everything is enqueued on `stream`; nothing synchronises. */
 typedef struct gem_trainer gem_trainer;
 typedef struct gem_train_opts {
     double  lr, beta1, beta2, eps, weight_decay;   /* torch.optim.Adam: 1e-3, 0.9, 0.999, 1e-8, train.py's --weight_decay */

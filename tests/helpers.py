@@ -114,14 +114,16 @@ def check_full_training_step(c, losses, grads, params, running, loss_rtol, grad_
     np.testing.assert_allclose(losses, c["losses"], rtol=loss_rtol)
     gmax = max(float(v[1]) for v in c["gnorm"].values())
     for k, idx in c["idx"].items():
-        g = np.asarray(grads[k], np.float64).reshape(-1)
-        ref_norm, ref_max = (float(v) for v in c["gnorm"][k])
         if k.endswith(".0.bias") and not k.startswith("final_layer.3"):
             # a conv bias in front of a BatchNorm: its exact gradient is zero, both sides hold rounding noise
-            assert np.abs(g).max() <= 5e-6 * gmax, (k, np.abs(g).max())
+            if k in grads:
+                assert np.abs(np.asarray(grads[k], np.float64)).max() <= 5e-6 * gmax, (k, np.abs(np.asarray(grads[k])).max())
             continue
-        assert abs(np.linalg.norm(g) - ref_norm) <= grad_tol * ref_norm + 1e-7 * gmax, (k, np.linalg.norm(g), ref_norm)
-        assert np.abs(g[idx] - c["grad"][k]).max() <= grad_tol * ref_max + 2e-7 * gmax, (k, np.abs(g[idx] - c["grad"][k]).max(), ref_max)
+        if k in grads:          # (the training-loop mode never writes the linear layers' weight gradients out: `grads` lacks those keys)
+            g = np.asarray(grads[k], np.float64).reshape(-1)
+            ref_norm, ref_max = (float(v) for v in c["gnorm"][k])
+            assert abs(np.linalg.norm(g) - ref_norm) <= grad_tol * ref_norm + 1e-7 * gmax, (k, np.linalg.norm(g), ref_norm)
+            assert np.abs(g[idx] - c["grad"][k]).max() <= grad_tol * ref_max + 2e-7 * gmax, (k, np.abs(g[idx] - c["grad"][k]).max(), ref_max)
         # Adam moves an entry by ~lr whatever the size of its gradient: entries whose gradient is rounding noise may land on the
         # other side (2 lr apart); all others agree to a small fraction of lr
         d = np.abs(np.asarray(params[k], np.float64).reshape(-1)[idx] - c["param1"][k])

@@ -114,7 +114,7 @@ def test_full_size_partitions_emulated_8_ranks(fitted_weights_cache, workload, w
     independent (/root/reference/optimizer.py:370), the merge is optimizer.py:425-437: every window must finish, the gathered
     array must be in window order, the optimisation must improve the MPJPE, and the per-rank work (evaluations) and time must be
     balanced -- the only thing that can cost the 8-GPU scaling."""
-    line = _run_bench(["--gpus", "1", "--workload", workload, "--emulate-ranks", "8", "--steps", "2", "--warmup", "1", "--cpu-windows", "0",
+    line = _run_bench(["--gpus", "1", "--workload", workload, "--emulate-ranks", "8", "--steps", "3", "--warmup", "2", "--cpu-windows", "0",
                        "--weights-cache", fitted_weights_cache], {}, timeout=1500)
     cfg, part = line["config"], line["partition"]
     assert cfg["windows_total"] == windows and cfg["emulated_ranks"] == 8 and cfg["ranks"] == 1 and cfg["precision"] == "bf16"

@@ -325,6 +325,41 @@ def _device_problem(eng, n_frames, starts, seed, n_dup, chunk=100):
             "eps_l": eps[:, 0].contiguous().to(eng.device), "eps_g": eps[:, 1].contiguous().to(eng.device), "n_dup": n_dup}
 
 
+def _oracle_windows(p, sd_l, sd_g, windows, T=10, threads=8):
+    """Both stages of the fp32 CPU oracle (optimizer.py:242-276 chained as optimizer.py:370-423 does) for the listed windows of
+    problem `p`: {window: (global pose [T,15,3] f64, stats local stage, stats global stage)}.  Windows are independent: a thread pool
+    (numpy releases the GIL in its matrix products) brings 48 windows to about half a minute on the box's host cores."""
+    from concurrent.futures import ThreadPoolExecutor
+    vae_l, vae_g, cam = O.fold_vae(sd_l), O.fold_vae(sd_g), oracle_camera()
+    est_np, cams_np = p["seq"]["est_local_np"], p["seq"]["cams_np"]
+    mb_np, eps_l, eps_g = p["mb"].cpu().numpy(), p["eps_l"].cpu().numpy(), p["eps_g"].cpu().numpy()
+    heats = {int(b): p["seq"]["heat"][int(p["starts"][b]):int(p["starts"][b]) + T].cpu().numpy() for b in windows}
+
+    def one(b):
+        s = int(p["starts"][b])
+        a, sa = O.optimize_stage(vae_l, cam, O.Weights(*W_LOCAL), est_np[s:s + T], heats[b], mb_np[b], eps_l[b])
+        relo = O.relative_global(a, cams_np[s:s + T])
+        c, sb = O.optimize_stage(vae_g, cam, O.Weights(*W_GLOBAL), relo.astype(np.float32), heats[b], mb_np[b], eps_g[b])
+        return b, (O.to_global(c, cams_np[s:s + T]), sa, sb)
+    with ThreadPoolExecutor(threads) as ex:
+        return dict(ex.map(one, [int(b) for b in windows]))
+
+
+def _chunk_sequences_against_oracle(glob_np, refs, p, chunks, per=12):
+    """For every listed chunk: MPJPE (vs ground truth) of the merged + smoothed sequence (optimizer.py:425-450) built from the
+    oracle's windows and from `glob_np`'s, and the mean distance between the two sequences -- where north_star's 0.5 mm applies."""
+    out = []
+    for c in chunks:
+        w = list(range(c * per, (c + 1) * per))
+        gt = p["seq"]["gt_global"][c * 100:c * 100 + 98]
+        seq_or = final_smooth(merge_batches(np.stack([refs[b] for b in w])))
+        seq_hip = final_smooth(merge_batches(glob_np[w[0]:w[-1] + 1]))
+        out.append({"chunk": int(c), "mpjpe_oracle_mm": float(np.linalg.norm(seq_or - gt, axis=-1).mean() * 1e3),
+                    "mpjpe_hip_mm": float(np.linalg.norm(seq_hip - gt, axis=-1).mean() * 1e3),
+                    "sequence_diff_mm": float(np.linalg.norm(seq_or - seq_hip, axis=-1).mean() * 1e3)})
+    return out
+
+
 def _run(eng, p):
     return eng.optimize_windows(p["seq"]["est_local"], p["seq"]["cams"], p["seq"]["heat"], p["f0"], p["mb"], p["eps_l"], p["eps_g"],
                                 _ew(W_LOCAL), _ew(W_GLOBAL))
@@ -376,20 +411,11 @@ def _check_properties(torch, eng, p, sd_l, sd_g, spot, tag, pose_tol_mm, loss_rt
     assert (sn["final_loss"][B + idx] <= E0g.cpu().numpy().astype(np.float32) + slack * (1 + np.abs(E0g.cpu().numpy()))).all(), tag
     small.close()
     # oracle spot check: both stages chained on the CPU, fp32
-    vae_l, vae_g, cam = O.fold_vae(sd_l), O.fold_vae(sd_g), oracle_camera()
-    est_np, cams_np = p["seq"]["est_local_np"], p["seq"]["cams_np"]
-    mb_np = p["mb"].cpu().numpy()
-    eps_l, eps_g = p["eps_l"].cpu().numpy(), p["eps_g"].cpu().numpy()
+    T = 10
     glob_np = glob.cpu().numpy()
     rep = []
     refs = {}
-    for b in spot:
-        s = int(p["starts"][b])
-        hs = p["seq"]["heat"][s:s + T].cpu().numpy()
-        a, sa = O.optimize_stage(vae_l, cam, O.Weights(*W_LOCAL), est_np[s:s + T], hs, mb_np[b], eps_l[b])
-        relo = O.relative_global(a, cams_np[s:s + T])
-        c, sb = O.optimize_stage(vae_g, cam, O.Weights(*W_GLOBAL), relo.astype(np.float32), hs, mb_np[b], eps_g[b])
-        ref = O.to_global(c, cams_np[s:s + T])
+    for b, (ref, sa, sb) in _oracle_windows(p, sd_l, sd_g, spot).items():
         refs[int(b)] = ref
         d = np.linalg.norm(glob_np[b] - ref, axis=-1).mean()
         rep.append({"window": int(b), "diff_mm": float(d * 1e3), "evals": [int(sn["func_evals"][b]), int(sn["func_evals"][B + b])],
@@ -417,9 +443,10 @@ def _seq_mpjpe(glob, p, n_chunks, per):
 def test_config2_all_sequences_in_one_call_bf16(torch_cuda, friendly_vaes, tmp_path):
     """BASELINE configs[2]: "all 5 test-sequence shapes concurrently on 1 MI355X, bf16 VAE decoder / fp32 energy" -- five
     sequences of 20 + 27 + 27 + 27 + 27 chunks = 1536 windows, every window in ONE device call.
-    bf16 against the fp32 CPU ORACLE (north_star's tolerance): the 12 windows of the first chunk each within the bf16 activation
-    noise floor (see _check_properties), and the MPJPE of that chunk's merged + smoothed sequence within 0.5 mm of the oracle's; over all 126 chunks bf16 vs fp32 HIP (the
-    path pinned to the reference at 0.1 mm by the golden tests) within 0.5 mm as well."""
+    bf16 against the fp32 CPU ORACLE (north_star's tolerance): the 48 windows of FOUR chunks spread over the batch (0, 42, 85, 125)
+    each within the bf16 activation noise floor (see _check_properties), and the MPJPE of each of those chunks' merged + smoothed
+    sequences within 0.5 mm of the oracle's; over all 126 chunks bf16 vs fp32 HIP (the path pinned to the reference at 0.1 mm by the
+    golden tests) within 0.5 mm as well."""
     torch = torch_cuda
     sd_l, sd_g = friendly_vaes
     n_chunks, per = 128, 12
@@ -430,20 +457,18 @@ def test_config2_all_sequences_in_one_call_bf16(torch_cuda, friendly_vaes, tmp_p
     _, glob_f32, _ = _run(eng, p)
     mp_f32 = _seq_mpjpe(glob_f32, p, n_chunks - 2, per)          # (the last two chunks hold the duplicated windows)
     eng.set_precision("bf16")
-    mid, glob, sn, refs = _check_properties(torch, eng, p, sd_l, sd_g, spot=tuple(range(12)) + (640, 1511), tag="configs2_bf16",
-                                            pose_tol_mm=4.5, loss_rtol=2e-2)
+    # FOUR chunks spread over the batch (the last two chunks hold the duplicated windows) go to the oracle: 48 windows
+    or_chunks = (0, 42, 85, 125)
+    spot = tuple(b for c in or_chunks for b in range(c * per, (c + 1) * per)) + (640,)
+    mid, glob, sn, refs = _check_properties(torch, eng, p, sd_l, sd_g, spot=spot, tag="configs2_bf16", pose_tol_mm=4.5, loss_rtol=2e-2)
     mp_bf16 = _seq_mpjpe(glob, p, n_chunks - 2, per)
-    # chunk 0: the oracle's merged + smoothed sequence against the bf16 HIP one, both against the ground truth
-    gt0 = p["seq"]["gt_global"][:98]
-    seq_or = final_smooth(merge_batches(np.stack([refs[b] for b in range(12)])))
-    seq_hip = final_smooth(merge_batches(glob.cpu().numpy()[:12]))
-    mp_or0, mp_hip0 = np.linalg.norm(seq_or - gt0, axis=-1).mean(), np.linalg.norm(seq_hip - gt0, axis=-1).mean()
-    d0 = np.linalg.norm(seq_or - seq_hip, axis=-1).mean()
-    print("configs[2]: MPJPE f32 %.3f mm, bf16 %.3f mm over %d frames; chunk 0: oracle %.3f mm, bf16 HIP %.3f mm, sequence diff %.3f mm"
-          % (mp_f32 * 1e3, mp_bf16 * 1e3, (n_chunks - 2) * 98, mp_or0 * 1e3, mp_hip0 * 1e3, d0 * 1e3))
-    _report("configs2_mpjpe.json", {"mpjpe_f32_mm": mp_f32 * 1e3, "mpjpe_bf16_mm": mp_bf16 * 1e3, "chunk0_mpjpe_oracle_mm": mp_or0 * 1e3,
-                                    "chunk0_mpjpe_bf16_hip_mm": mp_hip0 * 1e3, "chunk0_sequence_diff_mm": d0 * 1e3})
-    assert abs(mp_hip0 - mp_or0) < 0.5e-3, (mp_hip0, mp_or0)      # north_star: MPJPE within 0.5 mm of the reference path
+    # per chunk: the oracle's merged + smoothed sequence against the bf16 HIP one, both against the ground truth
+    seqs = _chunk_sequences_against_oracle(glob.cpu().numpy(), refs, p, or_chunks, per)
+    print("configs[2]: MPJPE f32 %.3f mm, bf16 %.3f mm over %d frames; chunks vs oracle: %s"
+          % (mp_f32 * 1e3, mp_bf16 * 1e3, (n_chunks - 2) * 98, seqs))
+    _report("configs2_mpjpe.json", {"mpjpe_f32_mm": mp_f32 * 1e3, "mpjpe_bf16_mm": mp_bf16 * 1e3, "chunks_vs_oracle": seqs})
+    for r in seqs:                                                # north_star: MPJPE within 0.5 mm of the reference path
+        assert abs(r["mpjpe_hip_mm"] - r["mpjpe_oracle_mm"]) < 0.5 and r["sequence_diff_mm"] < 1.0, r
     assert abs(mp_bf16 - mp_f32) < 0.5e-3, (mp_bf16, mp_f32)
     eng.close()
 
@@ -493,14 +518,15 @@ def test_bf16_on_fitted_vae_against_the_oracle(torch_cuda):
     resolves to ~1-2 mm per rounding (the 3.5 mm per-window gate there); a FITTED network spreads a coordinate over many channels.
     Two full-size VAEs are fitted on the device (`fit_vae_device`, the bench's recipe and seeds: ~3 s each), BASELINE configs[2]'s
     1536 windows run in bf16 AND in fp32 (the control: two fp32 implementations of these 30-evaluation L-BFGS runs already part by a
-    few tenths of a mm per window), and the 12 windows of chunk 0 plus 12 spread over the batch are compared with the oracle.
+    few tenths of a mm per window), and the 48 windows of FOUR chunks spread over the batch (0, 42, 85, 127) are compared with the
+    oracle, window by window and as each chunk's merged + smoothed sequence.
 
     Measured (round 4, profiles/parity_r04_bf16_fitted_vs_oracle.json): bf16 0.5-2.4 mm per window (mean 1.3 mm) -- NOT the 1.0 mm
     the round-3 review hoped for: a decoded coordinate of ~1 m is a sum of ~200 bf16 products, each good to 2^-9, so ~1 mm of
     zero-mean noise per coordinate is what the format carries whatever the weights are.  It IS zero-mean: the chunk's merged +
     smoothed sequence -- where north_star's 0.5 mm applies -- differs from the oracle's by 0.06 mm MPJPE.
-    Asserted: bf16 per window <= 1.8 mm on average (<= 5 mm each), fp32 median <= 0.3 mm (<= 5 mm each: a trajectory that parts at a texel
-    edge), |dMPJPE| of the sequence <= 0.5 mm for both."""
+    Asserted: bf16 per window <= 1.5 mm on average (<= 5 mm each), fp32 median <= 0.3 mm (<= 5 mm each: a trajectory that parts at a texel
+    edge), |dMPJPE| of every one of the four chunks' sequences <= 0.5 mm for both."""
     torch = torch_cuda
     from globalegomocap_amd.vae_train import fit_vae_device
     from globalegomocap_amd.engine import stats_to_numpy
@@ -527,40 +553,30 @@ def test_bf16_on_fitted_vae_against_the_oracle(torch_cuda):
         sn = stats_to_numpy(stats)
         assert (sn["status"] == 1).all() and np.isfinite(glob.cpu().numpy()).all(), mode
         glob_np[mode] = glob.cpu().numpy()
-    vae_l, vae_g, cam = O.fold_vae(sd_l), O.fold_vae(sd_g), oracle_camera()
-    est_np, cams_np = p["seq"]["est_local_np"], p["seq"]["cams_np"]
-    mb_np, eps_l, eps_g = p["mb"].cpu().numpy(), p["eps_l"].cpu().numpy(), p["eps_g"].cpu().numpy()
-    spot = tuple(range(12)) + tuple(int(b) for b in np.linspace(12, B - 1, 12).astype(int))
+    # FOUR chunks spread over the batch against the oracle (48 windows): per window, and per chunk as the merged + smoothed sequence
+    or_chunks = (0, 42, 85, 127)
+    spot = tuple(b for c in or_chunks for b in range(c * per, (c + 1) * per))
     refs, rep = {}, []
-    for b in spot:
-        s = int(p["starts"][b])
-        hs = p["seq"]["heat"][s:s + T].cpu().numpy()
-        a, sa = O.optimize_stage(vae_l, cam, O.Weights(*W_LOCAL), est_np[s:s + T], hs, mb_np[b], eps_l[b])
-        relo = O.relative_global(a, cams_np[s:s + T])
-        c, sb = O.optimize_stage(vae_g, cam, O.Weights(*W_GLOBAL), relo.astype(np.float32), hs, mb_np[b], eps_g[b])
-        refs[b] = O.to_global(c, cams_np[s:s + T])
-        rep.append({"window": b, "bf16_diff_mm": float(np.linalg.norm(glob_np["bf16"][b] - refs[b], axis=-1).mean() * 1e3),
-                    "f32_diff_mm": float(np.linalg.norm(glob_np["f32"][b] - refs[b], axis=-1).mean() * 1e3),
+    for b, (ref, sa, sb) in _oracle_windows(p, sd_l, sd_g, spot).items():
+        refs[b] = ref
+        rep.append({"window": b, "bf16_diff_mm": float(np.linalg.norm(glob_np["bf16"][b] - ref, axis=-1).mean() * 1e3),
+                    "f32_diff_mm": float(np.linalg.norm(glob_np["f32"][b] - ref, axis=-1).mean() * 1e3),
                     "oracle_evals": [int(sa["func_evals"]), int(sb["func_evals"])]})
-    gt0 = p["seq"]["gt_global"][:98]
-    seq_or = final_smooth(merge_batches(np.stack([refs[b] for b in range(12)])))
-    mp_or0 = float(np.linalg.norm(seq_or - gt0, axis=-1).mean())
-    mp_hip0 = {m: float(np.linalg.norm(final_smooth(merge_batches(g[:12])) - gt0, axis=-1).mean()) for m, g in glob_np.items()}
+    seqs = {m: _chunk_sequences_against_oracle(g, refs, p, or_chunks, per) for m, g in glob_np.items()}
     d16 = np.array([r["bf16_diff_mm"] for r in rep])
     d32 = np.array([r["f32_diff_mm"] for r in rep])
-    _report("bf16_fitted_vs_oracle.json", {"windows": rep, "chunk0_mpjpe_oracle_mm": mp_or0 * 1e3,
-                                           "chunk0_mpjpe_hip_mm": {m: v * 1e3 for m, v in mp_hip0.items()},
+    _report("bf16_fitted_vs_oracle.json", {"windows": rep, "chunks_vs_oracle": seqs,
                                            "bf16_per_window_mm": {"min": d16.min(), "mean": d16.mean(), "max": d16.max()},
                                            "f32_per_window_mm": {"min": d32.min(), "mean": d32.mean(), "max": d32.max()}})
-    print("fitted VAEs vs oracle, per window: bf16 %.2f / %.2f / %.2f mm (min / mean / max), fp32 %.2f / %.2f / %.2f mm; chunk 0 MPJPE "
-          "oracle %.3f, bf16 %.3f, fp32 %.3f mm" % (d16.min(), d16.mean(), d16.max(), d32.min(), d32.mean(), d32.max(), mp_or0 * 1e3,
-                                                     mp_hip0["bf16"] * 1e3, mp_hip0["f32"] * 1e3))
+    print("fitted VAEs vs oracle, per window: bf16 %.2f / %.2f / %.2f mm (min / mean / max), fp32 %.2f / %.2f / %.2f mm; chunks: %s"
+          % (d16.min(), d16.mean(), d16.max(), d32.min(), d32.mean(), d32.max(), seqs))
     # (per-window maxima are the fragile statistic here: one L-BFGS trajectory that crosses a heat-map texel edge on the other side
     # ends millimetres away at nearly the same energy -- in fp32 as well; seen: 4.3 mm on one of 24 fp32 windows)
-    assert d16.max() <= 5.0 and d16.mean() <= 1.8, rep
+    assert d16.max() <= 5.0 and d16.mean() <= 1.5, rep
     assert d32.max() <= 5.0 and np.median(d32) <= 0.3 and d32.mean() <= 0.8, rep
     for m in ("bf16", "f32"):
-        assert abs(mp_hip0[m] - mp_or0) <= 0.5e-3, (m, mp_hip0[m], mp_or0)
+        for r in seqs[m]:
+            assert abs(r["mpjpe_hip_mm"] - r["mpjpe_oracle_mm"]) <= 0.5, (m, r)
     eng.close()
 
 

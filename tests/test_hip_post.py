@@ -280,3 +280,91 @@ def test_equal_chunks_take_the_vectorised_report_path_and_the_sidecar_cache(gold
             np.testing.assert_allclose(summary[k], ref, rtol=0, atol=tol, err_msg=k)
     # cache vs pickle: the same device inputs, so the same results bit for bit
     assert np.array_equal(np.asarray(runs[0][3]), np.asarray(runs[2][3]))
+
+
+# ------------------------------------------------------------------------------------------------ INTEGRATION.md, executed
+def test_integration_md_ctypes_stub_runs_verbatim():
+    """The reference-side ctypes stub of INTEGRATION.md section 2 (what a maintainer would paste into
+    BodyPoseOptimizer.optimize_pose_seq_pytorch_LBFGS, /root/reference/optimizer.py:242-276), extracted from the markdown and
+    executed VERBATIM against libgem_hip.so -- its own CDLL handle, no argtypes, its own struct mirror -- with stand-ins for the
+    reference objects it reads (`self.fisheye_camera_model`, `self.kinematic_parents`, the weights, `state_dict` in ConvVAE module
+    order).  Its result must be bitwise what WindowEngine.optimize_stage returns for the same window and noise."""
+    import re
+    import textwrap
+    import types
+    import torch
+    from globalegomocap_amd import _capi, vae as V
+    from globalegomocap_amd.camera import FisheyeCamera
+    from globalegomocap_amd.engine import WindowEngine, energy_weights, LOCAL_STAGE
+    from globalegomocap_amd.skeleton import KINEMATIC_PARENTS
+    from globalegomocap_amd.vae_torch import MotionVAE
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    sec = text.split("## 2.", 1)[1]
+    code = re.search(r"```python\n(.*?)```", sec, flags=re.S).group(1)
+    assert "gem_optimize_stage" in code and "gem_load_vae" in code
+    ns = {}
+    exec("def stub(self, state_dict, relative_global_pose, heatmap_seq, GemLbfgsOpts):\n" + textwrap.indent(code, "    "), ns)
+    FULL = V.VAEShape()
+    cam = FisheyeCamera.from_json(DEFAULT_CALIBRATION)
+    sd_np = V.structured_state_dict(FULL, 7, feature_offset=0.0)
+    net = MotionVAE(FULL.latent_dim, FULL.seq_len, tuple(FULL.hidden))          # the reference's module layout: state_dict() in ConvVAE order, num_batches_tracked included
+    net.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in sd_np.items()}, strict=False)
+    state_dict = net.state_dict()
+    assert any(not v.dtype.is_floating_point for v in state_dict.values())
+    seq = synth.make_sequence(n_frames=10, seed=21, camera=cam)
+    pose = np.asarray(seq["estimated_local_skeleton"], dtype=np.float32)
+    heat = np.asarray(seq["heatmap_list"], dtype=np.float32)
+    eng = WindowEngine(FULL, cam, max_windows=8)
+    try:
+        eng.load_vae(LOCAL_STAGE, sd_np)
+        mb = eng.mean_bone_length(pose)
+        me = types.SimpleNamespace(fisheye_camera_model=types.SimpleNamespace(fisheye_inverse_polynomial=np.asarray(cam.poly_w2c),
+                                                                             img_center=np.array([cam.cx, cam.cy])),
+                                   kinematic_parents=list(KINEMATIC_PARENTS), weight_3d=1e-6, smooth_weight=1e-5, bone_length_weight=1e-2,
+                                   vae_weight=0.0, reproj_weight=1e-2, mean_bone_length=mb.reshape(1, 15).contiguous())
+        cwd = os.getcwd()
+        os.chdir(root)              # (the stub opens the library by its path relative to the repository)
+        try:
+            torch.manual_seed(5)
+            out = ns["stub"](me, state_dict, pose, heat, _capi.GemLbfgsOpts)
+        finally:
+            os.chdir(cwd)
+        torch.manual_seed(5)
+        eps = torch.randn(1, 2048)
+        ref, stats = eng.optimize_stage(LOCAL_STAGE, pose[None], mb, eps, energy_weights(1e-6, 1e-5, 1e-2, 0.0, 1e-2), heat, np.zeros(1, np.int32))
+        assert int(stats.cpu().numpy()[0, 3]) == 1 and int(stats.cpu().numpy()[0, 1]) > 5
+        assert out.shape == (10, 15, 3) and out.dtype == np.float32
+        assert np.array_equal(out, ref[0].cpu().numpy())
+        assert np.abs(out - pose).max() > 1e-4          # (the stage moved the pose)
+    finally:
+        eng.close()
+
+
+def test_main_returns_the_reference_container_types(golden, tmp_path):
+    """optimizer.main's 5-tuple like /root/reference/optimizer.py:425-450,506-507: merge_batches builds LISTS of [15,3] frames; only
+    final_smooth=True turns final_optimized_seq into an ndarray (gaussian_filter1d)."""
+    import pickle
+    import torch
+    from collections import OrderedDict
+    from globalegomocap_amd import optimizer as gopt
+    from helpers import sd_from_npz
+    g, lt = golden("pipeline_tiny"), golden("lbfgs_tiny")
+    data = synth.make_sequence(n_frames=100, seed=int(g["seq_seed"]))
+    d = tmp_path / "chunk0"
+    d.mkdir()
+    with open(d / "test_data.pkl", "wb") as f:
+        pickle.dump({k: data[k] for k in ("estimated_local_skeleton", "gt_global_skeleton", "camera_pose_list", "heatmap_list")}, f)
+    args = (str(d), DEFAULT_CALIBRATION, 0.0, 0.0, float(g["smooth"]), 0.01, float(g["weight_3d"]), 0.01)
+    for smooth in (False, True):
+        torch.manual_seed(int(g["eps_seed"]))
+        res = gopt.main(*args, final_smooth=smooth, global_vae_path=sd_from_npz(lt, "global/"), local_vae_path=sd_from_npz(lt, "local/"),
+                        eps=torch.randn(24, 32))
+        errors, est, mid, opt, gt = res
+        assert isinstance(errors, OrderedDict) and len(errors) == 18
+        for name, seq_ in (("final_estimated_seq", est), ("mid_local_pose_seq", mid), ("final_gt_seq", gt)):
+            assert isinstance(seq_, list) and len(seq_) == 98 and np.asarray(seq_[0]).shape == (15, 3), name
+        if smooth:
+            assert isinstance(opt, np.ndarray) and opt.shape == (98, 15, 3) and opt.dtype == np.float64
+        else:
+            assert isinstance(opt, list) and len(opt) == 98 and opt[0].shape == (15, 3) and opt[0].dtype == np.float64

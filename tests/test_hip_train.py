@@ -16,19 +16,27 @@ def _close(a, b, rtol, scale_atol, msg):
     np.testing.assert_allclose(a, b, rtol=rtol, atol=scale_atol * max(1e-30, float(np.abs(b).max())), err_msg=msg)
 
 
+LINEAR_WEIGHTS = ("fc_mu.weight", "fc_var.weight", "decoder_input.weight")
+
+
+@pytest.mark.parametrize("loop_mode", [False, True])
 @pytest.mark.parametrize("case", ["mn", "sum"])
-def test_training_steps_against_the_reference_run(golden, case):
+def test_training_steps_against_the_reference_run(golden, case, loop_mode):
+    """Three to four steps of the unmodified reference (ConvVAE + torch.optim.Adam at its eps = 1e-8, tests/golden/train_tiny.npz)
+    in both step modes of the trainer: update = 1 (every gradient left in the arena) and update = 2 = the training loop's mode (what
+    VAETrainer.fit and fit_vae_device run: the linear layers' weight gradients formed inside their Adam step) -- losses, the
+    gradients the mode leaves, parameters, Adam moments and running statistics against the reference's."""
     from globalegomocap_amd.vae_train import VAETrainer
     c = train_golden_case(golden("train_tiny"), case)
     tr = VAETrainer(c["shape"], batch_size=c["batch"], lr=c["lr"], weight_decay=c["wd"], state_dict=c["init"],
                     recon_reduction="sum" if c["form"] == "kl_weight" else "mean")
     try:
         for s in range(c["steps"]):
-            out = tr.step(c["poses"][s], c["w"], eps=c["eps"][s])
+            out = tr.step(c["poses"][s], c["w"], eps=c["eps"][s], keep_gradients=not loop_mode)
             np.testing.assert_allclose(out, c["losses"][s], rtol=5e-5)
             if s == 0:
                 g = tr.gradients()
-                assert set(g) == set(c["grad0"])
+                assert set(g) == set(c["grad0"]) - (set(LINEAR_WEIGHTS) if loop_mode else set())
                 gmax = max(float(np.abs(v).max()) for v in c["grad0"].values())
                 for k, v in g.items():
                     r = c["grad0"][k]
@@ -58,20 +66,53 @@ def test_training_steps_against_the_reference_run(golden, case):
         tr.close()
 
 
-def test_full_size_training_step_against_the_reference_run(golden):
+@pytest.mark.parametrize("loop_mode", [False, True])
+def test_full_size_training_step_against_the_reference_run(golden, loop_mode):
     """ONE device step at D = 2048, batch 8, against the unmodified reference's own step (tests/golden/train_full.npz, made by
     oracle/make_golden_train.py --full from networks/train.py:77-83 + SeqConvVAE.py:191-219): losses, every tensor's gradient
-    2-norm and 256 sampled entries at 1e-4, the sampled parameters after Adam, the BatchNorm running statistics."""
+    2-norm and 256 sampled entries at 1e-4, the sampled parameters after Adam, the BatchNorm running statistics -- in both step
+    modes (loop_mode = gem_trainer_step update = 2, the mode the training loop runs; its linear-layer weight gradients are never
+    written out, their PARAMETERS after the step are compared like everyone else's)."""
     from globalegomocap_amd.vae_train import VAETrainer
     from helpers import train_full_case, check_full_training_step
     c = train_full_case(golden("train_full"))
     tr = VAETrainer(c["shape"], batch_size=64, lr=c["lr"], weight_decay=c["wd"], state_dict=c["init"])
     try:
-        losses = tr.step(c["poses"], c["w"], eps=c["eps"])
+        losses = tr.step(c["poses"], c["w"], eps=c["eps"], keep_gradients=not loop_mode)
         sd = tr.state_dict()
-        check_full_training_step(c, losses, tr.gradients(), sd, sd, loss_rtol=5e-5, grad_tol=1e-4)
+        grads = tr.gradients()
+        assert all((k in grads) != loop_mode for k in LINEAR_WEIGHTS)
+        check_full_training_step(c, losses, grads, sd, sd, loss_rtol=5e-5, grad_tol=1e-4)
+        if loop_mode:          # nothing hands out the incomplete arena as if it were whole
+            from globalegomocap_amd import _capi
+            with pytest.raises(_capi.GemError, match="incomplete"):
+                tr.arena_tensor(1)
     finally:
         tr.close()
+
+
+@pytest.mark.parametrize("batch", [96, 256])
+def test_step_modes_share_the_linear_layers_bits_between_65_and_256_windows(batch):
+    """For 64 < B <= 256 both step modes run the SAME backward-data kernels for the linear layers (the fused dX form of update = 2 is
+    for B <= 64 only), so the weight gradient a mode forms -- in the arena (update = 1) or inside the Adam step (update = 2) -- is a sum
+    over the same rows in the same order: parameters and both Adam moments of fc_mu | fc_var and decoder_input must come out BITWISE
+    equal after a step at the reference's eps = 1e-8 (csrc/train.hip: gemm_tn_adam_kernel against gemm_tn + adam_kernel)."""
+    from globalegomocap_amd.vae_train import VAETrainer, initial_state_dict, unpack_arena
+    init = initial_state_dict(FULL, 9)
+    poses = synth.make_training_windows(batch, FULL.seq_len, 6)
+    eps = np.random.default_rng(6).standard_normal((batch, FULL.latent_dim)).astype(np.float32)
+    a = VAETrainer(FULL, batch_size=batch, lr=1e-3, weight_decay=1e-5, state_dict=init)
+    b = VAETrainer(FULL, batch_size=batch, lr=1e-3, weight_decay=1e-5, state_dict=init)
+    try:
+        la = a.step(poses, 0.01, eps=eps)
+        lb = b.step(poses, 0.01, eps=eps, keep_gradients=False)
+        np.testing.assert_array_equal(la, lb)
+        for what in (0, 3, 4):
+            ua, ub = unpack_arena(a._down(what), FULL), unpack_arena(b._down(what), FULL)
+            for k in LINEAR_WEIGHTS:
+                assert np.array_equal(ua[k], ub[k]), (what, k, float(np.abs(ua[k] - ub[k]).max()))
+    finally:
+        a.close(); b.close()
 
 
 def test_full_size_training_step_against_the_port():
@@ -201,6 +242,12 @@ def test_trainer_rejects_bad_arguments():
             tr.step(np.zeros((1, 10, 45), np.float32), 0.1)
         with pytest.raises(ValueError):
             tr.step(np.zeros((4, 10, 44), np.float32), 0.1)
+        import ctypes as C
+        import torch
+        x = torch.zeros(4, 10, 45, device="cuda")
+        e = torch.zeros(4, 64, device="cuda")
+        for bad in (-1, 3):          # (gem_trainer_step: update is 0, 1 or 2 -- nothing else silently behaves like 1)
+            assert tr.lib.gem_trainer_step(tr._t, 4, x.data_ptr(), e.data_ptr(), C.byref(tr.opts), bad, None, None) != 0
     finally:
         tr.close()
 

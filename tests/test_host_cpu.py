@@ -27,6 +27,23 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert lib.gem_version() == 1
 
 
+def test_library_has_no_packed_fp32_arithmetic():
+    """gfx950: v_pk_{fma,mul,add}_f32 with op_sel on the second source return wrong lanes 48-63 beside another wavefront's bf16 MFMA
+    (tools/slp_hazard/pk_mfma_repro.hip).  The build switches the instructions off for every source
+    (__graft_entry__.NO_PACKED_FP32) and a translation unit compiled without the define does not compile (gem_internal.h); here the
+    linked library is disassembled: no packed fp32 arithmetic instruction may be left in any of its kernels."""
+    import re
+    import __graft_entry__ as ge
+    ge.build()
+    isa = ge.device_isa()
+    assert len(re.findall(r"\bs_endpgm\b", isa)) > 100          # (the disassembly really covers the kernels)
+    assert "v_mfma_f32_16x16x32_bf16" in isa.replace("v_mfma_f32_16x16x32bf16", "v_mfma_f32_16x16x32_bf16")
+    assert re.findall(r"\bv_pk_(?:fma|mul|add)_f32\b", isa) == []
+    assert ge.check_no_packed_fp32() > 100000
+    src = open(os.path.join(ROOT, "globalegomocap_amd", "csrc", "gem_internal.h")).read()
+    assert "#error" in src and "GEM_NO_PACKED_FP32" in src
+
+
 def test_struct_layouts_match_the_header():
     import ctypes as C
     from globalegomocap_amd import _capi

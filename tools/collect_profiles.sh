@@ -3,7 +3,7 @@
 # of the default bench command (BASELINE configs[1], fp32) and of the bf16 decoder mode at configs[2] / configs[3] sizes.
 #   gpurun --timeout 1200 -- 'bash tools/collect_profiles.sh r04'
 set -o pipefail
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=gpurun_out/${TAG}p
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p $OUT
@@ -17,15 +17,22 @@ run() {   # name, rocprof args, bench args
 run f32/trace      "--kernel-trace --stats" "--steps 5 --warmup 1"
 run f32/pmc_fetch  "--pmc FETCH_SIZE"       "--steps 2 --warmup 1 --no-profile"
 run f32/pmc_write  "--pmc WRITE_SIZE"       "--steps 2 --warmup 1 --no-profile"
+# third counter pass (round 5): MFMA pipe busy cycles (summed over the 1024 SIMDs) beside the active cycles of the same dispatches
+run f32/pmc_mfma   "--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "--steps 2 --warmup 1 --no-profile"
 # bf16 decoder mode: configs[2] (1536 windows in one call) and configs[3] per-GPU shard (8196 windows)
 run bf16_1536/trace     "--kernel-trace --stats" "--steps 5 --warmup 1 --workload 128 --precision bf16"
 run bf16_8192/trace     "--kernel-trace --stats" "--steps 3 --warmup 1 --workload w8192x --precision bf16"
 run bf16_8192/pmc_fetch "--pmc FETCH_SIZE"       "--steps 1 --warmup 1 --workload w8192x --precision bf16 --no-profile"
 run bf16_8192/pmc_write "--pmc WRITE_SIZE"       "--steps 1 --warmup 1 --workload w8192x --precision bf16 --no-profile"
+run bf16_8192/pmc_mfma  "--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "--steps 1 --warmup 1 --workload w8192x --precision bf16 --no-profile"
 run bf16_1536/pmc_fetch "--pmc FETCH_SIZE"       "--steps 2 --warmup 1 --workload 128 --precision bf16 --no-profile"
 run bf16_1536/pmc_write "--pmc WRITE_SIZE"       "--steps 2 --warmup 1 --workload 128 --precision bf16 --no-profile"
+run bf16_1536/pmc_mfma  "--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "--steps 2 --warmup 1 --workload 128 --precision bf16 --no-profile"
 # fp32 at configs[2] size (the LDS-DMA fp32 kernel takes over the decoder_input products)
 run f32_1536/trace      "--kernel-trace --stats" "--steps 3 --warmup 1 --workload 128"
+run f32_1536/pmc_fetch  "--pmc FETCH_SIZE"       "--steps 2 --warmup 1 --workload 128 --no-profile"
+run f32_1536/pmc_write  "--pmc WRITE_SIZE"       "--steps 2 --warmup 1 --workload 128 --no-profile"
+run f32_1536/pmc_mfma   "--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "--steps 2 --warmup 1 --workload 128 --no-profile"
 # the training step at the reference's batch of 64: kernel stats (traffic: tools/train_traffic.sh)
 mkdir -p $OUT/train
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train/trace -- python tools/train_bench.py 64 50 > $OUT/train/trace.log 2>&1 || { echo "FAILED train"; tail -5 $OUT/train/trace.log; exit 1; }
@@ -35,8 +42,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train1024/trace -- 
 grep "^B=" $OUT/train1024/trace.log
 # keep the summaries small: per-dispatch traces are dropped, the stats / counter tables stay
 find $OUT -name '*_kernel_trace.csv' -delete
-for d in f32 bf16_8192 bf16_1536; do
-  for k in pmc_fetch pmc_write; do
+for d in f32 bf16_8192 bf16_1536 f32_1536; do
+  for k in pmc_fetch pmc_write pmc_mfma; do
     f=$(find $OUT/$d/$k -name '*counter_collection.csv' | head -1)
     [ -n "$f" ] && python - "$f" <<'PY'
 import csv, sys, collections

@@ -64,6 +64,22 @@ def traffic(sub, dominant_substr, out_name, note_cmd, windows, precision):
         out["dominant_kernel"] = " + ".join(dom)
         out["hbm_bytes_per_launch"] = round(sum((out["kernels"][k]["read_bytes_corrected"] + out["kernels"][k]["write_bytes"]) *
                                                 out["kernels"][k]["dispatches"] for k in dom) / max(n, 1))
+    # third pass (round 5): SQ_VALU_MFMA_BUSY_CYCLES (MFMA-pipe busy cycles summed over the 1024 SIMDs) and GRBM_GUI_ACTIVE (summed over
+    # the 8 XCDs: / 8 = the dispatch's active cycles, profiler overhead of ~15-20 k cycles included) of the same command
+    f = newest(glob.glob(os.path.join(src, sub, "pmc_mfma", "*", "*counter_summary.csv")))
+    if f:
+        m = {}
+        for r in csv.DictReader(open(f[0])):
+            m.setdefault(short(r["kernel"]), {})[r["counter"]] = (float(r["mean_value"]), int(r["dispatches"]))
+        out["note_mfma"] = ("rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE, a third pass of the same command: "
+                            "mfma_busy_cycles = busy cycles of the matrix pipes summed over the 1024 SIMDs, per launch; gui_active_cycles = "
+                            "GRBM_GUI_ACTIVE / 8 XCDs (the profiled dispatch's ~15-20 k cycles of overhead included); mfma_busy_frac_of_active "
+                            "= mfma_busy_cycles / (1024 * gui_active_cycles)")
+        for k, v in m.items():
+            if k in out["kernels"] and "SQ_VALU_MFMA_BUSY_CYCLES" in v and "GRBM_GUI_ACTIVE" in v:
+                busy, act = v["SQ_VALU_MFMA_BUSY_CYCLES"][0], v["GRBM_GUI_ACTIVE"][0] / 8.0
+                out["kernels"][k].update({"mfma_dispatches": v["SQ_VALU_MFMA_BUSY_CYCLES"][1], "mfma_busy_cycles": round(busy),
+                                          "gui_active_cycles": round(act), "mfma_busy_frac_of_active": round(busy / (1024.0 * act), 4) if act else None})
     json.dump(out, open(os.path.join(dst, out_name), "w"), indent=1)
     return out
 
@@ -116,6 +132,8 @@ b = traffic("bf16_8192", "gemm_glds_kernel<false, 1, |gemm_big_kernel", "traffic
             "python bench.py --steps 1 --warmup 1 --workload w8192x --precision bf16 --cpu-windows 0 --no-extra --no-profile", 8192, "bf16")
 c = traffic("bf16_1536", "gemm_glds_kernel<false, 1, ", "traffic_%s_bf16_1536_windows.json" % tag,
             "python bench.py --steps 2 --warmup 1 --workload 128 --precision bf16 --cpu-windows 0 --no-extra --no-profile", 1536, "bf16")
+d = traffic("f32_1536", "gemm_glds_kernel<true, 1, |gemm_f32_kernel<1, ", "traffic_%s_f32_1536_windows.json" % tag,
+            "python bench.py --steps 2 --warmup 1 --workload 128 --cpu-windows 0 --no-extra --no-profile", 1536, "f32")
 if b:
     for k, v in b["kernels"].items():
         if "glds" in k or "big" in k or "lbfgs" in k or "energy" in k or "tail" in k:

@@ -1,5 +1,5 @@
 // Stand-alone timing harness for csrc/tail_bf16.hip (developer tool): per-phase timestamps of workgroup 0 and launch times.
-//   hipcc -w --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -o tools/tail16_bench tools/tail16_bench.hip && ./tools/tail16_bench 1536 [nslab]
+//   hipcc -w --offload-arch=gfx950 -O3 -std=c++17 -Xclang -target-feature -Xclang -packed-fp32-ops -DGEM_NO_PACKED_FP32 -o tools/tail16_bench tools/tail16_bench.hip && ./tools/tail16_bench 1536 [nslab]
 //   TAIL_DETERMINISM=1 [TAIL_HEAT=1] [TAIL_SCRAMBLE=1] ./tools/tail16_bench 8192: repeated launches must write bitwise identical rows
 #include <cstdio>
 #include <cstdlib>
@@ -123,6 +123,17 @@ int main(int argc, char** argv) {
         hipMemcpy((void*)a.a_in_b, hin.data(), hin.size() * 2, hipMemcpyHostToDevice);
         std::vector<uint16_t> ref(rows * 256), cur(rows * 256);
         int bad_launches = 0;
+#ifdef GEM_TB_DEBUG_DUMP
+        uint16_t* d_gd; hipMalloc(&d_gd, rows * 64 * 2); hipMemset(d_gd, 0, rows * 64 * 2);
+        hipMemcpyToSymbol(HIP_SYMBOL(gem::tb::g_tb_dump_gd), &d_gd, sizeof(d_gd));
+        float* d_xp; hipMalloc(&d_xp, rows * 64 * 4); hipMemset(d_xp, 0, rows * 64 * 4);
+        a.Xp = d_xp;
+        float* d_ep; hipMalloc(&d_ep, (size_t)B * 150 * 8 * 4); hipMemset(d_ep, 0, (size_t)B * 150 * 8 * 4);
+        hipMemcpyToSymbol(HIP_SYMBOL(gem::g_ep_dump), &d_ep, sizeof(d_ep));
+        std::vector<float> ep_ref((size_t)B * 150 * 8), ep_cur((size_t)B * 150 * 8);
+        std::vector<uint16_t> gd_ref(rows * 64), gd_cur(rows * 64);
+        std::vector<float> xp_ref(rows * 64), xp_cur(rows * 64);
+#endif
         for (int rep = 0; rep < 12; ++rep) {
             hipMemsetAsync(a.g_out_b, 0xFF, rows * 256 * 2, s);
             if (getenv("TAIL_SCRAMBLE")) {
@@ -133,6 +144,42 @@ int main(int argc, char** argv) {
             launch_tail_bf16(&h, a, lds, s);
             hipStreamSynchronize(s);
             hipMemcpy(rep ? cur.data() : ref.data(), a.g_out_b, rows * 256 * 2, hipMemcpyDeviceToHost);
+#ifdef GEM_TB_DEBUG_DUMP
+            hipMemcpy(rep ? gd_cur.data() : gd_ref.data(), d_gd, rows * 64 * 2, hipMemcpyDeviceToHost);
+            hipMemcpy(rep ? xp_cur.data() : xp_ref.data(), d_xp, rows * 64 * 4, hipMemcpyDeviceToHost);
+            hipMemcpy(rep ? ep_cur.data() : ep_ref.data(), d_ep, ep_cur.size() * 4, hipMemcpyDeviceToHost);
+            if (rep) {
+                size_t cnt[8] = {0}; int shown2 = 0;
+                for (size_t i = 0; i < ep_cur.size(); ++i)
+                    if (memcmp(&ep_cur[i], &ep_ref[i], 4)) {
+                        ++cnt[i % 8];
+                        if (shown2 < 4 && i % 8 == 3) {
+                            const size_t b8 = i - 3;
+                            printf("      fields ref:"); for (int k = 0; k < 8; ++k) printf(" %.9g", ep_ref[b8 + k]);
+                            printf("\n      fields cur:"); for (int k = 0; k < 8; ++k) printf(" %.9g", ep_cur[b8 + k]);
+                            printf("\n      rho*a+c = %.9g\n", (double)ep_ref[b8 + 5] * ep_ref[b8 + 0] + ep_ref[b8 + 1]);
+                        }
+                        if (shown2 < 4) { ++shown2; printf("    ep differs: window %zu pair %zu (lane %zu) field %zu: %g vs %g\n", i / 8 / 150, (i / 8) % 150, ((i / 8) % 150) & 63, i % 8, ep_ref[i], ep_cur[i]); }
+                    }
+                printf("  rep %d intermediates differing: a %zu c %zu inv %zu dudx %zu xx2 %zu rho %zu i3 %zu ux %zu\n", rep, cnt[0], cnt[1], cnt[2], cnt[3], cnt[4], cnt[5], cnt[6], cnt[7]);
+            }
+            if (rep) {
+                size_t nx = 0, ng = 0; int lanehist[64] = {0}, triphist[3] = {0}, comphist[3] = {0}, shown = 0;
+                for (size_t i = 0; i < xp_cur.size(); ++i) nx += memcmp(&xp_cur[i], &xp_ref[i], 4) != 0;
+                for (size_t i = 0; i < gd_cur.size(); ++i)
+                    if (gd_cur[i] != gd_ref[i]) {
+                        ++ng;
+                        const size_t row = i / 64; const int c = (int)(i % 64), t = (int)(row % T), j = c / 3, p = t * J + j;
+                        if (c < 45) { ++lanehist[p & 63]; ++triphist[p >> 6]; ++comphist[c % 3]; }
+                        if (shown < 6) { ++shown; printf("    gd differs: window %zu (wg %zu, win-in-wg %zu) t %d col %d (joint %d comp %d, pair %d = trip %d lane %d): %04x vs %04x\n",
+                                                         row / T, row / T / 8, (row / T) % 8, t, c, j, c % 3, p, p >> 6, p & 63, gd_ref[i], gd_cur[i]); }
+                    }
+                printf("  rep %d: pose values differing %zu, pose-gradient values differing %zu; by trip %d %d %d; by comp %d %d %d; by lane:", rep, nx, ng,
+                       triphist[0], triphist[1], triphist[2], comphist[0], comphist[1], comphist[2]);
+                for (int l = 0; l < 64; ++l) printf(" %d", lanehist[l]);
+                printf("\n");
+            }
+#endif
             if (!rep) continue;
             size_t nbad = 0; long first = -1;
             int colhist[16] = {0}, tilehist[5] = {0};
