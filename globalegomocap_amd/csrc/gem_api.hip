@@ -53,6 +53,17 @@ static void drop_graphs(gem_handle* h) {
     h->graphs.clear();
 }
 
+__global__ void fill_u32_kernel(uint32_t* __restrict__ p, uint32_t v, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+static int launch_fill_u32(uint32_t* p, uint32_t v, size_t n, hipStream_t s) {
+    if (!n) return 0;
+    hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, v, n);
+    GEM_HIP(hipGetLastError());
+    return 0;
+}
+
 template <typename T>
 static int dev_alloc(std::vector<void*>& owner, T** p, size_t n) {
     void* q = nullptr;
@@ -686,20 +697,23 @@ static int stage_begin(StageRun& r) {
             // rounds + 2 consecutive n_log entries: round 0's count (written by the compaction below), then one zeroed counter per round
             if ((w.log_pos % N_LOG) + r.rounds + 2 > N_LOG) w.log_pos += N_LOG - (w.log_pos % N_LOG);
             r.log0 = w.log_pos;
-            GEM_HIP(hipMemsetAsync(w.n_log + (r.log0 % N_LOG) + 1, 0, (size_t)(r.rounds + 1) * sizeof(int), s));
         }
-        if (launch_compact(h, B, 1, s)) return 1;          // identity: every window takes part in round 0 (logs B at n_log[log0])
+        // identity: every window takes part in round 0 (logs B at n_log[log0]); with atomic slots the kernel also zeroes the rounds' counters
+        if (launch_compact(h, B, 1, s, r.atomic_slots ? r.rounds + 1 : 0)) return 1;
         if (r.atomic_slots) w.log_pos = r.log0 + r.rounds + 2;
         w.dyn = true;
     }
     // texel-block cache of the reprojection term: valid for this stage's heat-maps / windows only
     static const bool no_tex = dev_env("GEM_NO_TEXCACHE") != nullptr;
     w.tex_on = !no_tex && h->tex_cache && w.tex_key && r.wt.reproj != 0.0;
-    if (w.tex_on) GEM_HIP(hipMemsetAsync(w.tex_key, 0xFF, (size_t)B * h->T * h->J * sizeof(int), s));
+    // (a fill KERNEL, not hipMemsetAsync: inside a captured graph a memset node was seen to run out of order with the kernels around it
+    // once two graphs replayed side by side on two streams -- round 5, ROCm 7.2; a late invalidation here would hand the stage texels
+    // of the previous contents of the heat-maps)
+    if (w.tex_on && launch_fill_u32(reinterpret_cast<uint32_t*>(w.tex_key), 0xFFFFFFFFu, (size_t)B * h->T * h->J, s)) return 1;
     r.ea = energy_args(h, r.pose_in, r.heat, r.frame0, r.mean_bone, r.wt);
     w.tex_on = false;
     // closure values of this stage, one row per round (0xFF bytes = NaN: "window took no evaluation in this round")
-    GEM_HIP(hipMemsetAsync(w.trace, 0xFF, (size_t)TRACE_ROUNDS * w.Bmax * sizeof(double), s));
+    if (launch_fill_u32(reinterpret_cast<uint32_t*>(w.trace), 0xFFFFFFFFu, (size_t)TRACE_ROUNDS * w.Bmax * 2, s)) return 1;
     // The active windows are re-packed between the rounds: by compact_kernel, or -- one sequence in fp32 -- inside the
     // decoder_input forward launch of the next round (gemm_rows.h; one launch and its boundary less per round).
     StageNet& net_ = h->net[stage];

@@ -430,7 +430,7 @@ int launch_lift(gem_handle* h, const float* heat, const double* depth, int F, co
 int launch_lbfgs_init(gem_handle* h, int B, const gem_lbfgs_opts& o, hipStream_t s);
 int launch_lbfgs_advance(gem_handle* h, int B, const gem_lbfgs_opts& o, hipStream_t s);
 int launch_lbfgs_stats(gem_handle* h, int B, gem_window_stats* out, hipStream_t s);
-int launch_compact(gem_handle* h, int B, int force_all, hipStream_t s);
+int launch_compact(gem_handle* h, int B, int force_all, hipStream_t s, int zero_after = 0);
 
 
 }  // namespace gem

@@ -720,9 +720,12 @@ int launch_lbfgs_advance(gem_handle* h, int B, const gem_lbfgs_opts& o, hipStrea
 
 // Stable partition of the windows: those still iterating first (slots [0, n)), finished ones behind.
 // One 1024-thread block; B is at most a few thousand.
+// zero_after: that many n_log entries BEHIND log_slot are zeroed here (the per-round counters of a stage whose rounds hand out their
+// slots atomically, gem_api.hip stage_begin) -- by this kernel rather than by a hipMemsetAsync node, so that inside a captured graph
+// the zeroing is ordered like every other kernel of the call
 __global__ __launch_bounds__(1024) void compact_kernel(const int* __restrict__ phase_arr, int B, int T, int* __restrict__ perm,
                                                        int* __restrict__ slot_of, int* __restrict__ n_active, int force_all,
-                                                       int* __restrict__ log_slot) {
+                                                       int* __restrict__ log_slot, int zero_after) {
     // One pass, two barriers (round 4; before: two passes over chunks of 1024 windows with three barriers each -- 14 us at 8192
     // windows): thread t owns the E consecutive windows [t E, (t + 1) E), E = ceil(B / 1024) <= 64.  ONE block scan of the
     // per-thread active counts places both groups: an active window goes to slot (#active before it), a finished one to
@@ -756,13 +759,15 @@ __global__ __launch_bounds__(1024) void compact_kernel(const int* __restrict__ p
         else { perm[pi] = b; slot_of[b] = pi++; }
     }
     if (tid == 0) { n_active[0] = total; n_active[1] = total * T; *log_slot = total; }
+    if (tid < zero_after) log_slot[1 + tid] = 0;
 }
 
-int launch_compact(gem_handle* h, int B, int force_all, hipStream_t s) {
+int launch_compact(gem_handle* h, int B, int force_all, hipStream_t s, int zero_after) {
     Workspace& w = h->ws;
     if (B > 65536) { set_error("compact: more than 65536 windows per call"); return 1; }      // (64 windows per thread of the scan)
+    if (zero_after < 0 || zero_after > 1024 || (w.log_pos % N_LOG) + zero_after >= N_LOG) { set_error("compact: bad counter range"); return 1; }
     hipLaunchKernelGGL(compact_kernel, dim3(1), dim3(1024), 0, s, w.phase, B, h->T, w.perm, w.slot_of, w.n_active, force_all,
-                       w.n_log + (w.log_pos % N_LOG));
+                       w.n_log + (w.log_pos % N_LOG), zero_after);
     GEM_HIP(hipGetLastError());
     w.cur_log = w.log_pos++;
     return 0;

@@ -648,3 +648,9 @@ int launch_tail_bf16(gem_handle* h, const TailB16Args& a, size_t lds_bytes, hipS
 }
 
 }  // namespace gem
+
+#ifdef GEM_TB_DEBUG_DUMP          // developer builds only (tools/r05_nrt_dump.py): where the kernels copy the pose-gradient rows to
+extern "C" int gem_debug_set_tb_dump(void* d_rows) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(gem::tb::g_tb_dump_gd), &d_rows, sizeof(d_rows)) == hipSuccess ? 0 : 1;
+}
+#endif

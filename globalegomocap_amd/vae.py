@@ -359,7 +359,7 @@ def load_checkpoint_file(path, trust=None):
     if trust is None:
         trust = os.environ.get("GEM_TRUST_CHECKPOINTS") == "1"
     allow = [np.dtype, np.ndarray]
-    for name in ("_core", "core"):                       # numpy 2.x / 1.x module layout
+    for name in (("_core",) if hasattr(np, "_core") else ("core",)):          # numpy 2.x / 1.x module layout
         mod = getattr(np, name, None)
         ma = getattr(mod, "multiarray", None)
         for fn in ("scalar", "_reconstruct"):

@@ -92,17 +92,19 @@ def test_full_size_training_step_against_the_reference_run(golden, loop_mode):
 
 
 @pytest.mark.parametrize("batch", [96, 256])
-def test_step_modes_share_the_linear_layers_bits_between_65_and_256_windows(batch):
+def test_step_modes_agree_on_the_linear_layers_between_65_and_256_windows(batch):
     """For 64 < B <= 256 both step modes run the SAME backward-data kernels for the linear layers (the fused dX form of update = 2 is
-    for B <= 64 only), so the weight gradient a mode forms -- in the arena (update = 1) or inside the Adam step (update = 2) -- is a sum
-    over the same rows in the same order: parameters and both Adam moments of fc_mu | fc_var and decoder_input must come out BITWISE
-    equal after a step at the reference's eps = 1e-8 (csrc/train.hip: gemm_tn_adam_kernel against gemm_tn + adam_kernel)."""
+    for B <= 64 only); what differs is where the weight gradient is summed -- into the arena (gemm_tn + adam_kernel, update = 1) or
+    inside the Adam step (gemm_tn_adam_kernel, update = 2: other strip order over the rows).  At the reference's eps = 1e-8, after one
+    step: identical losses (same forward), parameters of fc_mu | fc_var and decoder_input within a thousandth of the step lr (measured:
+    1 ulp, 9e-10), first moments to 1e-5 of their largest entry, second moments to 1e-5 relative."""
     from globalegomocap_amd.vae_train import VAETrainer, initial_state_dict, unpack_arena
     init = initial_state_dict(FULL, 9)
     poses = synth.make_training_windows(batch, FULL.seq_len, 6)
     eps = np.random.default_rng(6).standard_normal((batch, FULL.latent_dim)).astype(np.float32)
-    a = VAETrainer(FULL, batch_size=batch, lr=1e-3, weight_decay=1e-5, state_dict=init)
-    b = VAETrainer(FULL, batch_size=batch, lr=1e-3, weight_decay=1e-5, state_dict=init)
+    lr = 1e-3
+    a = VAETrainer(FULL, batch_size=batch, lr=lr, weight_decay=1e-5, state_dict=init)
+    b = VAETrainer(FULL, batch_size=batch, lr=lr, weight_decay=1e-5, state_dict=init)
     try:
         la = a.step(poses, 0.01, eps=eps)
         lb = b.step(poses, 0.01, eps=eps, keep_gradients=False)
@@ -110,7 +112,12 @@ def test_step_modes_share_the_linear_layers_bits_between_65_and_256_windows(batc
         for what in (0, 3, 4):
             ua, ub = unpack_arena(a._down(what), FULL), unpack_arena(b._down(what), FULL)
             for k in LINEAR_WEIGHTS:
-                assert np.array_equal(ua[k], ub[k]), (what, k, float(np.abs(ua[k] - ub[k]).max()))
+                x, y = np.asarray(ua[k], np.float64), np.asarray(ub[k], np.float64)
+                if what == 0:
+                    assert np.abs(x - y).max() <= 1e-3 * lr, (k, float(np.abs(x - y).max()))
+                    assert np.abs(x - np.asarray(init[k], np.float64)).max() > 0.5 * lr          # (the step really moved them)
+                else:
+                    assert np.abs(x - y).max() <= 1e-5 * np.abs(x).max(), (what, k, float(np.abs(x - y).max()), float(np.abs(x).max()))
     finally:
         a.close(); b.close()
 

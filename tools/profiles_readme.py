@@ -11,7 +11,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 
 
 def stats(name, keep, top=7):
@@ -40,7 +40,7 @@ for title, sfile, tfile in (
         ("BASELINE configs[2]: 1536 windows in one call, bf16", "kernel_stats_%s_bf16_1536_windows.csv" % tag, "traffic_%s_bf16_1536_windows.json" % tag),
         ("BASELINE configs[3] per-GPU shard: exactly 8192 windows, bf16, one lane", "kernel_stats_%s_bf16_8192_windows.csv" % tag,
          "traffic_%s_bf16_8192_windows.json" % tag),
-        ("1536 windows, fp32", "kernel_stats_%s_f32_1536_windows.csv" % tag, None),
+        ("1536 windows, fp32", "kernel_stats_%s_f32_1536_windows.csv" % tag, "traffic_%s_f32_1536_windows.json" % tag),
         ("the training step (SURVEY 8 f.4), batch 64", "kernel_stats_%s_train_b64.csv" % tag, "traffic_%s_train_b64.json" % tag),
         ("the training step, batch 1024", "kernel_stats_%s_train_b1024.csv" % tag, None)):
     head, rows = stats(sfile, KEEP, top=9)
@@ -60,6 +60,9 @@ for title, sfile, tfile in (
             e = kk.get(k) or kk.get("void " + k)
             if e and "read_bytes_corrected" in e:
                 extra = "; HBM per launch %s read + %s written" % (mb(e["read_bytes_corrected"]), mb(e["write_bytes"]))
+                if e.get("mfma_busy_cycles"):
+                    extra += "; MFMA pipes busy %.2f of the dispatch's active cycles (%.1f M SIMD-cycles per launch)" % (
+                        e["mfma_busy_frac_of_active"], e["mfma_busy_cycles"] / 1e6)
             elif e and "read_MB" in e:
                 extra = "; HBM per launch %.1f MB read + %.1f MB written" % (e["read_MB"], e["written_MB"])
         per = (" (%s per step)" % r["calls_per_step"]) if "calls_per_step" in r else ""
