@@ -324,6 +324,8 @@ int gem_create(const gem_config* cfg, gem_handle** out) {
     if (dev_alloc(w.allocs, &w.pose_b, rows * h->C)) return 1;
     if (dev_alloc(w.allocs, &w.n_log, (size_t)N_LOG)) return 1;
     if (dev_alloc(w.allocs, &w.perm2, (size_t)B) || dev_alloc(w.allocs, &w.slot_of2, (size_t)B)) return 1;
+    if (dev_alloc(w.allocs, &w.grid_bar, 1)) return 1;
+    GEM_HIP(hipMemset(w.grid_bar, 0, sizeof(unsigned)));
     if (dev_alloc(w.allocs, &w.perm, (size_t)B) || dev_alloc(w.allocs, &w.slot_of, (size_t)B) || dev_alloc(w.allocs, &w.n_active, 2))
         return 1;
     w.perm_home = w.perm; w.slot_of_home = w.slot_of; w.n_active_home = w.n_active;
@@ -639,7 +641,9 @@ static int evaluate(gem_handle* h, int stage, int B, const float* zp, const Ener
         // dE/dz = Wf^T . (gradient w.r.t. the pre-activation of conv 0): replaces the conv adjoint, its reduce pass and the
         // decoder_input backward product; in the rounds lbfgs_advance sums the slabs of this product itself (its bias is zero)
         w.defer_reduce = w.dyn;
+        w.fuse_lbfgs = w.fuse_lbfgs_req;          // (experiment: THIS launch may carry lbfgs_advance behind a device-wide barrier)
         const int rc = launch_gemm(h, net.front_bwd, EPI_BIAS, w.dec_grad[st], net.front_bwd.K, nullptr, w.dz, h->Dp, B, h->T, s, 0);
+        w.fuse_lbfgs = nullptr;
         w.grad_slab = w.defer_reduce ? w.deferred : SlabSrc{};
         w.defer_reduce = false;
         return rc;
@@ -750,7 +754,14 @@ static int stage_round(StageRun& r, int k) {
             rc = launch_compact(h, r.B, 0, r.s);
         }
     }
-    rc = rc || evaluate(h, r.stage, r.B, w.trial, r.ea, r.s) || launch_lbfgs_advance(h, r.B, r.opt, r.s);
+    // (experiment, GEM_DEV=1 GEM_FUSE_BWD_LBFGS=1: the backward front product carries the advance behind a device-wide barrier)
+    const bool fuse_exp = dev_env("GEM_FUSE_BWD_LBFGS") != nullptr;          // (read per round: a test flips it inside one process)
+    w.lbfgs_fused_done = false;
+    w.fuse_lbfgs_req = (fuse_exp && w.dyn && r.fuse && !h->graphs_on && !h->prof.on && h->precision == GEM_PRECISION_F32) ? &r.opt : nullptr;
+    rc = rc || evaluate(h, r.stage, r.B, w.trial, r.ea, r.s);
+    w.fuse_lbfgs_req = nullptr;
+    if (!rc && !w.lbfgs_fused_done) rc = launch_lbfgs_advance(h, r.B, r.opt, r.s);
+    w.lbfgs_fused_done = false;
     if (w.fuse_compact) { set_error("optimize: the fused compaction was not picked up"); rc = 1; w.fuse_compact = false; }
     if (w.mid_event) {          // (no evaluation path picked the half-round marker up: record it now rather than never)
         GEM_HIP(hipEventRecord(w.mid_event, r.s));

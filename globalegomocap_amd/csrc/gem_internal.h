@@ -147,6 +147,15 @@ struct Workspace {
     // `perm`, `slot_of`, `n_active` above always point at the CURRENT round's set; *_home are the allocations they return to.
     int *perm2 = nullptr, *slot_of2 = nullptr, *perm_home = nullptr, *slot_of_home = nullptr, *n_active_home = nullptr;
     int *next_perm = nullptr, *next_slot_of = nullptr, *next_count = nullptr;      // what lbfgs_advance of this round fills (nullptr: off)
+    // EXPERIMENT (GEM_DEV=1 GEM_FUSE_BWD_LBFGS=1, fp32, <= 256 windows, eager launches only): the backward front product and
+    // lbfgs_advance as ONE kernel with a device-wide barrier between them -- what a grid barrier costs against a launch boundary
+    // in this pipeline.  fuse_lbfgs: the round's options while such a launch is wanted; lbfgs_fused_done:
+    // the product's launch carried the advance; grid_bar: monotonic arrival counter, grid_bar_target: its value after this launch.
+    const gem_lbfgs_opts* fuse_lbfgs_req = nullptr;      // set by the round loop, handed to the backward launch only (evaluate)
+    const gem_lbfgs_opts* fuse_lbfgs = nullptr;
+    bool lbfgs_fused_done = false;
+    unsigned* grid_bar = nullptr;
+    unsigned grid_bar_target = 0;
     bool dyn = false;                   // rounds in flight: GEMM / energy launches read their row count from n_active
     int* n_log = nullptr;               // [N_LOG] n_active after every compaction (profiling: true row counts)
     long log_pos = 0, cur_log = -1;
@@ -431,6 +440,9 @@ int launch_lbfgs_init(gem_handle* h, int B, const gem_lbfgs_opts& o, hipStream_t
 int launch_lbfgs_advance(gem_handle* h, int B, const gem_lbfgs_opts& o, hipStream_t s);
 int launch_lbfgs_stats(gem_handle* h, int B, gem_window_stats* out, hipStream_t s);
 int launch_compact(gem_handle* h, int B, int force_all, hipStream_t s, int zero_after = 0);
+namespace rows { struct Args; }
+// lbfgs.hip (experiment): gemm_rows_body<4, 5> + device-wide barrier + lbfgs_advance in one launch; -1: shape not covered
+int launch_rows_bwd_lbfgs(gem_handle* h, const rows::Args& ra, int rows_grid, size_t rows_smem, const SlabSrc& gslab, hipStream_t s);
 
 
 }  // namespace gem

@@ -401,6 +401,10 @@ static int launch_rows_as(gem_handle* h, const Layer& L, const float* A, int lda
         a.perm_out = w.perm; a.slot_of_out = w.slot_of; a.n_active_out = w.n_active; a.log_slot = w.fuse_log;
     }
     const int grid = p.n_rb * (L.N / rows::BN) * p.n_split;
+    if (!FUSE && S == 4 && RT == 5 && !direct && w.fuse_lbfgs && w.dyn) {          // experiment: this launch carries lbfgs_advance too
+        const int rc = launch_rows_bwd_lbfgs(h, a, grid, (size_t)S * rows::Geometry<RT>::STAGE_BYTES, w.deferred, s);
+        if (rc >= 0) return rc;
+    }
     note_kernel(h, reinterpret_cast<const void*>(k));
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), (size_t)S * rows::Geometry<RT>::STAGE_BYTES, s, a);
     GEM_HIP(hipGetLastError());

@@ -87,8 +87,10 @@ __device__ long long g_rows_clock[6];
 
 constexpr int FUSE_MAX_WINDOWS = 512;
 
+// The kernel's body as a device function (the early returns leave the body, not the kernel): gemm_rows_kernel below is this and
+// nothing else; lbfgs.hip's experimental rows_bwd_lbfgs_kernel runs it in front of a device-wide barrier.
 template <int S, int RT, bool FUSE = false>
-__global__ __launch_bounds__(256) void gemm_rows_kernel(const Args a) {
+__device__ __forceinline__ void gemm_rows_body(const Args& a) {
     typedef Geometry<RT> G;
     static_assert(S >= 3 && S * G::STAGE_BYTES <= 160 * 1024, "ring must fit the LDS");
     static_assert(4 * RT * 4096 <= S * G::STAGE_BYTES, "the four partial tiles are reduced through the ring's LDS");
@@ -357,6 +359,9 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const Args a) {
         default: body(std::integral_constant<int, RT>{}); break;
     }
 }
+
+template <int S, int RT, bool FUSE = false>
+__global__ __launch_bounds__(256) void gemm_rows_kernel(const Args a) { gemm_rows_body<S, RT, FUSE>(a); }
 
 // How a launch is cut: row blocks (fixed for the launch) and K slices.  Cost in units of one K-step of one row tile;
 // a slab costs its write plus the consumer's read.

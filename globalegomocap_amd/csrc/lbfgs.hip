@@ -18,6 +18,7 @@
 // One 256-thread workgroup per window; the D latent values are strided over the threads (coalesced),
 // dot products / max-norms are wavefront butterflies + a 4-entry LDS combine.
 #include "gem_internal.h"
+#include "gemm_rows.h"
 
 namespace gem {
 
@@ -679,6 +680,50 @@ static AdvArgs make_args(gem_handle* h, const gem_lbfgs_opts& o) {
     a.clk = w.lbfgs_clk;
     a.Dp = h->Dp; a.hist_cap = w.hist_cap; a.o = o;        // hist_cap: power of two (gem_create)
     return a;
+}
+
+// ---- EXPERIMENT: one launch for the backward front product and the L-BFGS advance, a device-wide barrier in between -----------------
+// Every workgroup runs its tile of dE/dz = dpre0 . Wf (split-K slabs, gemm_rows.h), publishes them (agent-scope release), arrives at
+// the barrier (one atomic add on a monotonic counter), waits until all workgroups of the launch have arrived (bounded spin: a grid
+// that is not co-resident must not hang the device), acquires, and advances window blockIdx.x.  The grid is one workgroup per CU
+// (the product's LDS ring allows no second one), so co-residency holds on an otherwise idle chip.
+template <int S, int RT>
+__global__ __launch_bounds__(256) void rows_bwd_lbfgs_kernel(const rows::Args ra, AdvArgs la, int B, unsigned* bar, unsigned target) {
+    rows::gemm_rows_body<S, RT, false>(ra);
+    // (MI355X_MICROARCH.md "Correctness boundaries": every storing wave drains its stores, the workgroup meets, ONE lane releases at
+    // agent scope -- the per-XCD L2s are not coherent with each other: that is an L2 write-back --, arrives, polls, acquires -- an
+    // invalidate of this CU's L1 and its XCD's L2 --, the workgroup meets again, plain loads follow)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while ((int)(__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0 && ++spins < (1u << 22))
+            __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if ((int)blockIdx.x < B) lbfgs_advance_body<8, 256, true, false>(la);
+}
+
+int launch_rows_bwd_lbfgs(gem_handle* h, const rows::Args& ra, int rows_grid, size_t rows_smem, const SlabSrc& gslab, hipStream_t s) {
+    Workspace& w = h->ws;
+    if (!w.fuse_lbfgs || !w.grid_bar || h->Dp != 2048 || h->precision != GEM_PRECISION_F32 || ra.M > h->n_cu || rows_grid > h->n_cu) return -1;
+    const int B = ra.M;
+    w.grad_slab = gslab;
+    AdvArgs la = make_args(h, *w.fuse_lbfgs);
+    auto k = rows_bwd_lbfgs_kernel<4, 5>;
+    static PerDeviceOnce once;
+    if (once.need(h->cfg.device))
+        GEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rows_smem));
+    const int grid = rows_grid > B ? rows_grid : B;
+    w.grid_bar_target += (unsigned)grid;
+    note_kernel(h, reinterpret_cast<const void*>(k));
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), rows_smem, s, ra, la, B, w.grid_bar, w.grid_bar_target);
+    GEM_HIP(hipGetLastError());
+    w.lbfgs_fused_done = true;
+    return 0;
 }
 
 int launch_lbfgs_init(gem_handle* h, int B, const gem_lbfgs_opts& o, hipStream_t s) {

@@ -654,6 +654,31 @@ def test_two_lanes_are_bitwise_one_lane(torch_cuda, friendly_vaes, B):
     two.close()
 
 
+def test_device_wide_barrier_experiment_is_bitwise_the_product(torch_cuda, full_vaes, monkeypatch):
+    """The experiment behind DESIGN.md section 4's "a device-wide barrier against a launch boundary" (GEM_DEV=1
+    GEM_FUSE_BWD_LBFGS=1: the backward front product and lbfgs_advance of every fp32 round as ONE launch with a grid barrier in
+    between, csrc/lbfgs.hip rows_bwd_lbfgs_kernel): it is only a timing argument if it computes the same thing -- 240 windows, both
+    stages, bitwise the product path's poses and statistics."""
+    torch = torch_cuda
+    data, sd_l, sd_g, w_l, w_g = full_vaes
+    n_chunks = 20
+    starts = np.concatenate([c * 100 + window_starts(100) for c in range(n_chunks)])
+    eng = _engine(len(starts), sd_l, sd_g, "f32")
+    p = _device_problem(eng, n_chunks * 100, starts, seed=707, n_dup=0)
+    ref = [t.clone() for t in _run(eng, p)]
+    monkeypatch.setenv("GEM_DEV", "1")
+    monkeypatch.setenv("GEM_FUSE_BWD_LBFGS", "1")
+    eng.profile_enable(True)                      # (names the kernels that ran; the experiment is off while events are recorded ...)
+    eng.profile_enable(False)                     # (... so: off again)
+    out = [t.clone() for t in _run(eng, p)]
+    torch.cuda.synchronize()
+    monkeypatch.delenv("GEM_FUSE_BWD_LBFGS")
+    assert all(torch.equal(a, b) for a, b in zip(ref, out))
+    from globalegomocap_amd.engine import stats_to_numpy
+    assert stats_to_numpy(out[2])["finished"].all()
+    eng.close()
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # hipGraph replay (BASELINE configs[4])
 # ------------------------------------------------------------------------------------------------------------------
