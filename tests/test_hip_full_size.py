@@ -668,8 +668,6 @@ def test_device_wide_barrier_experiment_is_bitwise_the_product(torch_cuda, full_
     ref = [t.clone() for t in _run(eng, p)]
     monkeypatch.setenv("GEM_DEV", "1")
     monkeypatch.setenv("GEM_FUSE_BWD_LBFGS", "1")
-    eng.profile_enable(True)                      # (names the kernels that ran; the experiment is off while events are recorded ...)
-    eng.profile_enable(False)                     # (... so: off again)
     out = [t.clone() for t in _run(eng, p)]
     torch.cuda.synchronize()
     monkeypatch.delenv("GEM_FUSE_BWD_LBFGS")
