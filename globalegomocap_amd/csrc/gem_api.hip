@@ -1136,6 +1136,16 @@ int gem_graph_enable(gem_handle* h, int on) {
     return 0;
 }
 
+#ifdef GEM_DEBUG_EXPORTS          // developer builds only (tools/r05_nrt_dump.py): internal buffers by number, no copy
+int gem_debug_buffer(gem_handle* h, int which, void** d_ptr) {
+    if (!h || !d_ptr) return 1;
+    Workspace& w = h->ws;
+    const int st = h->net[0].tail_start;
+    *d_ptr = which == 0 ? (void*)w.dec_grad_b[st] : which == 1 ? (void*)w.dec_act_b[st - 1] : which == 2 ? (void*)w.dz : nullptr;
+    return *d_ptr ? 0 : 1;
+}
+#endif
+
 int gem_graph_stats(gem_handle* h, int64_t* n_captures, int64_t* n_replays) {
     if (!h) { set_error("gem_graph_stats: null handle"); return 1; }
     if (n_captures) *n_captures = h->graph_captures;

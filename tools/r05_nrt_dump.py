@@ -1,4 +1,5 @@
-"""Developer check (library built with -DGEM_TB_DEBUG_DUMP): the bf16 pose-gradient rows the energy terms leave, per row-tile variant."""
+"""Developer check (library with gem_api.hip built -DGEM_DEBUG_EXPORTS; the tail's object file is the product's): the bf16 gradient rows
+the tail hands to the backward front product, per row-tile variant."""
 import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -21,23 +22,28 @@ pose = np.stack([est[s:s + 10] for s in starts])
 mb = O.mean_bone_length(est)
 z = rng.normal(size=(B, FULL.latent_dim)).astype(np.float32) * 0.3
 os.environ["GEM_DEV"] = "1"; os.environ["GEM_TAIL16"] = "1"
-lib = _capi.load_library()
-dump = torch.zeros(B * 10 * 64, dtype=torch.int16, device="cuda")
 raw = C.CDLL(_capi.LIB_PATH)
-assert raw.gem_debug_set_tb_dump(C.c_void_p(dump.data_ptr())) == 0
 res = {}
 for nrt in (2, 3):
     os.environ["GEM_TAIL16_NRT"] = str(nrt)
     eng = WindowEngine(FULL, FisheyeCamera.from_json(DEFAULT_CALIBRATION), max_windows=B)
     eng.load_vae(0, sd); eng.set_precision("bf16")
-    dump.zero_()
     E, parts, dz, X = eng.energy_grad(0, z, pose, mb, energy_weights(1e-2, 1e-2, 1e-1, 1e-3, 1e-2), heat, starts)
     torch.cuda.synchronize()
-    res[nrt] = (dump.cpu().numpy().reshape(B, 10, 64).copy(), dz.cpu().numpy())
+    bufs = []
+    for which, cols in ((0, 256), (1, 256)):
+        p = C.c_void_p()
+        assert raw.gem_debug_buffer(eng._h, which, C.byref(p)) == 0
+        t = torch.empty(B * 10 * cols, dtype=torch.int16, device="cuda")
+        hip = C.CDLL("libamdhip64.so")
+        assert hip.hipMemcpy(C.c_void_p(t.data_ptr()), p, C.c_size_t(t.numel() * 2), C.c_int(3)) == 0
+        bufs.append(t.cpu().numpy().reshape(B, 10, cols).copy())
+    res[nrt] = (bufs[0], bufs[1], dz.cpu().numpy())
     eng.close()
-g2, g3 = res[2][0], res[3][0]
-bad = np.argwhere(g2 != g3)
-print("pose-gradient rows (bf16) differing entries:", len(bad), bad[:10].tolist())
-for w, t, c in bad[:5]:
-    print("  window %d t %d col %d (joint %d comp %d): %04x vs %04x" % (w, t, c, c // 3, c % 3, g2[w, t, c] & 0xFFFF, g3[w, t, c] & 0xFFFF))
-print("dz differing windows:", np.unique(np.nonzero(res[2][1] != res[3][1])[0]))
+for name, i in (("g_out (gradient w.r.t. conv 0's pre-activation)", 0), ("a_in (conv 0's activation)", 1)):
+    a, b = res[2][i], res[3][i]
+    bad = np.argwhere(a != b)
+    print(name, "differing entries:", len(bad), bad[:12].tolist())
+    for w, t, c in bad[:6]:
+        print("   window %d t %d col %d: %04x vs %04x" % (w, t, c, a[w, t, c] & 0xFFFF, b[w, t, c] & 0xFFFF))
+print("dz differing windows:", np.unique(np.nonzero(res[2][2] != res[3][2])[0]))

@@ -199,6 +199,22 @@ int main(int argc, char** argv) {
             }
         }
         printf("determinism B=%d: %d of 11 launches differ from the first\n", B, bad_launches);
+        if (getenv("TAIL_NRT_B")) {          // the same batch through ANOTHER row-tile instantiation: every window's rows must come out the same
+            const int nrt_b = atoi(getenv("TAIL_NRT_B"));
+            const size_t lds_b = plan_tail_bf16(net.dec, 1, T, J, &a, nrt_b);
+            hipMemsetAsync(a.g_out_b, 0xFF, rows * 256 * 2, s);
+            launch_tail_bf16(&h, a, lds_b, s);
+            hipStreamSynchronize(s);
+            hipMemcpy(cur.data(), a.g_out_b, rows * 256 * 2, hipMemcpyDeviceToHost);
+            size_t nbad = 0, nwin = 0; long lastw = -1;
+            for (size_t i = 0; i < cur.size(); ++i)
+                if (cur[i] != ref[i]) {
+                    ++nbad;
+                    const long w = (long)(i / 256 / T);
+                    if (w != lastw) { ++nwin; lastw = w; if (nwin <= 6) printf("   window %ld row %zu col %zu: %04x vs %04x\n", w, (i / 256) % T, i % 256, ref[i], cur[i]); }
+                }
+            printf("row tiles %d vs %d: %zu differing values in %zu of %d windows\n", nrt, nrt_b, nbad, nwin, B);
+        }
         return 0;
     }
     for (int fo = 1; fo >= 0; --fo) {
