@@ -127,6 +127,40 @@ static int launch_big(gem_handle* h, const Layer& L, int epi, const uint16_t* A,
     return 0;
 }
 
+// Mid-size batches in the evaluation rounds (round 5): the same 256 x 256 tile with the K range CUT so that the launch is one round of
+// ~one workgroup per CU -- 1536 rows: 6 x 10 tiles x 4 slices (forward), 6 x 8 x 5 (backward) = 240 workgroups of eight 64-deep K-steps
+// -- writing raw fp32 slabs that the consumer sums anyway (the tail while staging, lbfgs_advance while reading its gradient).  128
+// FLOP per byte moved L2 -> LDS instead of the 128 x 128 tile's 64: the fill rate (~30 B/clk/CU) that bounds the small kernel at these
+// sizes allows twice the rate.  Only with a device row count and a consumer that takes slabs; the two-lane mode (whose bitwise test
+// needs a batch and its halves to be cut alike) keeps the old kernels.
+constexpr int BIG_SPLIT_MIN_ROWS = 1024;
+static bool launch_big_split(gem_handle* h, const Layer& L, const uint16_t* A, int lda, int ldc, int M, hipStream_t s, const int* row_map,
+                             int m_max, int* n_split_out) {
+    Workspace& w = h->ws;
+    const int tiles = ((M + 255) / 256) * (L.N / 256), k_tiles = L.K / 64;
+    int sk = h->n_cu / tiles;
+    if (const char* fs = dev_env("GEM_BIG_SPLIT_SK")) sk = atoi(fs);          // developer override (A/B runs)
+    if (sk > k_tiles / 4) sk = k_tiles / 4;
+    if (sk > 8) sk = 8;
+    while (sk > 1 && (size_t)sk * M * ldc > w.splitk_elems) --sk;
+    if (sk < 2) return false;
+    big::Args a{};
+    a.A = A; a.W = L.wb_hi; a.bias = nullptr; a.C = w.splitk; a.zero16 = w.zero16;
+    a.m_dev = w.n_active; a.row_map = row_map;
+    a.lda = lda; a.ldc = ldc; a.M = M; a.N = L.N; a.K = L.K; a.m_min = 1; a.m_max = m_max;
+    a.tiles_per_split = (k_tiles + sk - 1) / sk;
+    a.n_split = (k_tiles + a.tiles_per_split - 1) / a.tiles_per_split;
+    a.slab_stride = (size_t)M * ldc;
+    static PerDeviceOnce once;
+    if (once.need(h->cfg.device))
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(big::gemm_big_kernel<4, 4, 4, 4, big::EPI_NONE, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    note_kernel(h, reinterpret_cast<const void*>(big::gemm_big_kernel<4, 4, 4, 4, big::EPI_NONE, false>));
+    hipLaunchKernelGGL((big::gemm_big_kernel<4, 4, 4, 4, big::EPI_NONE, false>), dim3(tiles * a.n_split), dim3(1024), 2 * (256 + 256) * 128, s, a);
+    if (hipGetLastError() != hipSuccess) return false;
+    *n_split_out = a.n_split;
+    return true;
+}
+
 // C = epi(conv/linear(A)) with bf16 operands.  `out_bf16`: activation / gradient for the next bf16 layer; otherwise fp32.
 // allow_split: small row counts cut K over several workgroups (fp32 slabs in ws.splitk); with `defer` the slabs are left to
 // the consumer (described in ws.deferred), otherwise a reduce pass applies the epilogue.
@@ -151,6 +185,31 @@ static int gemm_bf16a(gem_handle* h, const Layer& L, int epi, const uint16_t* A,
     static const int big_min = dev_env("GEM_BIG_MIN") ? atoi(dev_env("GEM_BIG_MIN")) : BIG_MIN_ROWS;          // developer override (A/B runs)
     const bool use_big = family == 0 && !no_big && M >= big_min && big_fits(L, epi, out_bf16);
     if (use_big) a.m_max = big_min;
+    // mid-size rounds: the K-cut one-round kernel (see launch_big_split); the consumer takes the slabs
+    // MEASURED AND NOT ADOPTED (round 5, tools/r05_exp5.sh, windows/s with the 128 x 128 kernel | with this): 1536 windows 182.7 | 175.6 k,
+    // 2052: 180.4 | 186.4 k, 3072: 229.5 | 227.4 k, 4092: 235.1 | 232.0 k, 768: 123.6 | 114.4 k -- the four-pass fp32 epilogue of a 256 x 256
+    // tile and twice the slab traffic eat what the better FLOP-per-byte ratio gives.  Off unless GEM_DEV=1 GEM_BIG_SPLIT=1.
+    static const bool no_big_split = dev_env("GEM_BIG_SPLIT") == nullptr;
+    static const int big_split_min = dev_env("GEM_BIG_SPLIT_MIN") ? atoi(dev_env("GEM_BIG_SPLIT_MIN")) : BIG_SPLIT_MIN_ROWS;
+    if (family == 0 && !no_big && !no_big_split && !use_big && h->lanes_min == 0 && w.dyn && defer && allow_split && L.taps == 1 && M >= big_split_min &&
+        L.N % 256 == 0 && L.K % 64 == 0 && (epi == EPI_NONE || epi == EPI_BIAS_LRELU)) {
+        Profile::Rec rec2;
+        const bool prof2 = h->prof.on;
+        if (prof2) {
+            GEM_HIP(hipEventCreate(&rec2.a)); GEM_HIP(hipEventCreate(&rec2.b));
+            rec2.family = family; rec2.flops = 2.0 * M * (double)L.N * L.K;
+            rec2.log_idx = w.cur_log; rec2.flops_per_window = 2.0 * (double)L.N * L.K;
+            GEM_HIP(hipEventRecord(rec2.a, s));
+        }
+        int ns = 0;
+        if (launch_big_split(h, L, A, lda, ldc, M, s, row_map, 0, &ns)) {
+            SlabSrc& d = w.deferred;
+            d.base = w.splitk; d.nslab = ns; d.stride = (size_t)M * ldc; d.dyn_W = 0; d.m_dev = w.n_active;
+            if (prof2) { GEM_HIP(hipEventRecord(rec2.b, s)); h->prof.recs.push_back(rec2); }
+            commit_kernel_names(h, prof2 ? family : -1);
+            return 0;
+        }
+    }
     if (allow_split && epi != EPI_MASK) {
         // fill the chip: about two workgroups per CU (the number co-resident with this kernel's 64 KB of LDS; measured at 768 ..
         // 3072 rows, tools/gemm_glds_bench split: the best cut of every shape) while every slice keeps >= 4 k-tiles and the slabs fit

@@ -47,6 +47,11 @@ struct Args {
     const int* row_map;       // gathered A rows or nullptr
     int lda, ldc, M, N, K;
     int m_min;                // run only when the row count is >= m_min (the small-tile kernel takes the launches below)
+    // K cut (round 5; fp32 output only): slice ks = K-tiles [ks * tiles_per_split, ...) goes to the raw fp32 slab C + ks * slab_stride;
+    // the consumer sums the slabs (the tail while staging its input, lbfgs_advance while reading its gradient).  n_split <= 1: none.
+    int n_split, tiles_per_split;
+    size_t slab_stride;       // elements between slabs
+    int m_max;                // > 0: run only when the row count is < m_max
 };
 
 // Tile shape = a grid of WM x WN waves, each owning MB x NB blocks of 16 x 16: BM = 16 MB WM = 256 rows, BN = 16 NB WN = 256
@@ -70,9 +75,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_big_kernel(const Args a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int M = a.m_dev ? *a.m_dev : a.M;
-    if (M < a.m_min || M <= 0) return;
+    if (M < a.m_min || M <= 0 || (a.m_max > 0 && M >= a.m_max)) return;
     const int n_mt = (M + BM - 1) / BM, n_nt = a.N / BN;
-    const int total = n_mt * n_nt;
+    const int n_split = (!OUT_BF16 && EPI == EPI_NONE && a.n_split > 1) ? a.n_split : 1;
+    const int total = n_mt * n_nt * n_split;
     if ((int)blockIdx.x >= total) return;
     // XCD-aware tile order: the dispatcher deals consecutive workgroup ids round-robin over the 8 XCDs (ids congruent mod 8 share
     // one), so id -> (id % 8) * ceil(total / 8) + id / 8 gives every XCD a contiguous range of logical tiles, row panel major:
@@ -80,9 +86,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_big_kernel(const Args a) {
     // row panels an XCD holds walk the weight panels together.  Speed only: any placement computes the same tiles.
     const int q8 = total >> 3, r8 = total & 7, x8 = blockIdx.x & 7, k8 = blockIdx.x >> 3;
     const int pid = (x8 < r8 ? x8 * (q8 + 1) : r8 * (q8 + 1) + (x8 - r8) * q8) + k8;
-    const int mt = pid / n_nt, nt = pid - mt * n_nt;
+    // (the K slices of a tile are neighbours: they share the tile's operand panels in one XCD's L2)
+    const int ks = pid % n_split, tile = pid / n_split;
+    const int mt = tile / n_nt, nt = tile - mt * n_nt;
     const int m0 = mt * BM, n0 = nt * BN;
-    const int kTiles = a.K / 64;
+    const int kAll = a.K / 64;
+    const int kt0 = n_split > 1 ? ks * a.tiles_per_split : 0;
+    const int kTiles = n_split > 1 ? min(kAll, kt0 + a.tiles_per_split) : kAll;          // end of this slice
+    if (kt0 >= kTiles) return;
 
     // ---- DMA source addressing.  Piece p covers tile rows 8p .. 8p + 7; lane l brings the 16-byte chunk (l & 7) ^ swz(row) of
     // row l >> 3.  Wave w brings pieces w, w + NW, ... of either operand.
@@ -163,10 +174,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_big_kernel(const Args a) {
 
     // two buffers: the DMA of K-step t + 1 is issued inside step t; the barrier that ends a step (with the vmcnt(0) the compiler
     // puts in front of it) completes step t + 1 for everybody.  The waves of a SIMD hide each other's waits.
-    stage(0, 0);
+    stage(0, kt0);
     __syncthreads();
     int cur = 0;
-    for (int kt = 0; kt < kTiles; ++kt) {
+    for (int kt = kt0; kt < kTiles; ++kt) {
         kstep(cur, kt + 1, kt + 1 < kTiles);
         __syncthreads();
         cur ^= 1;
@@ -179,7 +190,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_big_kernel(const Args a) {
     constexpr int CW = OUT_BF16 ? 8 : 4;                          // columns per store chunk (16 bytes out either way)
     constexpr int CHUNKS = 64 * (BN / CW);                        // per pass
     static_assert(64 * ROWB <= 2 * BUF, "a pass fits the operand buffers");
-    unsigned char* Cb = reinterpret_cast<unsigned char*>(a.C);
+    unsigned char* Cb = reinterpret_cast<unsigned char*>(a.C) + (n_split > 1 ? (size_t)ks * a.slab_stride * 4 : 0);
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
         if (pass) __syncthreads();                                // the previous pass has been read out
