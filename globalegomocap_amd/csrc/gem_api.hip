@@ -908,8 +908,14 @@ static int windows_dual(WindowsRun& a, WindowsRun& b, gem_handle* h, hipStream_t
     int rc = windows_begin_local(a) || windows_begin_local(b);
     size_t ev = 0;
     hipEvent_t last_b = nullptr;
+    // (GEM_DEV=1 GEM_LANES_FREE=1, A/B runs: the two lanes run free on their streams, no half-round lock)
+    const bool free_run = dev_env("GEM_LANES_FREE") != nullptr;
     auto rounds = [&]() {
         for (int k = 0; k < a.st.rounds && !rc; ++k) {
+            if (free_run) {
+                rc = rc || stage_round(a.st, k) || stage_round(b.st, k);
+                continue;
+            }
             hipEvent_t ea = lane_event(h, ev++), eb = lane_event(h, ev++);
             if (!ea || !eb) { set_error("optimize: hipEventCreate failed"); rc = 1; break; }
             if (last_b) rc = rc || !hip_ok(hipStreamWaitEvent(sa, last_b, 0), "hipStreamWaitEvent");
