@@ -580,15 +580,14 @@ static EnergyArgs energy_args(gem_handle* h, const float* X0, const float* heat,
 static int evaluate(gem_handle* h, int stage, int B, const float* zp, const EnergyArgs& ea, hipStream_t s, bool forward_only = false) {
     StageNet& net = h->net[stage];
     Workspace& w = h->ws;
-    // The fused tail trades throughput for latency (~45 us per workgroup whatever the batch, one workgroup per CU at a
-    // time): measured against the batched GEMMs for the narrow layers it wins up to about five waves of workgroups
-    // (fp32, windows/s: 480 windows 19.6 k vs 16.7 k, 960 windows 21.7 k vs 20.6 k, 1500 windows 23.4 k vs 23.7 k).
-    // GEM_FORCE_TAIL=1 keeps it on for any batch.
+    // The fused tail trades throughput for latency (~45 us per workgroup whatever the batch, one or two workgroups per CU at a
+    // time): measured against the batched GEMMs for the narrow layers it wins up to ten workgroups per CU in its two-per-CU
+    // shape, five otherwise (tail_cap_workgroups, tail.hip, has the table).  GEM_FORCE_TAIL=1 keeps it on for any batch.
     if (h->precision == GEM_PRECISION_BF16) return evaluate_bf16(h, stage, B, ea, s, forward_only);      // zp == ws.trial, mirrored in ws.trial_b
     static const bool force_tail = dev_env("GEM_FORCE_TAIL") != nullptr;
     const int tail_g = h->T <= 16 ? 16 / h->T : 1;
     const int tail_wgs = (B + tail_g - 1) / tail_g;
-    const int tail_cap = 5 * h->n_cu;
+    const int tail_cap = net.tail_start >= 0 ? tail_cap_workgroups(h, net.dec, net.tail_start, net.tail_lds) : 0;
     if (net.tail_start < 0 || (tail_wgs > tail_cap && !force_tail)) {
         if (decoder_forward(h, stage, B, zp, s)) return 1;
         if (forward_only) return 0;

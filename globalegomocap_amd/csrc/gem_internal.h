@@ -420,6 +420,7 @@ int tail_bf16_row_tiles(const gem_handle* h, int B, int T);
 int build_tail_bf16_stream(gem_handle* h, StageNet& net);
 int launch_tail_bf16(gem_handle* h, const TailB16Args& a, size_t lds_bytes, hipStream_t s);
 int launch_tail(gem_handle* h, const TailArgs& a, size_t lds_bytes, hipStream_t s);
+int tail_cap_workgroups(const gem_handle* h, const std::vector<Layer>& dec, int start, size_t lds_bytes);   // fused tail up to this many workgroups
 int launch_mean_bone(gem_handle* h, const float* pose, int n_frames, float* out, hipStream_t s);
 int launch_gather_windows(const float* frames, const int32_t* frame0, float* out, int B, int T, int JC, hipStream_t s);
 int launch_relative_global(const float* local, const double* cams, const int32_t* frame0, float* rel, int B, int T, int J,

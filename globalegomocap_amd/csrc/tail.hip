@@ -38,9 +38,17 @@ __device__ __forceinline__ float bf16_round(float x) {
 }
 
 // 8 waves per workgroup = 2 per SIMD: the per-block latency chain (L2 weight fragment -> LDS fragment -> 16 MFMAs)
-// of one wave overlaps the other's, and K is cut twice as fine (each wave walks half as many blocks).
+// of one wave overlaps the other's, and K is cut twice as fine (each wave walks half as many blocks).  That is the shape for
+// batches of at most one workgroup per CU (the 240-window workload): the window's chain is as short as it gets.
+// With MORE workgroups than CUs the 8-wave kernel (243 VGPRs, 2 waves per SIMD) runs them one after the other on a CU, each
+// paying its staging / barrier / energy latencies with the MFMA pipes idle.  The 4-wave shape (W = 4: one wave per SIMD, each
+// wave owns twice the columns, so one LDS A fragment feeds twice the MFMAs) lets TWO workgroups share a CU (2 x 70 KB LDS,
+// 2 waves per SIMD in total, the same register budget): one window's latencies hide behind the other's matrix work.  Same K walk
+// per output element, so the layers' results are bitwise those of the 8-wave shape; the energies' fp64 partial sums are
+// combined over 4 instead of 8 wavefronts (last-bit differences in f only).
 constexpr int TAIL_WAVES = 8;
 constexpr int TAIL_THREADS = TAIL_WAVES * 64;
+constexpr int TAIL_WAVES_SHARED = 4;       // the two-workgroups-per-CU shape
 
 // Tiling: 16x16 output tiles (v_mfma_f32_16x16x4_f32), tile i of wave w = columns 16w + 128i, FULL K walk per
 // tile, so no partial sums have to be combined through LDS.  K blocks of 64: lane (r = lane&15, q = lane>>4) holds, for each of the
@@ -51,6 +59,7 @@ constexpr int TAIL_ROWS = 16;          // rows of (window, frame) per workgroup 
 
 // B fragments of the first block of the first tile a wave owns in layer L: issued before the barrier that ends
 // the previous layer, so that their L2 latency overlaps the epilogue / barrier / energy phase.
+template <int W>
 __device__ __forceinline__ void tail_prefetch_first(const TailLayerDev L, f32x4 (&dst)[4]) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 15, q = lane >> 4;
@@ -65,16 +74,17 @@ __device__ __forceinline__ void tail_prefetch_first(const TailLayerDev L, f32x4 
 // epi(acc, tile_row0, col, bias_value) receives the 4 rows tile_row0 + 4*(lane>>4) + {0..3} of column `col`.
 // NT = tiles per wave (N / 128, at least 1): the NT tiles of a wave share the 16 rows, so they walk K together:
 // one A fragment feeds NT independent accumulators.
-template <int NT, typename Epi>
+template <int W, int NT, typename Epi>
 __device__ __forceinline__ void tail_gemm_nt(const float* in, int ld_in, const float* zero_line, const TailLayerDev L,
                                              const TailLayerDev next, bool has_next, int T, int R, f32x4 (&bpre)[4], Epi epi) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
     const int kb = L.K / 64, nblk = 3 * kb;                   // (tap, 64-wide k block) pairs
     const f32x4* W4 = reinterpret_cast<const f32x4*>(L.w4);
-    const int n0 = wave * 16;                                 // tile i of this wave: columns n0 + 128*i
-    if (n0 >= L.N) {                                          // 64-wide layer: waves 4-7 only fetch ahead
-        if (has_next) tail_prefetch_first(next, bpre);
+    constexpr int TS = 16 * W;                                // column stride between the tiles of a wave
+    const int n0 = wave * 16;                                 // tile i of this wave: columns n0 + TS*i
+    if (n0 >= L.N) {                                          // 64-wide layer, 8 waves: waves 4-7 only fetch ahead
+        if (has_next) tail_prefetch_first<W>(next, bpre);
         return;
     }
     const int row = fr;
@@ -84,7 +94,7 @@ __device__ __forceinline__ void tail_gemm_nt(const float* in, int ld_in, const f
     f32x4 acc[NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-        bv[i] = L.bias ? L.bias[n0 + 128 * i + fr] : 0.f;      // issued now, consumed in the epilogue
+        bv[i] = L.bias ? L.bias[n0 + TS * i + fr] : 0.f;      // issued now, consumed in the epilogue
         acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     // B: with the [tap][K/4][N][4] layout the (tap, k-block) pairs are consecutive: block blk starts 16*N float4 after
@@ -100,7 +110,7 @@ __device__ __forceinline__ void tail_gemm_nt(const float* in, int ld_in, const f
     {                                                                                                  \
         const f32x4* p_ = pB + (size_t)(blk_) * strideB;                                               \
         _Pragma("unroll") for (int i = 0; i < NT; ++i)                                                 \
-            _Pragma("unroll") for (int g = 0; g < 4; ++g) dst_[i][g] = p_[(size_t)(4 * g) * L.N + 128 * i]; \
+            _Pragma("unroll") for (int g = 0; g < 4; ++g) dst_[i][g] = p_[(size_t)(4 * g) * L.N + TS * i]; \
     }
 #define TAIL_LOAD_A(blk_, dst_)                                                                        \
     {                                                                                                  \
@@ -142,27 +152,31 @@ __device__ __forceinline__ void tail_gemm_nt(const float* in, int ld_in, const f
         __builtin_amdgcn_sched_barrier(0);
     }
     if (nblk & 1) TAIL_COMPUTE(a0, b0);
-    if (has_next) tail_prefetch_first(next, bpre);
+    if (has_next) tail_prefetch_first<W>(next, bpre);
 #undef TAIL_LOAD_A
 #undef TAIL_LOAD_B
 #undef TAIL_COMPUTE
 #pragma unroll
-    for (int i = 0; i < NT; ++i) epi(acc[i], 4 * fq, n0 + 128 * i + fr, bv[i]);
+    for (int i = 0; i < NT; ++i) epi(acc[i], 4 * fq, n0 + TS * i + fr, bv[i]);
 }
 
-template <typename Epi>
+template <int W, typename Epi>
 __device__ __forceinline__ void tail_gemm(const float* in, int ld_in, const float* zero_line, const TailLayerDev L,
                                           const TailLayerDev next, bool has_next, int T, int R, f32x4 (&bpre)[4], Epi epi) {
-    // N is 64, 128, 256 or 512 (plan_tail): N/128 tiles per wave, at least one
-    if (L.N > 256) tail_gemm_nt<4>(in, ld_in, zero_line, L, next, has_next, T, R, bpre, epi);
-    else if (L.N > 128) tail_gemm_nt<2>(in, ld_in, zero_line, L, next, has_next, T, R, bpre, epi);
-    else tail_gemm_nt<1>(in, ld_in, zero_line, L, next, has_next, T, R, bpre, epi);
+    // N is 64, 128, 256 or 512 (plan_tail): N / (16 W) tiles per wave, at least one (W = 4: N <= 256, launch_tail checks)
+    if (L.N > 32 * W) tail_gemm_nt<W, 4>(in, ld_in, zero_line, L, next, has_next, T, R, bpre, epi);
+    else if (L.N > 16 * W) tail_gemm_nt<W, 2>(in, ld_in, zero_line, L, next, has_next, T, R, bpre, epi);
+    else tail_gemm_nt<W, 1>(in, ld_in, zero_line, L, next, has_next, T, R, bpre, epi);
 }
 
 // NL = number of fused layers (compile time: the two layer loops unroll, so every layer's descriptor sits at a fixed
 // kernel-argument offset instead of being fetched by index behind each barrier)
-template <int NL>
-__global__ __launch_bounds__(TAIL_THREADS, 2) void decoder_tail_kernel(TailArgs a) {
+// W = wavefronts per workgroup: 8 (one workgroup per CU) or 4 (two per CU, G == 1 and N <= 256 only); launch_tail chooses
+template <int NL, int W>
+__global__ __launch_bounds__(64 * W, 2) void decoder_tail_kernel(TailArgs a) {
+    constexpr int THREADS = 64 * W;
+    constexpr int STAGE_U = 2048 / THREADS;                  // float4 per thread that cover 16 rows of K0 <= 512
+    constexpr int PRE_E = TAIL_THREADS / THREADS;            // parked energy inputs per thread (up to 512 values per window)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int T = a.e.T;
@@ -190,8 +204,8 @@ __global__ __launch_bounds__(TAIL_THREADS, 2) void decoder_tail_kernel(TailArgs 
             int nslab;
             size_t stride;
             slab_layout(a.in_slab, nslab, stride);
-            for (int u = 0; u < 4; ++u) {
-                const int i = tid + u * TAIL_THREADS, r = i / q4, c = (i - r * q4) * 4;
+            for (int u = 0; u < STAGE_U; ++u) {
+                const int i = tid + u * THREADS, r = i / q4, c = (i - r * q4) * 4;
                 if (i >= n4) break;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (r < R) {
@@ -211,16 +225,16 @@ __global__ __launch_bounds__(TAIL_THREADS, 2) void decoder_tail_kernel(TailArgs 
                 *reinterpret_cast<f32x4*>(dst + r * a.ld_act[0] + c) = v;
             }
         } else {
-            f32x4 v[4];
+            f32x4 v[STAGE_U];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = tid + u * TAIL_THREADS, r = i / q4, c = (i - r * q4) * 4;
+            for (int u = 0; u < STAGE_U; ++u) {
+                const int i = tid + u * THREADS, r = i / q4, c = (i - r * q4) * 4;
                 v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (i < n4 && r < R) v[u] = *reinterpret_cast<const f32x4*>(a.a_in + (row0 + r) * K0 + c);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = tid + u * TAIL_THREADS, r = i / q4, c = (i - r * q4) * 4;
+            for (int u = 0; u < STAGE_U; ++u) {
+                const int i = tid + u * THREADS, r = i / q4, c = (i - r * q4) * 4;
                 if (i < n4) *reinterpret_cast<f32x4*>(dst + r * a.ld_act[0] + c) = v[u];
             }
         }
@@ -228,16 +242,23 @@ __global__ __launch_bounds__(TAIL_THREADS, 2) void decoder_tail_kernel(TailArgs 
     }
     // What the energy terms need besides the decoded pose does not depend on the layers: requested now (registers), parked in LDS
     // behind the first layer -- instead of two global round trips between the last forward layer and the first adjoint layer.
-    float pre_x0 = 0.f, pre_mb = 0.f;
-    int pre_par = 0, pre_ch = -1;
-    // (one element per thread: windows of more than TAIL_THREADS pose values -- T >= 12 with 15 joints -- read their inputs from
+    float pre_x0[PRE_E], pre_mb = 0.f;
+    int pre_par = 0, pre_ch[PRE_E];
+#pragma unroll
+    for (int k = 0; k < PRE_E; ++k) { pre_x0[k] = 0.f; pre_ch[k] = -1; }
+    // (PRE_E elements per thread, 512 per window: windows of more pose values -- T >= 12 with 15 joints -- read their inputs from
     // global memory inside energy_window instead)
+    static_assert(MAXJ * MAXJ <= TAIL_THREADS && MAXJ <= 64, "the children table is parked by PRE_E passes of the workgroup");
     const bool pre_on = a.G == 1 && !a.forward_only && T * a.e.J * 3 <= TAIL_THREADS;
     if (pre_on) {
         const int J = a.e.J, n = T * J * 3, bw = a.e.perm ? a.e.perm[w0] : w0;
-        if (tid < n) pre_x0 = a.e.X0[(size_t)bw * n + tid];
+#pragma unroll
+        for (int k = 0; k < PRE_E; ++k) {
+            const int e = tid + k * THREADS;
+            if (e < n) pre_x0[k] = a.e.X0[(size_t)bw * n + e];
+            if (e < J * MAXJ) pre_ch[k] = a.e.children[e];
+        }
         if (tid < J) { pre_mb = a.e.mean_bone[(size_t)bw * J + tid]; pre_par = a.e.parents[tid]; }
-        if (tid < J * MAXJ) pre_ch = a.e.children[tid];
     }
     TAIL_PROBE();
     __syncthreads();
@@ -245,7 +266,7 @@ __global__ __launch_bounds__(TAIL_THREADS, 2) void decoder_tail_kernel(TailArgs 
 
     // ---- forward layers
     f32x4 bpre[4];
-    tail_prefetch_first(a.fwd[0], bpre);
+    tail_prefetch_first<W>(a.fwd[0], bpre);
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
         const bool last = (i + 1 == NL);
@@ -254,7 +275,7 @@ __global__ __launch_bounds__(TAIL_THREADS, 2) void decoder_tail_kernel(TailArgs 
         float* Xp = last ? a.Xp : nullptr;
         // (by value: taking the address of a kernel-argument member would put the whole struct in scratch)
         const TailLayerDev nxt = !last ? a.fwd[i + 1 < NL ? i + 1 : i] : a.bwd[NL - 1];
-        tail_gemm(lds + a.off_act[i], a.ld_act[i], lds + a.off_zero, a.fwd[i], nxt, !last || !a.forward_only, T, R, bpre,
+        tail_gemm<W>(lds + a.off_act[i], a.ld_act[i], lds + a.off_zero, a.fwd[i], nxt, !last || !a.forward_only, T, R, bpre,
                   [&](const f32x4& acc, int r0, int col, float bv) {
 #pragma unroll
                       for (int e = 0; e < 4; ++e) {
@@ -268,9 +289,13 @@ __global__ __launch_bounds__(TAIL_THREADS, 2) void decoder_tail_kernel(TailArgs 
             const int J = a.e.J, n = T * J * 3;
             float* pre = lds + a.off_pre;
             int* prei = reinterpret_cast<int*>(pre + n + J);
-            if (tid < n) pre[tid] = pre_x0;
+#pragma unroll
+            for (int k = 0; k < PRE_E; ++k) {
+                const int e = tid + k * THREADS;
+                if (e < n) pre[e] = pre_x0[k];
+                if (e < J * MAXJ) prei[J + e] = pre_ch[k];
+            }
             if (tid < J) { pre[n + tid] = pre_mb; prei[tid] = pre_par; }
-            if (tid < J * MAXJ) prei[J + tid] = pre_ch;
         }
         __syncthreads();
         TAIL_PROBE();
@@ -287,12 +312,12 @@ __global__ __launch_bounds__(TAIL_THREADS, 2) void decoder_tail_kernel(TailArgs 
         const float* pre = lds + a.off_pre;
         const int* prei = reinterpret_cast<const int*>(pre + n + J);
         if (T == 10 && J == 15)      // the usual window shape: compile-time index arithmetic (same numbers)
-            energy_window<true, TAIL_THREADS, 10, 15>(a.e, a.e.perm ? a.e.perm[w0] : w0, tid, lds + a.off_act[NL], a.ld_act[NL], scr,
+            energy_window<true, THREADS, 10, 15>(a.e, a.e.perm ? a.e.perm[w0] : w0, tid, lds + a.off_act[NL], a.ld_act[NL], scr,
                                                       scr + a.escr, scr + 2 * a.escr, scr + 3 * a.escr, g_cur, a.ld_g, a.fwd[NL - 1].N,
                                                       nullptr, pre_on ? pre : nullptr, pre_on ? pre + n : nullptr, pre_on ? prei : nullptr,
                                                       pre_on ? prei + J : nullptr);
         else
-            energy_window<true, TAIL_THREADS>(a.e, a.e.perm ? a.e.perm[w0] : w0, tid, lds + a.off_act[NL], a.ld_act[NL], scr,
+            energy_window<true, THREADS>(a.e, a.e.perm ? a.e.perm[w0] : w0, tid, lds + a.off_act[NL], a.ld_act[NL], scr,
                                               scr + a.escr, scr + 2 * a.escr, scr + 3 * a.escr, g_cur, a.ld_g, a.fwd[NL - 1].N,
                                               nullptr, pre_on ? pre : nullptr, pre_on ? pre + n : nullptr, pre_on ? prei : nullptr,
                                               pre_on ? prei + J : nullptr);
@@ -314,7 +339,7 @@ __global__ __launch_bounds__(TAIL_THREADS, 2) void decoder_tail_kernel(TailArgs 
         float* gout = a.g_out;
         uint16_t* gout_b = a.g_out_b;
         const int K0 = a.fwd[0].K;
-        tail_gemm(g_cur, a.ld_g, lds + a.off_zero, a.bwd[i], a.bwd[i > 0 ? i - 1 : 0], i > 0, T, R, bpre,
+        tail_gemm<W>(g_cur, a.ld_g, lds + a.off_zero, a.bwd[i], a.bwd[i > 0 ? i - 1 : 0], i > 0, T, R, bpre,
                   [&](const f32x4& acc, int r0, int col, float) {
 #pragma unroll
                       for (int e = 0; e < 4; ++e) {
@@ -372,12 +397,64 @@ size_t plan_tail(const std::vector<Layer>& dec, int start, int T, int J, TailArg
     return (size_t)off * sizeof(float);
 }
 
+template <int NL, int W>
+static void launch_tail_as(gem_handle* h, const TailArgs& a, int wgs, size_t lds_bytes, hipStream_t s) {
+    note_kernel(h, reinterpret_cast<const void*>(decoder_tail_kernel<NL, W>));
+    hipLaunchKernelGGL((decoder_tail_kernel<NL, W>), dim3(wgs), dim3(64 * W), lds_bytes, s, a);
+}
+
+template <int W>
+static int launch_tail_w(gem_handle* h, const TailArgs& a, int wgs, size_t lds_bytes, hipStream_t s) {
+    switch (a.n) {
+        case 1: launch_tail_as<1, W>(h, a, wgs, lds_bytes, s); break;
+        case 2: launch_tail_as<2, W>(h, a, wgs, lds_bytes, s); break;
+        case 3: launch_tail_as<3, W>(h, a, wgs, lds_bytes, s); break;
+        case 4: launch_tail_as<4, W>(h, a, wgs, lds_bytes, s); break;
+        case 5: launch_tail_as<5, W>(h, a, wgs, lds_bytes, s); break;
+        case 6: launch_tail_as<6, W>(h, a, wgs, lds_bytes, s); break;
+        default: set_error("launch_tail: unsupported number of fused layers"); return 1;
+    }
+    return 0;
+}
+
+// More workgroups than CUs: the 4-wave shape, two workgroups per CU (see TAIL_WAVES_SHARED).  It needs one window per workgroup
+// (its energy phase is the whole-workgroup one), layers of at most 256 columns (four 16-column tiles per wave) and room for two
+// LDS carves per CU.
+static bool tail_can_share_cu(const TailArgs& a, size_t lds_bytes) {
+    if (a.G != 1 || 2 * lds_bytes > 160 * 1024) return false;
+    for (int i = 0; i < a.n; ++i)
+        if (a.fwd[i].N > 64 * TAIL_WAVES_SHARED || a.bwd[i].N > 64 * TAIL_WAVES_SHARED) return false;
+    return true;
+}
+
+static bool tail_shares_cu(const gem_handle* h, const TailArgs& a, int wgs, size_t lds_bytes) {
+    if (const char* f = dev_env("GEM_TAIL_WAVES")) return atoi(f) == TAIL_WAVES_SHARED && a.G == 1;
+    return wgs > h->n_cu && tail_can_share_cu(a, lds_bytes);
+}
+
+// Up to how many workgroups the fused tail beats the batched narrow layers + energy kernel (fp32, windows/s, MI355X, round 5):
+//   windows              480     768    1152    1536    2040    2556    3072    4092
+//   4-wave, two per CU  42.9 k  45.5 k  44.9 k  48.0 k  51.4 k  51.4 k  53.2 k  52.0 k
+//   8-wave, one per CU  40.8 k                  45.1 k                          48.3 k
+//   batched layers      30.7 k  38.5 k  41.6 k  45.8 k  50.4 k  49.8 k  55.6 k  54.7 k
+// (the fused tail costs one workgroup's latency chain per pair of windows and CU whatever the batch; the batched layers amortise)
+int tail_cap_workgroups(const gem_handle* h, const std::vector<Layer>& dec, int start, size_t lds_bytes) {
+    if (const char* f = dev_env("GEM_TAIL_CAP")) return atoi(f) * h->n_cu;
+    TailArgs a{};
+    if (!plan_tail(dec, start, h->T, h->J, &a)) return 0;
+    for (int i = 0; i < a.n; ++i) { a.fwd[i].N = dec[start + i].N; a.bwd[i].N = dec[start + i].K; }
+    return (tail_can_share_cu(a, lds_bytes) ? 10 : 5) * h->n_cu;
+}
+
 int launch_tail(gem_handle* h, const TailArgs& a, size_t lds_bytes, hipStream_t s) {
     static PerDeviceOnce attr_once;
     if (attr_once.need(h->cfg.device)) {
-        const void* ks[] = {reinterpret_cast<const void*>(decoder_tail_kernel<1>), reinterpret_cast<const void*>(decoder_tail_kernel<2>),
-                            reinterpret_cast<const void*>(decoder_tail_kernel<3>), reinterpret_cast<const void*>(decoder_tail_kernel<4>),
-                            reinterpret_cast<const void*>(decoder_tail_kernel<5>), reinterpret_cast<const void*>(decoder_tail_kernel<6>)};
+        const void* ks[] = {reinterpret_cast<const void*>(decoder_tail_kernel<1, 8>), reinterpret_cast<const void*>(decoder_tail_kernel<2, 8>),
+                            reinterpret_cast<const void*>(decoder_tail_kernel<3, 8>), reinterpret_cast<const void*>(decoder_tail_kernel<4, 8>),
+                            reinterpret_cast<const void*>(decoder_tail_kernel<5, 8>), reinterpret_cast<const void*>(decoder_tail_kernel<6, 8>),
+                            reinterpret_cast<const void*>(decoder_tail_kernel<1, 4>), reinterpret_cast<const void*>(decoder_tail_kernel<2, 4>),
+                            reinterpret_cast<const void*>(decoder_tail_kernel<3, 4>), reinterpret_cast<const void*>(decoder_tail_kernel<4, 4>),
+                            reinterpret_cast<const void*>(decoder_tail_kernel<5, 4>), reinterpret_cast<const void*>(decoder_tail_kernel<6, 4>)};
         for (const void* k : ks) GEM_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     Profile::Rec rec;
@@ -394,15 +471,8 @@ int launch_tail(gem_handle* h, const TailArgs& a, size_t lds_bytes, hipStream_t 
         GEM_HIP(hipEventRecord(rec.a, s));
     }
     const int wgs = (a.B + a.G - 1) / a.G;
-    switch (a.n) {
-        case 1: note_kernel(h, reinterpret_cast<const void*>(decoder_tail_kernel<1>)); hipLaunchKernelGGL(decoder_tail_kernel<1>, dim3(wgs), dim3(TAIL_THREADS), lds_bytes, s, a); break;
-        case 2: note_kernel(h, reinterpret_cast<const void*>(decoder_tail_kernel<2>)); hipLaunchKernelGGL(decoder_tail_kernel<2>, dim3(wgs), dim3(TAIL_THREADS), lds_bytes, s, a); break;
-        case 3: note_kernel(h, reinterpret_cast<const void*>(decoder_tail_kernel<3>)); hipLaunchKernelGGL(decoder_tail_kernel<3>, dim3(wgs), dim3(TAIL_THREADS), lds_bytes, s, a); break;
-        case 4: note_kernel(h, reinterpret_cast<const void*>(decoder_tail_kernel<4>)); hipLaunchKernelGGL(decoder_tail_kernel<4>, dim3(wgs), dim3(TAIL_THREADS), lds_bytes, s, a); break;
-        case 5: note_kernel(h, reinterpret_cast<const void*>(decoder_tail_kernel<5>)); hipLaunchKernelGGL(decoder_tail_kernel<5>, dim3(wgs), dim3(TAIL_THREADS), lds_bytes, s, a); break;
-        case 6: note_kernel(h, reinterpret_cast<const void*>(decoder_tail_kernel<6>)); hipLaunchKernelGGL(decoder_tail_kernel<6>, dim3(wgs), dim3(TAIL_THREADS), lds_bytes, s, a); break;
-        default: set_error("launch_tail: unsupported number of fused layers"); return 1;
-    }
+    if (tail_shares_cu(h, a, wgs, lds_bytes) ? launch_tail_w<TAIL_WAVES_SHARED>(h, a, wgs, lds_bytes, s) : launch_tail_w<TAIL_WAVES>(h, a, wgs, lds_bytes, s))
+        return 1;
     GEM_HIP(hipGetLastError());
     if (prof) { GEM_HIP(hipEventRecord(rec.b, s)); h->prof.recs.push_back(rec); }
     commit_kernel_names(h, prof ? 1 : -1);

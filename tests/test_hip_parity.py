@@ -515,6 +515,60 @@ def test_graph_cache_is_dropped_when_the_weights_are_reloaded(torch_cuda):
     eng.close()
 
 
+def test_graph_replay_survives_freed_and_reallocated_inputs(torch_cuda):
+    """A captured call holds the ADDRESS of the caller's heat-map tensor.  The caller drops that tensor and allocates another of the
+    same size (torch's caching allocator hands back the same address): without the engine's pin (WindowEngine._pin) the old graph
+    would be replayed on a buffer it does not own -- on ROCm 7.2 that ended in a GPU memory fault.  With the pin
+    the old tensor stays alive, so the new one gets a NEW address, the call is a new signature, and its result is the eager result
+    for the new heat maps.  `drop_graphs()` releases the pins; MAX_PINNED + 1 distinct inputs drop every captured call."""
+    import weakref
+    torch = torch_cuda
+    B = 6
+    seqs = [synth.make_sequence(n_frames=8 * (B - 1) + 10, seed=70 + i) for i in range(2)]
+    est = np.asarray(seqs[0]["estimated_local_skeleton"], dtype=np.float32)
+    starts = (8 * np.arange(B)).astype(np.int32)
+    pose = np.stack([est[s:s + 10] for s in starts])
+    mb = O.mean_bone_length(est)
+    eps = np.random.default_rng(9).normal(size=(B, TINY.latent_dim)).astype(np.float32)
+    w = _ew((1e-2, 1e-2, 1e-1, 1e-3, 1e-2))
+    heats = [np.asarray(s["heatmap_list"], dtype=np.float32) for s in seqs]
+    ref = _engine(TINY, max_windows=8)
+    ref.load_vae(0, vae_schema.synthetic_state_dict(TINY, 11))
+    eager = [ref.optimize_stage(0, pose, mb, eps, w, torch.as_tensor(h, device="cuda"), starts)[0].clone() for h in heats]
+    ref.close()
+    assert not torch.equal(eager[0], eager[1])
+    eng = _engine(TINY, max_windows=8)
+    eng.load_vae(0, vae_schema.synthetic_state_dict(TINY, 11))
+    eng.enable_graphs(True)
+    heat = torch.as_tensor(heats[0], device="cuda")
+    addr0, alive = heat.data_ptr(), weakref.ref(heat)
+    for k in range(3):                                   # eager, capture, replay
+        out = eng.optimize_stage(0, pose, mb, eps, w, heat, starts)[0]
+        torch.cuda.synchronize()
+        assert torch.equal(out, eager[0]), k
+    del heat
+    assert alive() is not None, "the engine must keep a captured call's inputs alive"
+    heat = torch.as_tensor(heats[1], device="cuda")
+    assert heat.data_ptr() != addr0
+    for k in range(3):
+        out = eng.optimize_stage(0, pose, mb, eps, w, heat, starts)[0]
+        torch.cuda.synchronize()
+        assert torch.equal(out, eager[1]), k
+    assert eng.graph_stats()["captures"] == 2
+    eng.drop_graphs()
+    assert alive() is None and len(eng._pinned) == 0
+    out = eng.optimize_stage(0, pose, mb, eps, w, heat, starts)[0]       # eager again after the drop, graphs still enabled
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager[1])
+    keep = [torch.as_tensor(heats[i % 2], device="cuda") for i in range(eng.MAX_PINNED + 1)]
+    for i, h in enumerate(keep):
+        out = eng.optimize_stage(0, pose, mb, eps, w, h, starts)[0]
+        torch.cuda.synchronize()
+        assert torch.equal(out, eager[i % 2]), i
+    assert len(eng._pinned) <= eng.MAX_PINNED
+    eng.close()
+
+
 @pytest.mark.parametrize("net,B", [("tiny", 3), ("tiny", 21), ("full", 8), ("full", 21), ("full", 40), ("structured", 40)])
 def test_bf16_multi_window_tail_against_the_batched_bf16_layers(torch_cuda, monkeypatch, golden, net, B):
     """bf16 decoder mode: the multi-window fused tail (csrc/tail_bf16.hip: 8 windows = five 16-row MFMA tiles per workgroup,
@@ -576,6 +630,71 @@ def test_bf16_multi_window_tail_against_the_batched_bf16_layers(torch_cuda, monk
     for k in range(min(B, 3)):
         Xo = O.decode(vae, z[k:k + 1])[0]
         assert np.abs(Xa[k] - Xo).max() <= 8e-3 * max(1.0, np.abs(Xo).max()), k
+
+
+@pytest.mark.parametrize("net", ["full", "structured"])
+def test_fp32_tail_shapes_compute_the_same(torch_cuda, monkeypatch, net):
+    """The fp32 fused tail (csrc/tail.hip) runs a window as one 8-wave workgroup per CU up to 256 windows and as 4-wave workgroups,
+    two per CU, beyond (up to ten per CU; then the batched narrow layers + energy kernel take over).  Both shapes walk K in the same
+    order for every output element and run the same energy arithmetic per element: decoded poses and latent gradients of 600 windows
+    are BITWISE the same, the fp64 energies agree to 1e-13 (their partial sums are combined over 4 instead of 8 wavefronts), and a
+    whole stage finishes with the same poses.  Against the batched layers: rounding level; against the fp32 oracle: first windows."""
+    from globalegomocap_amd.engine import stats_to_numpy
+    torch = torch_cuda
+    shape = FULL
+    sd = vae_schema.synthetic_state_dict(FULL, 5) if net == "full" else vae_schema.structured_state_dict(FULL, 7, feature_offset=0.0)
+    vae = O.fold_vae(sd)
+    B = 600
+    seq = synth.make_sequence(n_frames=200, seed=37)
+    est = np.asarray(seq["estimated_local_skeleton"], dtype=np.float32)
+    heat = torch.as_tensor(np.asarray(seq["heatmap_list"], dtype=np.float32), device="cuda")
+    rng = np.random.default_rng(B)
+    starts = rng.integers(0, 190, B).astype(np.int32)
+    pose = np.stack([est[s:s + 10] for s in starts])
+    mb = O.mean_bone_length(est)
+    mu, _ = O.encode(vae, pose[:64].reshape(64, 10, 45))
+    z = (np.tile(mu, (B // 64 + 1, 1))[:B] + 0.1 * rng.normal(size=(B, shape.latent_dim))).astype(np.float32)
+    eps = rng.normal(size=(B, shape.latent_dim)).astype(np.float32)
+    cam = oracle_camera()
+    res = {}
+    monkeypatch.setenv("GEM_DEV", "1")
+    for tag, env in (("two_per_cu", {}), ("one_per_cu", {"GEM_TAIL_WAVES": "8"}), ("batched", {"GEM_TAIL_CAP": "0"})):
+        for k in ("GEM_TAIL_WAVES", "GEM_TAIL_CAP"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = _engine(shape, max_windows=B)
+        eng.load_vae(0, sd)
+        eng.profile_enable(True)
+        E, parts, dz, X = eng.energy_grad(0, z, pose, mb, _ew(W_ALL), heat, starts)
+        torch.cuda.synchronize()
+        names = eng.profile_kernels(1)                   # family 1 = the fused tail (empty when the batched layers ran)
+        eng.profile_enable(False)
+        out, stats = eng.optimize_stage(0, pose, mb, eps, _ew((1e-6, 1e-5, 1e-2, 0.0, 1e-2)), heat, starts)
+        torch.cuda.synchronize()
+        res[tag] = (E.cpu().numpy(), parts.cpu().numpy(), dz.cpu().numpy(), X.cpu().numpy(), out.cpu().numpy(), stats_to_numpy(stats), names)
+        eng.close()
+    a, b, c = res["two_per_cu"], res["one_per_cu"], res["batched"]
+    assert "decoder_tail_kernel<5, 4>" in a[6] and "decoder_tail_kernel<5, 8>" in b[6] and "decoder_tail_kernel" not in c[6], (a[6], b[6], c[6])
+    assert np.array_equal(a[3], b[3]) and np.array_equal(a[2], b[2])
+    np.testing.assert_allclose(a[0], b[0], rtol=1e-13)
+    np.testing.assert_allclose(a[1], b[1], rtol=1e-12, atol=1e-300)
+    assert a[5]["finished"].all() and b[5]["finished"].all()
+    assert np.array_equal(a[5]["func_evals"], b[5]["func_evals"])
+    np.testing.assert_allclose(a[4], b[4], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(a[0], c[0], rtol=1e-5)
+    np.testing.assert_allclose(a[1], c[1], rtol=1e-5, atol=1e-9)
+    # (another summation order in the batched layers: a pre-activation at rounding distance from 0 takes the other LeakyReLU slope
+    # in a few of the 600 windows -- the structured weights have many exact-zero features)
+    qg = np.quantile(np.abs(a[2] - c[2]).ravel() / np.abs(c[2]).max(), [0.5, 0.999, 1.0])
+    assert qg[0] <= 1e-5 and qg[1] <= 1e-3 and qg[2] <= 2e-2, qg
+    for k in range(3):
+        Xo, acts = O.decode(vae, z[k:k + 1], keep=True)
+        f, p, dX = O.energy_and_grad(Xo[0], pose[k], mb, O.Weights(*W_ALL), cam, np.asarray(seq["heatmap_list"], dtype=np.float32)[starts[k]:starts[k] + 10])
+        dzo = O.decode_backward(vae, dX[None], acts)[0]
+        np.testing.assert_allclose(a[3][k], Xo[0], rtol=2e-4, atol=2e-5)
+        assert abs(a[0][k] - f) <= 2e-4 * abs(f) + 1e-7, (k, a[0][k], f)
+        assert np.abs(a[2][k] - dzo).max() <= 2e-3 * np.abs(dzo).max() + 1e-8
 
 
 def test_bf16_tail_row_tile_variants_compute_the_same(torch_cuda, monkeypatch):

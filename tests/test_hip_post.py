@@ -368,3 +368,37 @@ def test_main_returns_the_reference_container_types(golden, tmp_path):
             assert isinstance(opt, np.ndarray) and opt.shape == (98, 15, 3) and opt.dtype == np.float64
         else:
             assert isinstance(opt, list) and len(opt) == 98 and opt[0].shape == (15, 3) and opt[0].dtype == np.float64
+
+
+def test_integration_md_reporting_stub_runs_verbatim(engine, golden):
+    """The second ctypes block of INTEGRATION.md section 2 (the reporting call a maintainer would put behind
+    /root/reference/optimize_whole_sequence.py's calculate_errors, calculate_errors.py:114-179), executed verbatim against the library
+    -- its own CDLL handle, no argtypes -- on the sequences of the reference-generated golden run; its 17 + 15 numbers must be the
+    engine's own `calculate_errors_device` bit for bit and the reference's golden error dict (same tolerances as the test above)."""
+    import ctypes as C
+    import re
+    import types
+    import torch
+    from globalegomocap_amd.skeleton import mean_bone_length_mm
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sec = open(os.path.join(root, "INTEGRATION.md")).read().split("## 2.", 1)[1]
+    code = next(b for b in re.findall(r"```python\n(.*?)```", sec, flags=re.S) if "gem_calculate_errors" in b)
+    g = golden("pipeline_tiny")
+    cams = np.asarray(synth.make_sequence(n_frames=100, seed=int(g["seq_seed"]), with_heatmaps=False)["camera_pose_list"])
+    lib = C.CDLL(os.path.join(root, "globalegomocap_amd", "_lib", "libgem_hip.so"))
+    for tag in ("smooth", "raw"):
+        mid = g["mid_local_" + tag] + cams[:98, :3, 3][:, None, :]
+        est, mid, opt, gt = (torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float64, device="cuda")
+                             for x in (g["est_" + tag], mid, g["opt_" + tag], g["gt_" + tag]))
+        ns = {"C": C, "torch": torch, "lib": lib, "h": engine._h, "est": est, "mid": mid, "opt": opt, "gt": gt,
+              "skeleton_model": types.SimpleNamespace(bone_length=[float(v) for v in mean_bone_length_mm()]),
+              "stream": C.c_void_p(torch.cuda.current_stream().cuda_stream)}
+        exec(code, ns)
+        torch.cuda.synchronize()
+        assert ns["rc"] == 0
+        assert torch.equal(ns["out"], engine.calculate_errors_device(est, mid, opt, gt))
+        rep = ns["out"].cpu().numpy()
+        for i, k in enumerate(engine.ERROR_KEYS):
+            tol = dict(rtol=1e-5, atol=1e-7) if "mid" in k else dict(rtol=1e-9, atol=1e-12)
+            np.testing.assert_allclose(rep[i], g["err_%s/%s" % (tag, k)], err_msg=k, **tol)
+        np.testing.assert_allclose(rep[17:], g["err_%s/joints_error" % tag], rtol=1e-9, atol=1e-12)
