@@ -587,7 +587,7 @@ static int evaluate(gem_handle* h, int stage, int B, const float* zp, const Ener
     static const bool force_tail = dev_env("GEM_FORCE_TAIL") != nullptr;
     const int tail_g = h->T <= 16 ? 16 / h->T : 1;
     const int tail_wgs = (B + tail_g - 1) / tail_g;
-    const int tail_cap = net.tail_start >= 0 ? tail_cap_workgroups(h, net.dec, net.tail_start, net.tail_lds) : 0;
+    const int tail_cap = net.tail_start >= 0 ? tail_cap_workgroups(h, net.dec, net.tail_start) : 0;
     if (net.tail_start < 0 || (tail_wgs > tail_cap && !force_tail)) {
         if (decoder_forward(h, stage, B, zp, s)) return 1;
         if (forward_only) return 0;
@@ -621,7 +621,7 @@ static int evaluate(gem_handle* h, int stage, int B, const float* zp, const Ener
         }
     }
     TailArgs ta;
-    plan_tail(net.dec, st, h->T, h->J, &ta);
+    const size_t tail_lds = plan_tail_for(h, net.dec, st, tail_wgs, &ta);
     ta.B = B; ta.forward_only = forward_only ? 1 : 0; ta.dbg_ts = nullptr;
     ta.in_slab = in_slab; ta.in_bias = front ? net.front.bias : (st > 0 ? net.dec[st - 1].bias : nullptr);
     ta.in_bias_ld = front ? net.dec[0].N : 0;
@@ -633,7 +633,7 @@ static int evaluate(gem_handle* h, int stage, int B, const float* zp, const Ener
     }
     ta.a_in = st > 0 ? w.dec_act[st - 1] : w.h0; ta.g_out = w.dec_grad[st]; ta.g_out_b = nullptr; ta.Xp = (w.dyn && !forward_only) ? nullptr : w.dec_act.back();     // the pose is only read back outside the rounds
     ta.e = ea;
-    if (launch_tail(h, ta, net.tail_lds, s)) return 1;
+    if (launch_tail(h, ta, tail_lds, s)) return 1;
     if (forward_only) return 0;
     if (record_mid(h, s)) return 1;
     if (front) {

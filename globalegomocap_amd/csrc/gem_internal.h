@@ -375,6 +375,7 @@ constexpr int TAIL_MAX_LAYERS = 6;
 struct TailLayerDev { const float* w4; const float* bias; int K, N; };
 struct TailArgs {
     int n, B, G, forward_only, escr, mask_first;
+    int waves, rows;         // kernel shape (8 wavefronts, one workgroup per CU | 4, three per CU) and rows per LDS buffer (16 | G*T): plan_tail
     SlabSrc in_slab;         // a_in still lies in split-K slabs (+ in_bias, LeakyReLU to apply) when in_slab.base != nullptr
     const float* in_bias;    // bias of row r, column c: in_bias[(r % T) * in_bias_ld + c]
     int in_bias_ld;          // 0: one bias per channel (a conv produced a_in); K0: per (frame, channel) (the composed front layer)
@@ -387,7 +388,8 @@ struct TailArgs {
     int off_act[TAIL_MAX_LAYERS + 1], ld_act[TAIL_MAX_LAYERS + 1], off_g[2], ld_g, off_red, off_escr, off_zero, off_pre;   // LDS plan (floats); off_pre: per-window inputs of the energy terms (G == 1)
     EnergyArgs e;
 };
-size_t plan_tail(const std::vector<Layer>& dec, int start, int T, int J, TailArgs* out);
+size_t plan_tail(const std::vector<Layer>& dec, int start, int T, int J, TailArgs* out, bool shared = false);
+size_t plan_tail_for(const gem_handle* h, const std::vector<Layer>& dec, int start, int wgs, TailArgs* out);   // shape chosen for `wgs` workgroups
 
 // bf16 multi-window fused tail (tail_bf16.hip): nrt = 1 .. 5 row tiles of 16 rows = G = min(8, 16 nrt / T) windows per workgroup,
 // up to two workgroups per CU (<= 80 KB of LDS, <= 128 VGPRs)
@@ -420,7 +422,7 @@ int tail_bf16_row_tiles(const gem_handle* h, int B, int T);
 int build_tail_bf16_stream(gem_handle* h, StageNet& net);
 int launch_tail_bf16(gem_handle* h, const TailB16Args& a, size_t lds_bytes, hipStream_t s);
 int launch_tail(gem_handle* h, const TailArgs& a, size_t lds_bytes, hipStream_t s);
-int tail_cap_workgroups(const gem_handle* h, const std::vector<Layer>& dec, int start, size_t lds_bytes);   // fused tail up to this many workgroups
+int tail_cap_workgroups(const gem_handle* h, const std::vector<Layer>& dec, int start);   // fused tail up to this many workgroups
 int launch_mean_bone(gem_handle* h, const float* pose, int n_frames, float* out, hipStream_t s);
 int launch_gather_windows(const float* frames, const int32_t* frame0, float* out, int B, int T, int JC, hipStream_t s);
 int launch_relative_global(const float* local, const double* cams, const int32_t* frame0, float* rel, int B, int T, int J,

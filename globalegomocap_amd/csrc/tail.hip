@@ -40,15 +40,15 @@ __device__ __forceinline__ float bf16_round(float x) {
 // 8 waves per workgroup = 2 per SIMD: the per-block latency chain (L2 weight fragment -> LDS fragment -> 16 MFMAs)
 // of one wave overlaps the other's, and K is cut twice as fine (each wave walks half as many blocks).  That is the shape for
 // batches of at most one workgroup per CU (the 240-window workload): the window's chain is as short as it gets.
-// With MORE workgroups than CUs the 8-wave kernel (243 VGPRs, 2 waves per SIMD) runs them one after the other on a CU, each
-// paying its staging / barrier / energy latencies with the MFMA pipes idle.  The 4-wave shape (W = 4: one wave per SIMD, each
-// wave owns twice the columns, so one LDS A fragment feeds twice the MFMAs) lets TWO workgroups share a CU (2 x 70 KB LDS,
-// 2 waves per SIMD in total, the same register budget): one window's latencies hide behind the other's matrix work.  Same K walk
+// With MORE workgroups than CUs the 8-wave kernel (243 VGPRs, 2 waves per SIMD, 70 KB of LDS) runs them one after the other on a
+// CU, each paying its staging / barrier / energy latencies with the MFMA pipes idle.  The 4-wave shape (W = 4: one wave per SIMD,
+// each wave owns twice the columns, so one LDS A fragment feeds twice the MFMAs; LDS buffers of the window's T rows instead of 16:
+// 48 KB; 167 VGPRs) lets THREE workgroups share a CU: one window's latencies hide behind the others' matrix work.  Same K walk
 // per output element, so the layers' results are bitwise those of the 8-wave shape; the energies' fp64 partial sums are
 // combined over 4 instead of 8 wavefronts (last-bit differences in f only).
 constexpr int TAIL_WAVES = 8;
 constexpr int TAIL_THREADS = TAIL_WAVES * 64;
-constexpr int TAIL_WAVES_SHARED = 4;       // the two-workgroups-per-CU shape
+constexpr int TAIL_WAVES_SHARED = 4;       // the three-workgroups-per-CU shape
 
 // Tiling: 16x16 output tiles (v_mfma_f32_16x16x4_f32), tile i of wave w = columns 16w + 128i, FULL K walk per
 // tile, so no partial sums have to be combined through LDS.  K blocks of 64: lane (r = lane&15, q = lane>>4) holds, for each of the
@@ -74,15 +74,19 @@ __device__ __forceinline__ void tail_prefetch_first(const TailLayerDev L, f32x4 
 // epi(acc, tile_row0, col, bias_value) receives the 4 rows tile_row0 + 4*(lane>>4) + {0..3} of column `col`.
 // NT = tiles per wave (N / 128, at least 1): the NT tiles of a wave share the 16 rows, so they walk K together:
 // one A fragment feeds NT independent accumulators.
+// c0 / use_pre: a layer done as several passes over column ranges (4-wave shape, N = 256: two passes of two tiles per wave, so
+// that the operand double buffers stay within the register budget of three waves per SIMD) starts pass p at column c0 = p * NT * TS;
+// only the first pass finds its first B fragment in bpre, only the last one (has_next) fetches the next layer's.
 template <int W, int NT, typename Epi>
 __device__ __forceinline__ void tail_gemm_nt(const float* in, int ld_in, const float* zero_line, const TailLayerDev L,
-                                             const TailLayerDev next, bool has_next, int T, int R, f32x4 (&bpre)[4], Epi epi) {
+                                             const TailLayerDev next, bool has_next, int T, int R, f32x4 (&bpre)[4], Epi epi,
+                                             int c0 = 0, bool use_pre = true) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
     const int kb = L.K / 64, nblk = 3 * kb;                   // (tap, 64-wide k block) pairs
     const f32x4* W4 = reinterpret_cast<const f32x4*>(L.w4);
     constexpr int TS = 16 * W;                                // column stride between the tiles of a wave
-    const int n0 = wave * 16;                                 // tile i of this wave: columns n0 + TS*i
+    const int n0 = wave * 16 + c0;                            // tile i of this wave: columns n0 + TS*i
     if (n0 >= L.N) {                                          // 64-wide layer, 8 waves: waves 4-7 only fetch ahead
         if (has_next) tail_prefetch_first<W>(next, bpre);
         return;
@@ -131,8 +135,10 @@ __device__ __forceinline__ void tail_gemm_nt(const float* in, int ld_in, const f
     // two register sets for both operands, loads issued one block (16*NT MFMAs) ahead of their use
     f32x4 b0[NT][4], b1[NT][4], a0[4], a1[4];
     TAIL_LOAD_B(0, b0);
+    if (use_pre) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) b0[0][g] = bpre[g];           // tile 0 / block 0 was prefetched by the previous layer
+        for (int g = 0; g < 4; ++g) b0[0][g] = bpre[g];       // tile 0 / block 0 was prefetched by the previous layer
+    }
     TAIL_LOAD_A(0, a0);
     // Branch-free pair loop (a conditional prefetch makes hipcc fall back to vmcnt(0) at the join) with
     // sched_barriers (otherwise both prefetches are hoisted to the loop top and waited for together).
@@ -163,18 +169,27 @@ __device__ __forceinline__ void tail_gemm_nt(const float* in, int ld_in, const f
 template <int W, typename Epi>
 __device__ __forceinline__ void tail_gemm(const float* in, int ld_in, const float* zero_line, const TailLayerDev L,
                                           const TailLayerDev next, bool has_next, int T, int R, f32x4 (&bpre)[4], Epi epi) {
-    // N is 64, 128, 256 or 512 (plan_tail): N / (16 W) tiles per wave, at least one (W = 4: N <= 256, launch_tail checks)
-    if (L.N > 32 * W) tail_gemm_nt<W, 4>(in, ld_in, zero_line, L, next, has_next, T, R, bpre, epi);
-    else if (L.N > 16 * W) tail_gemm_nt<W, 2>(in, ld_in, zero_line, L, next, has_next, T, R, bpre, epi);
-    else tail_gemm_nt<W, 1>(in, ld_in, zero_line, L, next, has_next, T, R, bpre, epi);
+    // N is 64, 128, 256 or 512 (plan_tail): N / (16 W) tiles per wave, at least one (W = 4: N <= 256, tail_can_share_cu checks)
+    if constexpr (W == TAIL_WAVES_SHARED) {
+        if (L.N > 32 * W) {
+            tail_gemm_nt<W, 2>(in, ld_in, zero_line, L, next, false, T, R, bpre, epi);
+            tail_gemm_nt<W, 2>(in, ld_in, zero_line, L, next, has_next, T, R, bpre, epi, 32 * W, false);
+        } else if (L.N > 16 * W) tail_gemm_nt<W, 2>(in, ld_in, zero_line, L, next, has_next, T, R, bpre, epi);
+        else tail_gemm_nt<W, 1>(in, ld_in, zero_line, L, next, has_next, T, R, bpre, epi);
+    } else {
+        if (L.N > 32 * W) tail_gemm_nt<W, 4>(in, ld_in, zero_line, L, next, has_next, T, R, bpre, epi);
+        else if (L.N > 16 * W) tail_gemm_nt<W, 2>(in, ld_in, zero_line, L, next, has_next, T, R, bpre, epi);
+        else tail_gemm_nt<W, 1>(in, ld_in, zero_line, L, next, has_next, T, R, bpre, epi);
+    }
 }
 
 // NL = number of fused layers (compile time: the two layer loops unroll, so every layer's descriptor sits at a fixed
 // kernel-argument offset instead of being fetched by index behind each barrier)
 // W = wavefronts per workgroup: 8 (one workgroup per CU) or 4 (two per CU, G == 1 and N <= 256 only); launch_tail chooses
 template <int NL, int W>
-__global__ __launch_bounds__(64 * W, 2) void decoder_tail_kernel(TailArgs a) {
+__global__ __launch_bounds__(64 * W, W == TAIL_WAVES_SHARED ? 3 : 2) void decoder_tail_kernel(TailArgs a) {
     constexpr int THREADS = 64 * W;
+    constexpr bool TIGHT = W == TAIL_WAVES_SHARED;           // the LDS carve holds a.rows = G*T rows per buffer instead of 16
     constexpr int STAGE_U = 2048 / THREADS;                  // float4 per thread that cover 16 rows of K0 <= 512
     constexpr int PRE_E = TAIL_THREADS / THREADS;            // parked energy inputs per thread (up to 512 values per window)
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -198,7 +213,7 @@ __global__ __launch_bounds__(64 * W, 2) void decoder_tail_kernel(TailArgs a) {
     // rounds the producer GEMM leaves its split-K slabs here: they are summed in slab order (bitwise what the reduce
     // kernel would have written), bias and LeakyReLU applied on the way into LDS.
     {
-        const int K0 = a.fwd[0].K, q4 = K0 / 4, n4 = TAIL_ROWS * q4;      // K0 <= 512: at most 4 float4 per thread
+        const int K0 = a.fwd[0].K, q4 = K0 / 4, n4 = (TIGHT ? a.rows : TAIL_ROWS) * q4;      // K0 <= 512: at most 2048 / THREADS float4 per thread
         float* dst = lds + a.off_act[0];
         if (a.in_slab.base) {
             int nslab;
@@ -281,7 +296,7 @@ __global__ __launch_bounds__(64 * W, 2) void decoder_tail_kernel(TailArgs a) {
                       for (int e = 0; e < 4; ++e) {
                           float v = acc[e] + bv;
                           if (!last) v = v > 0.f ? v : v * LEAKY_SLOPE;
-                          out[(r0 + e) * ldo + col] = v;
+                          if (!TIGHT || r0 + e < a.rows) out[(r0 + e) * ldo + col] = v;
                           if (Xp && r0 + e < R) Xp[(row0 + r0 + e) * PAD + col] = v;
                       }
                   });
@@ -346,7 +361,7 @@ __global__ __launch_bounds__(64 * W, 2) void decoder_tail_kernel(TailArgs a) {
                           const int row = r0 + e;
                           // (a chain that starts at the first conv reads the linear decoder_input output: no mask)
                           const float v = (i > 0 || a.mask_first) ? acc[e] * (act[row * lda + col] > 0.f ? 1.f : LEAKY_SLOPE) : acc[e];
-                          if (i > 0) g_nxt[row * ldg + col] = v;
+                          if (i > 0) { if (!TIGHT || row < a.rows) g_nxt[row * ldg + col] = v; }
                           else if (row < R) {
                               if (gout_b) gout_b[(row0 + row) * K0 + col] = (uint16_t)(__builtin_bit_cast(unsigned int, bf16_round(v)) >> 16);
                               else gout[(row0 + row) * K0 + col] = v;
@@ -362,7 +377,7 @@ __global__ __launch_bounds__(64 * W, 2) void decoder_tail_kernel(TailArgs a) {
 
 // LDS plan for a fused chain starting at decoder conv `start` (input = output of conv start-1, or of
 // decoder_input when start == 0).  Returns the byte size, or 0 when the chain is not fusable.
-size_t plan_tail(const std::vector<Layer>& dec, int start, int T, int J, TailArgs* out) {
+size_t plan_tail(const std::vector<Layer>& dec, int start, int T, int J, TailArgs* out, bool shared) {
     const int n = (int)dec.size() - start;
     if (start < 0 || n < 1 || n > TAIL_MAX_LAYERS || T > TAIL_ROWS) return 0;
     for (int i = start; i < (int)dec.size(); ++i) {
@@ -374,17 +389,23 @@ size_t plan_tail(const std::vector<Layer>& dec, int start, int T, int J, TailArg
     a.n = n;
     a.mask_first = start > 0;
     a.G = TAIL_ROWS / T;
+    if (shared && a.G != 1) return 0;
+    // shared (4-wave shape, three workgroups per CU): buffers of G*T rows -- rows past them are never read (the A fragments of rows
+    // >= R come from the zero line) and the epilogues do not write them
+    a.waves = shared ? TAIL_WAVES_SHARED : TAIL_WAVES;
+    a.rows = shared ? a.G * T : TAIL_ROWS;
+    const int rows = a.rows;
     int off = 0, maxg = 0;
     for (int i = 0; i <= n; ++i) {
         const int width = i == 0 ? dec[start].K : dec[start + i - 1].N;
         a.off_act[i] = off;
         a.ld_act[i] = width + 4;
-        off += TAIL_ROWS * (width + 4);
+        off += rows * (width + 4);
         if (i >= 1 && width > maxg) maxg = width;
     }
     a.ld_g = maxg + 4;
-    a.off_g[0] = off; off += TAIL_ROWS * a.ld_g;
-    a.off_g[1] = off; off += TAIL_ROWS * a.ld_g;
+    a.off_g[0] = off; off += rows * a.ld_g;
+    a.off_g[1] = off; off += rows * a.ld_g;
     a.escr = (T * J * 3 + 3) / 4 * 4;
     a.off_red = off;                       // (unused since the 16x16 tiling needs no k-split scratch)
     a.off_escr = off;
@@ -417,33 +438,35 @@ static int launch_tail_w(gem_handle* h, const TailArgs& a, int wgs, size_t lds_b
     return 0;
 }
 
-// More workgroups than CUs: the 4-wave shape, two workgroups per CU (see TAIL_WAVES_SHARED).  It needs one window per workgroup
-// (its energy phase is the whole-workgroup one), layers of at most 256 columns (four 16-column tiles per wave) and room for two
-// LDS carves per CU.
-static bool tail_can_share_cu(const TailArgs& a, size_t lds_bytes) {
-    if (a.G != 1 || 2 * lds_bytes > 160 * 1024) return false;
-    for (int i = 0; i < a.n; ++i)
-        if (a.fwd[i].N > 64 * TAIL_WAVES_SHARED || a.bwd[i].N > 64 * TAIL_WAVES_SHARED) return false;
+// More workgroups than CUs: the 4-wave shape, three workgroups per CU (see TAIL_WAVES_SHARED).  It needs one window per workgroup
+// (its energy phase is the whole-workgroup one), layers of at most 256 columns (two passes of two 16-column tiles per wave) and
+// room for three of its LDS carves per CU.
+static bool tail_can_share_cu(const std::vector<Layer>& dec, int start, int T, int J) {
+    const size_t bytes = plan_tail(dec, start, T, J, nullptr, true);
+    if (!bytes || 3 * bytes > 160 * 1024) return false;
+    for (int i = start; i < (int)dec.size(); ++i)
+        if (dec[i].N > 64 * TAIL_WAVES_SHARED || dec[i].K > 64 * TAIL_WAVES_SHARED) return false;
     return true;
 }
 
-static bool tail_shares_cu(const gem_handle* h, const TailArgs& a, int wgs, size_t lds_bytes) {
-    if (const char* f = dev_env("GEM_TAIL_WAVES")) return atoi(f) == TAIL_WAVES_SHARED && a.G == 1;
-    return wgs > h->n_cu && tail_can_share_cu(a, lds_bytes);
+// The carve (and with it the kernel shape, TailArgs::waves) for a launch of `wgs` workgroups; returns the LDS bytes
+size_t plan_tail_for(const gem_handle* h, const std::vector<Layer>& dec, int start, int wgs, TailArgs* out) {
+    bool shared = wgs > h->n_cu && tail_can_share_cu(dec, start, h->T, h->J);
+    if (const char* f = dev_env("GEM_TAIL_WAVES")) shared = atoi(f) == TAIL_WAVES_SHARED && tail_can_share_cu(dec, start, h->T, h->J);
+    return plan_tail(dec, start, h->T, h->J, out, shared);
 }
 
 // Up to how many workgroups the fused tail beats the batched narrow layers + energy kernel (fp32, windows/s, MI355X, round 5):
-//   windows              480     768    1152    1536    2040    2556    3072    4092
-//   4-wave, two per CU  42.9 k  45.5 k  44.9 k  48.0 k  51.4 k  51.4 k  53.2 k  52.0 k
-//   8-wave, one per CU  40.8 k                  45.1 k                          48.3 k
-//   batched layers      30.7 k  38.5 k  41.6 k  45.8 k  50.4 k  49.8 k  55.6 k  54.7 k
-// (the fused tail costs one workgroup's latency chain per pair of windows and CU whatever the batch; the batched layers amortise)
-int tail_cap_workgroups(const gem_handle* h, const std::vector<Layer>& dec, int start, size_t lds_bytes) {
+//   windows                480     768    1152    1536    2040    2556    3072    4092
+//   4-wave, three per CU  42.5 k  47.9 k          48.5 k          52.1 k  54.3 k  52.7 k
+//   4-wave, two per CU    42.9 k  45.5 k  44.9 k  48.0 k  51.4 k  51.4 k  53.2 k  52.0 k     (16-row LDS buffers, 70 KB)
+//   8-wave, one per CU    40.8 k                  45.1 k                          48.3 k
+//   batched layers        30.7 k  38.5 k  41.6 k  45.8 k  50.4 k  49.8 k  55.6 k  54.7 k
+// (the fused tail costs a CU about 25 us per window whatever the batch -- 1.3 MB of weights from L2 per workgroup, one 16-row MFMA
+// tile with T = 10 rows used; the batched layers amortise their launches and reduce passes)
+int tail_cap_workgroups(const gem_handle* h, const std::vector<Layer>& dec, int start) {
     if (const char* f = dev_env("GEM_TAIL_CAP")) return atoi(f) * h->n_cu;
-    TailArgs a{};
-    if (!plan_tail(dec, start, h->T, h->J, &a)) return 0;
-    for (int i = 0; i < a.n; ++i) { a.fwd[i].N = dec[start + i].N; a.bwd[i].N = dec[start + i].K; }
-    return (tail_can_share_cu(a, lds_bytes) ? 10 : 5) * h->n_cu;
+    return (tail_can_share_cu(dec, start, h->T, h->J) ? 10 : 5) * h->n_cu;
 }
 
 int launch_tail(gem_handle* h, const TailArgs& a, size_t lds_bytes, hipStream_t s) {
@@ -471,7 +494,8 @@ int launch_tail(gem_handle* h, const TailArgs& a, size_t lds_bytes, hipStream_t 
         GEM_HIP(hipEventRecord(rec.a, s));
     }
     const int wgs = (a.B + a.G - 1) / a.G;
-    if (tail_shares_cu(h, a, wgs, lds_bytes) ? launch_tail_w<TAIL_WAVES_SHARED>(h, a, wgs, lds_bytes, s) : launch_tail_w<TAIL_WAVES>(h, a, wgs, lds_bytes, s))
+    if (a.waves != TAIL_WAVES && a.waves != TAIL_WAVES_SHARED) { set_error("launch_tail: the arguments do not come from plan_tail"); return 1; }
+    if (a.waves == TAIL_WAVES_SHARED ? launch_tail_w<TAIL_WAVES_SHARED>(h, a, wgs, lds_bytes, s) : launch_tail_w<TAIL_WAVES>(h, a, wgs, lds_bytes, s))
         return 1;
     GEM_HIP(hipGetLastError());
     if (prof) { GEM_HIP(hipEventRecord(rec.b, s)); h->prof.recs.push_back(rec); }

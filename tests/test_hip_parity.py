@@ -635,7 +635,7 @@ def test_bf16_multi_window_tail_against_the_batched_bf16_layers(torch_cuda, monk
 @pytest.mark.parametrize("net", ["full", "structured"])
 def test_fp32_tail_shapes_compute_the_same(torch_cuda, monkeypatch, net):
     """The fp32 fused tail (csrc/tail.hip) runs a window as one 8-wave workgroup per CU up to 256 windows and as 4-wave workgroups,
-    two per CU, beyond (up to ten per CU; then the batched narrow layers + energy kernel take over).  Both shapes walk K in the same
+    three per CU (LDS buffers of T instead of 16 rows), beyond (up to ten per CU; then the batched narrow layers + energy kernel take over).  Both shapes walk K in the same
     order for every output element and run the same energy arithmetic per element: decoded poses and latent gradients of 600 windows
     are BITWISE the same, the fp64 energies agree to 1e-13 (their partial sums are combined over 4 instead of 8 wavefronts), and a
     whole stage finishes with the same poses.  Against the batched layers: rounding level; against the fp32 oracle: first windows."""
@@ -658,7 +658,7 @@ def test_fp32_tail_shapes_compute_the_same(torch_cuda, monkeypatch, net):
     cam = oracle_camera()
     res = {}
     monkeypatch.setenv("GEM_DEV", "1")
-    for tag, env in (("two_per_cu", {}), ("one_per_cu", {"GEM_TAIL_WAVES": "8"}), ("batched", {"GEM_TAIL_CAP": "0"})):
+    for tag, env in (("shared_cu", {}), ("one_per_cu", {"GEM_TAIL_WAVES": "8"}), ("batched", {"GEM_TAIL_CAP": "0"})):
         for k in ("GEM_TAIL_WAVES", "GEM_TAIL_CAP"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
@@ -674,7 +674,7 @@ def test_fp32_tail_shapes_compute_the_same(torch_cuda, monkeypatch, net):
         torch.cuda.synchronize()
         res[tag] = (E.cpu().numpy(), parts.cpu().numpy(), dz.cpu().numpy(), X.cpu().numpy(), out.cpu().numpy(), stats_to_numpy(stats), names)
         eng.close()
-    a, b, c = res["two_per_cu"], res["one_per_cu"], res["batched"]
+    a, b, c = res["shared_cu"], res["one_per_cu"], res["batched"]
     assert "decoder_tail_kernel<5, 4>" in a[6] and "decoder_tail_kernel<5, 8>" in b[6] and "decoder_tail_kernel" not in c[6], (a[6], b[6], c[6])
     assert np.array_equal(a[3], b[3]) and np.array_equal(a[2], b[2])
     np.testing.assert_allclose(a[0], b[0], rtol=1e-13)
