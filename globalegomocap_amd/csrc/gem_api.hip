@@ -723,7 +723,7 @@ static int stage_begin(StageRun& r) {
     const bool front_ = net_.front.w && net_.tail_start == 1 && h->precision != GEM_PRECISION_BF16;
     const Layer& first_ = front_ ? net_.front : net_.dec_in;
     const int tail_g_ = h->T <= 16 ? 16 / h->T : 1;
-    const bool tail_path_ = net_.tail_start >= 0 && (B + tail_g_ - 1) / tail_g_ <= 5 * h->n_cu;
+    const bool tail_path_ = net_.tail_start >= 0 && (B + tail_g_ - 1) / tail_g_ <= tail_cap_workgroups(h, net_.dec, net_.tail_start);
     r.fuse = w.dyn && tail_path_ && rows_can_fuse_compaction(h, first_, h->Dp, first_.N, B, /*slabs=*/front_);
     return 0;
 }
