@@ -1174,11 +1174,12 @@ def test_fused_compaction_is_bitwise_the_compact_kernel(torch_cuda, tmp_path):
     assert (a["stats_240_0"][:, 3] == 1).all() and a["stats_240_0"][:, 1].mean() > 25
 
 
-@pytest.mark.parametrize("B", [400, 1280])
+@pytest.mark.parametrize("B", [400, 1280, 1536, 2560, 4096])
 def test_batches_between_the_regimes_agree_with_a_small_batch(torch_cuda, B):
-    """400..1280 windows in fp32: too many rows for the few-rows GEMM, still few enough workgroups for the fused tail -- the
-    composed front layer runs in the tiled kernels, its slabs go to the tail, compact_kernel re-packs the windows.  The first 40
-    windows must come out as they do in a 40-window batch: same evaluation counts, energies to 1e-5, poses to 0.01 mm."""
+    """400..2560 windows in fp32: too many rows for the few-rows GEMM, still few enough workgroups for the fused tail (its 4-wave
+    shape, three workgroups per CU) -- the composed front layer runs in the tiled kernels, its slabs go to the tail, compact_kernel
+    re-packs the windows; 4096 windows: the batched narrow layers + the stand-alone energy kernel.  The first 40 windows must come
+    out as they do in a 40-window batch (the 8-wave tail): same evaluation counts, energies to 1e-5, poses to 0.01 mm."""
     from globalegomocap_amd.engine import stats_to_numpy
     sd = vae_schema.synthetic_state_dict(FULL, 5)
     seq = synth.make_sequence(n_frames=200, seed=36)
