@@ -468,6 +468,54 @@ def test_fused_tail_with_windows_longer_than_its_thread_count(torch_cuda, monkey
     assert np.abs(dz - res["batched"][2]).max() <= 1e-4 * np.abs(dz).max()
 
 
+@pytest.mark.parametrize("T", [9, 12, 16])
+def test_fp32_tail_shared_shape_with_other_window_lengths(torch_cuda, monkeypatch, T):
+    """The 4-wave shape of the fused fp32 tail carves its LDS buffers for the window's T rows (9 .. 16 rows: one window per
+    workgroup) instead of 16: 300 windows of T frames (more workgroups than CUs) against the 8-wave shape -- bitwise poses and
+    gradients, energies to 1e-13 -- and against the oracle on the first windows.  T >= 12: the energy inputs are not parked in LDS."""
+    torch = torch_cuda
+    shape = vae_schema.VAEShape(latent_dim=32, seq_len=T, hidden=(16, 16, 32, 32, 64))
+    sd = vae_schema.synthetic_state_dict(shape, 13)
+    vae = O.fold_vae(sd, seq_len=T)
+    cam = oracle_camera()
+    B = 300
+    seq = synth.make_sequence(n_frames=120, seed=43)
+    est = np.asarray(seq["estimated_local_skeleton"], dtype=np.float32)
+    heat = np.asarray(seq["heatmap_list"], dtype=np.float32)
+    rng = np.random.default_rng(7)
+    starts = rng.integers(0, 120 - T, B).astype(np.int32)
+    pose = np.stack([est[s:s + T] for s in starts])
+    mu, _ = O.encode(vae, pose[:8].reshape(8, T, 45))
+    z = (np.tile(mu, (B // 8 + 1, 1))[:B] + 0.1 * rng.normal(size=(B, shape.latent_dim))).astype(np.float32)
+    mb = O.mean_bone_length(est)
+    res = {}
+    monkeypatch.setenv("GEM_DEV", "1")
+    for tag, waves in (("shared", None), ("one_per_cu", "8")):
+        if waves:
+            monkeypatch.setenv("GEM_TAIL_WAVES", waves)
+        else:
+            monkeypatch.delenv("GEM_TAIL_WAVES", raising=False)
+        eng = _engine(shape, max_windows=B)
+        eng.load_vae(0, sd)
+        eng.profile_enable(True)
+        E, parts, dz, X = eng.energy_grad(0, z, pose, mb, _ew(W_ALL), heat, starts)
+        torch.cuda.synchronize()
+        names = eng.profile_kernels(1)
+        res[tag] = (E.cpu().numpy(), parts.cpu().numpy(), dz.cpu().numpy(), X.cpu().numpy(), names)
+        eng.close()
+    a, b = res["shared"], res["one_per_cu"]
+    assert ", 4>" in a[4] and ", 8>" in b[4], (a[4], b[4])
+    assert np.array_equal(a[3], b[3]) and np.array_equal(a[2], b[2])
+    np.testing.assert_allclose(a[0], b[0], rtol=1e-13)
+    for k in range(2):
+        Xo, acts = O.decode(vae, z[k:k + 1], keep=True)
+        f, p, dX = O.energy_and_grad(Xo[0], pose[k], mb, O.Weights(*W_ALL), cam, heat[starts[k]:starts[k] + T])
+        dzo = O.decode_backward(vae, dX[None], acts)[0]
+        np.testing.assert_allclose(a[3][k], Xo[0], rtol=2e-4, atol=2e-5)
+        assert abs(a[0][k] - f) <= 2e-4 * abs(f) + 1e-7, (k, a[0][k], f)
+        assert np.abs(a[2][k] - dzo).max() <= 2e-3 * np.abs(dzo).max() + 1e-8
+
+
 def test_graph_cache_is_dropped_when_the_weights_are_reloaded(torch_cuda):
     """A captured call bakes the weight pointers into its kernel arguments: gem_load_vae on a loaded stage frees and re-allocates
     them, so it must drop the graph cache (else the next identical call replays kernels on freed / stale weights).  Graphs on,
