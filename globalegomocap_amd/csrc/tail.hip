@@ -140,23 +140,33 @@ __device__ __forceinline__ void tail_gemm_nt(const float* in, int ld_in, const f
         for (int g = 0; g < 4; ++g) b0[0][g] = bpre[g];       // tile 0 / block 0 was prefetched by the previous layer
     }
     TAIL_LOAD_A(0, a0);
-    // Branch-free pair loop (a conditional prefetch makes hipcc fall back to vmcnt(0) at the join) with
-    // sched_barriers (otherwise both prefetches are hoisted to the loop top and waited for together).
+    // Branch-free pair loop (a conditional prefetch makes hipcc fall back to vmcnt(0) at the join); a sched_barrier between the
+    // halves (otherwise both prefetches are hoisted to the loop top and waited for together), and inside a half the loads of the
+    // next block are dealt out between the MFMAs of the current one (sched_group_barrier): a wave issues them in the shadow of its
+    // own matrix instructions instead of in front of them -- with one wave per SIMD and workgroup (the 4-wave shape) nothing else
+    // would feed the pipe meanwhile (1536 windows fp32: 49.4 k against 48.0 k windows/s; no difference for the 8-wave shape).
     const int npairs = nblk / 2;
+    // one block = 16 NT MFMAs, 4 NT global loads (B of the next block), 4 LDS reads (A of the next block)
+#define TAIL_INTERLEAVE()                                                                                          \
+    {                                                                                                              \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4 * NT; ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); } \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 2 * NT, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); } \
+    }
     for (int p = 0; p < npairs; ++p) {
         const int blk = 2 * p;
         TAIL_LOAD_B(blk + 1, b1);
         TAIL_LOAD_A(blk + 1, a1);
-        __builtin_amdgcn_sched_barrier(0);
         TAIL_COMPUTE(a0, b0);
+        TAIL_INTERLEAVE();
         __builtin_amdgcn_sched_barrier(0);
         const int nxt = min(blk + 2, nblk - 1);            // last pair: harmless re-load of the final block
         TAIL_LOAD_B(nxt, b0);
         TAIL_LOAD_A(nxt, a0);
-        __builtin_amdgcn_sched_barrier(0);
         TAIL_COMPUTE(a1, b1);
+        TAIL_INTERLEAVE();
         __builtin_amdgcn_sched_barrier(0);
     }
+#undef TAIL_INTERLEAVE
     if (nblk & 1) TAIL_COMPUTE(a0, b0);
     if (has_next) tail_prefetch_first<W>(next, bpre);
 #undef TAIL_LOAD_A
