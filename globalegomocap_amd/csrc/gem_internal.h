@@ -141,7 +141,7 @@ struct Workspace {
     int* perm = nullptr;                // [B] slot -> window
     int* slot_of = nullptr;             // [B] window -> slot
     int* n_active = nullptr;            // [2] = {n_active, n_active*T}
-    // Slots handed out by lbfgs_advance itself (bf16 decoder mode with the fused tail, up to ATOMIC_COMPACT_MAX windows): a window
+    // Slots handed out by lbfgs_advance itself (bf16 decoder mode with the fused tail): a window
     // that keeps iterating takes the next free slot of the coming round with one atomic add, so the rounds need no compact_kernel
     // launch.  Two (perm, slot_of) buffer pairs alternate by round; a round's count lives in its n_log entry (zeroed at stage begin).
     // `perm`, `slot_of`, `n_active` above always point at the CURRENT round's set; *_home are the allocations they return to.
@@ -325,7 +325,6 @@ __device__ inline void slab_layout(const SlabSrc& s, int& nslab, size_t& stride)
     }
 }
 bool rows_can_fuse_compaction(const gem_handle* h, const Layer& L, int lda, int ldc, int B, bool slabs);
-constexpr int ATOMIC_COMPACT_MAX = 4096;      // beyond: compact_kernel's stable scan (~4 us of a ~440 us round; B same-address atomics would not be free)
 bool bf16_rounds_take_slots_atomically(const gem_handle* h, int stage, int B);      // decoder_bf16.hip: fused bf16 tail right behind the composed front layer
 int launch_splitk_reduce(gem_handle* h, int epi, int nslab, size_t slab, const float* bias, const float* aux, float* C, int M, int N,
                          int ldc, const int* m_dev, hipStream_t s, int dyn_W = 0, int n_tiles = 0);
