@@ -57,6 +57,7 @@ def parse():
     p.add_argument("--no-partition", action="store_true", help="skip the full-size 8-way partitions of configs[3] / configs[4] (`partition8`)")
     p.add_argument("--full-record", default=None, help="also write the whole JSON line, indented, to this file")
     p.add_argument("--no-graphs", action="store_true", help="configs4: eager launches instead of hipGraph replay (diagnosis)")
+    p.add_argument("--graphs", action="store_true", help="configs3: hipGraph replay as well (configs4 has it by default)")
     p.add_argument("--verbose", action="store_true", help="progress lines on stderr (sharded legs)")
     p.add_argument("--no-profile", action="store_true", help="no HIP-event timing of the dominant kernel")
     p.add_argument("--precision", default=None, choices=["f32", "bf16x3", "bf16"],
@@ -282,7 +283,7 @@ def run_sharded(a, world, rank, device, rehearsal, sd_local, sd_global, vae_note
     eng.set_precision(a.precision)
     if a.lanes is not None:
         eng.set_lanes(a.lanes)
-    eng.enable_graphs(stream and not getattr(a, "no_graphs", False))
+    eng.enable_graphs((stream or getattr(a, "graphs", False)) and not getattr(a, "no_graphs", False))
 
     def say(*msg):
         if getattr(a, "verbose", False):
