@@ -589,6 +589,7 @@ static int evaluate(gem_handle* h, int stage, int B, const float* zp, const Ener
     const int tail_wgs = (B + tail_g - 1) / tail_g;
     const int tail_cap = net.tail_start >= 0 ? tail_cap_workgroups(h, net.dec, net.tail_start) : 0;
     if (net.tail_start < 0 || (tail_wgs > tail_cap && !force_tail)) {
+        if (w.next_count) { set_error("evaluate: the batched layers need compact_kernel's slot order (stage_begin chose otherwise)"); return 1; }
         if (decoder_forward(h, stage, B, zp, s)) return 1;
         if (forward_only) return 0;
         if (launch_energy(h, ea, B, s) || record_mid(h, s)) return 1;
@@ -597,6 +598,7 @@ static int evaluate(gem_handle* h, int stage, int B, const float* zp, const Ener
     // wide layers as batched GEMMs, the narrow tail + energy + its adjoints in one kernel
     const int st = net.tail_start, rows = B * h->T;
     const bool front = net.front.w && st == 1 && h->precision != GEM_PRECISION_BF16;      // (the bf16 decoder mode has its own evaluate)
+    if (w.next_count && !front) { set_error("evaluate: slots handed out by lbfgs_advance need the composed front layer"); return 1; }
     const float* in = w.h0;
     SlabSrc in_slab;
     if (front) {
@@ -694,8 +696,19 @@ static int stage_begin(StageRun& r) {
     static const bool no_compact = dev_env("GEM_NO_COMPACT") != nullptr;
     compaction_home(w);
     r.atomic_slots = false;
+    // The active windows are re-packed between the rounds: inside the decoder_input forward launch of the next round (one sequence in
+    // fp32: gemm_rows.h, FUSE), by lbfgs_advance handing out the next round's slots itself (atomic_slots: every path whose kernels
+    // address rows through perm / slot_of only and do not depend on the slot ORDER -- the bf16 fused path, and the fp32 composed front
+    // layer + fused tail beyond one sequence), else by compact_kernel.
+    StageNet& net_ = h->net[stage];
+    const bool front_ = net_.front.w && net_.tail_start == 1 && h->precision != GEM_PRECISION_BF16;
+    const Layer& first_ = front_ ? net_.front : net_.dec_in;
+    const int tail_g_ = h->T <= 16 ? 16 / h->T : 1;
+    const bool tail_path_ = net_.tail_start >= 0 && (B + tail_g_ - 1) / tail_g_ <= tail_cap_workgroups(h, net_.dec, net_.tail_start);
+    const bool fuse_ = !no_compact && tail_path_ && rows_can_fuse_compaction(h, first_, h->Dp, first_.N, B, /*slabs=*/front_);
     if (!no_compact) {
-        r.atomic_slots = bf16_rounds_take_slots_atomically(h, stage, B);
+        r.atomic_slots = bf16_rounds_take_slots_atomically(h, stage, B) ||
+                         (h->precision == GEM_PRECISION_F32 && front_ && tail_path_ && !fuse_ && !dev_env("GEM_NO_ATOMIC_COMPACT"));
         if (r.atomic_slots) {
             // rounds + 2 consecutive n_log entries: round 0's count (written by the compaction below), then one zeroed counter per round
             if ((w.log_pos % N_LOG) + r.rounds + 2 > N_LOG) w.log_pos += N_LOG - (w.log_pos % N_LOG);
@@ -717,14 +730,7 @@ static int stage_begin(StageRun& r) {
     w.tex_on = false;
     // closure values of this stage, one row per round (0xFF bytes = NaN: "window took no evaluation in this round")
     if (launch_fill_u32(reinterpret_cast<uint32_t*>(w.trace), 0xFFFFFFFFu, (size_t)TRACE_ROUNDS * w.Bmax * 2, s)) return 1;
-    // The active windows are re-packed between the rounds: by compact_kernel, or -- one sequence in fp32 -- inside the
-    // decoder_input forward launch of the next round (gemm_rows.h; one launch and its boundary less per round).
-    StageNet& net_ = h->net[stage];
-    const bool front_ = net_.front.w && net_.tail_start == 1 && h->precision != GEM_PRECISION_BF16;
-    const Layer& first_ = front_ ? net_.front : net_.dec_in;
-    const int tail_g_ = h->T <= 16 ? 16 / h->T : 1;
-    const bool tail_path_ = net_.tail_start >= 0 && (B + tail_g_ - 1) / tail_g_ <= tail_cap_workgroups(h, net_.dec, net_.tail_start);
-    r.fuse = w.dyn && tail_path_ && rows_can_fuse_compaction(h, first_, h->Dp, first_.N, B, /*slabs=*/front_);
+    r.fuse = w.dyn && fuse_;
     return 0;
 }
 
