@@ -163,6 +163,148 @@ def peek_frames(path):
     return None if side is None else side[0][0]
 
 
+_SKIP_MIN = 128 * 1024            # bytes: payloads at least this long are not copied while un-pickling (pickle frames stay below it)
+
+
+class _SkippingReader:
+    """File object for `pickle.Unpickler` that SKIPS the large byte payloads (the raw data of the heat-map arrays): a skipped
+    `readinto` costs no copy -- the buffer the unpickler allocated is only tagged with the payload's index, the position moves
+    on -- and the payload's file offset is recorded.  The chunk's 100 heat-maps (24.6 MB) then never pass through Python objects:
+    the reader thread brings the FILE as it is into pinned memory (one read, outside the GIL) and on to the device, where one
+    strided copy picks the arrays out (`_stage_file_to_device`), instead of 100 bytes objects built under the GIL (1.5-3 ms per
+    chunk whatever the number of reader threads).  Everything else (opcodes, frames, small arrays) is read by the memory map's
+    own C methods, handed to the unpickler as they are: no Python frame per opcode and -- unlike a buffered file -- no system
+    call, so a reader thread keeps the GIL for the ~0.5 ms it parses a chunk instead of handing it over at every read.  No
+    `peek`, so the unpickler asks for exactly the bytes it needs and a payload always arrives as ONE request."""
+
+    def __init__(self, mm):
+        self._mm, self.segments = mm, []
+        self.read, self.readline = mm.read, mm.readline        # (bound C methods)
+        self._size = len(mm)
+
+    def readinto(self, b):
+        n = len(b)
+        mm = self._mm
+        if n < _SKIP_MIN:
+            data = mm.read(n)
+            b[:len(data)] = data
+            return len(data)
+        p = mm.tell()
+        if p + n > self._size:
+            return 0                                           # truncated file: the unpickler raises, the caller falls back
+        mm.seek(n, 1)
+        self.segments.append((p, n))
+        b[:8] = _TAG.pack(len(self.segments) - 1)
+        return n
+
+
+_TAG = __import__("struct").Struct("<q")
+
+
+def _load_pickle_skipping(path):
+    """(dict of the small arrays, heat shape, [file offsets of the heat-maps], opened file) or None when the pickle is not of the
+    expected form (then the caller un-pickles it the plain way): every heat-map must be a C-contiguous float32 array of one
+    shape whose data the reader skipped."""
+    import mmap
+    f = open(os.path.join(path, "test_data.pkl"), "rb", buffering=0)
+    try:
+        mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
+    except (ValueError, OSError):
+        f.close()
+        return None
+    rd = _SkippingReader(mm)
+    try:
+        d = pickle.Unpickler(rd).load()
+        heat = d["heatmap_list"] if isinstance(d, dict) else None
+        if not isinstance(heat, (list, tuple)) or not heat or not rd.segments:
+            return None
+        shp, offs, seen = None, [], set()
+        for a in heat:
+            if not isinstance(a, np.ndarray) or a.dtype != np.float32 or not a.flags.c_contiguous or a.nbytes < _SKIP_MIN:
+                return None
+            k = _TAG.unpack(a.reshape(-1)[:2].tobytes())[0]
+            if not (0 <= k < len(rd.segments)) or rd.segments[k][1] != a.nbytes or k in seen:
+                return None
+            if shp is None:
+                shp = a.shape
+            elif a.shape != shp:
+                return None
+            seen.add(k)
+            offs.append(rd.segments[k][0])
+        if len(seen) != len(rd.segments):               # some other large object lost its bytes: not a pickle for this path
+            return None
+        small = {k: v for k, v in d.items() if k != "heatmap_list"}
+        ok = (f, (len(heat),) + tuple(shp), offs, small)
+        f = None
+        return ok
+    except (pickle.UnpicklingError, EOFError, ValueError, TypeError, IndexError, AttributeError, ImportError, KeyError):
+        return None
+    finally:
+        rd.read = rd.readline = rd._mm = None                   # (the bound methods keep the map exported)
+        try:
+            mm.close()
+        except (BufferError, ValueError):
+            pass
+        if f is not None:
+            f.close()
+
+
+def _stage_file_to_device(f, shape, offs, device, dest=None):
+    """The heat-maps of a chunk whose pickle holds them as `shape[0]` byte payloads of one length at the file offsets `offs`:
+    the whole file -> this reader thread's pinned staging buffer (one read, outside the GIL) -> the device (one async copy on the
+    thread's stream), then one strided byte copy on the device gathers the payloads -- equally spaced, as a pickler writes a list
+    of equal arrays -- into `dest` (or a fresh tensor).  Payloads that are not equally spaced are scattered on the host instead
+    (one os.preadv into the float staging buffer).  Returns (device tensor, event)."""
+    n, nb = shape[0], int(np.prod(shape[1:])) * 4
+    stride = offs[1] - offs[0] if n > 1 else nb
+    if n > 1 and (stride < nb or any(offs[i + 1] - offs[i] != stride for i in range(n - 1))):
+        fd = f.fileno()
+
+        def fill(view):
+            iov, want, scrap = [], 0, bytearray(65536)
+            for i, o in enumerate(offs):
+                gap = o - (offs[i - 1] + nb) if i else 0
+                if gap < 0 or gap > len(scrap) or len(iov) > 1000:
+                    iov = None
+                    break
+                if gap:
+                    iov.append(memoryview(scrap)[:gap])
+                iov.append(memoryview(view[i]).cast("B"))
+                want += gap + nb
+            if iov is not None and os.preadv(fd, iov, offs[0]) == want:
+                return
+            for i, o in enumerate(offs):
+                if os.preadv(fd, [memoryview(view[i]).cast("B")], o) != nb:
+                    raise IOError("short read of %s" % f.name)
+        return _stage_to_device(fill, shape, device, dest)
+    tl = _reader_local
+    if getattr(tl, "stream", None) is None or tl.device != device:
+        tl.stream, tl.device, tl.stage, tl.copied, tl.turn = torch.cuda.Stream(device=device), device, [None, None], [None, None], 0
+    if getattr(tl, "fstage", None) is None or tl.fdevice != device:
+        tl.fstage, tl.fimg, tl.fdevice = [None, None], [None, None], device
+    first, span = offs[0], stride * (n - 1) + nb                  # the byte range of the file that holds the payloads
+    k = tl.turn
+    tl.turn ^= 1
+    if tl.fstage[k] is None or tl.fstage[k].numel() < span:
+        tl.fstage[k] = torch.empty(span + (1 << 20), dtype=torch.uint8).pin_memory()
+        tl.fimg[k] = torch.empty(span + (1 << 20), dtype=torch.uint8, device=device)
+    if tl.copied[k] is not None:
+        tl.copied[k].synchronize()                     # the copy that last used this staging buffer has left it
+    host = tl.fstage[k][:span]
+    if os.preadv(f.fileno(), [memoryview(host.numpy())], first) != span:
+        raise IOError("short read of %s" % f.name)
+    with torch.cuda.stream(tl.stream):
+        img = tl.fimg[k][:span]
+        img.copy_(host, non_blocking=True)
+        t = dest if (dest is not None and tuple(dest.shape) == tuple(shape) and dest.is_contiguous()) else \
+            torch.empty(shape, dtype=torch.float32, device=device)
+        t.view(torch.uint8).view(n, nb).copy_(img.as_strided((n, nb), (stride, 1)))
+        ev = torch.cuda.Event()
+        ev.record(tl.stream)
+    tl.copied[k] = ev
+    return t, ev
+
+
 def load_chunk(path, device=None, sidecar=False, dest=None):
     """`<chunk>/test_data.pkl` (optimizer.py:315-324) as dense arrays; KeyError on a missing key like the reference.
     With `device`, the heat-maps (99 % of the bytes) go straight to that device from the calling thread.
@@ -188,6 +330,18 @@ def load_chunk(path, device=None, sidecar=False, dest=None):
                 fill(c["heat"])
         else:
             c["heat"], c["heat_ready"] = _stage_to_device(fill, shape, device, dest)
+        return c
+    fast = _load_pickle_skipping(path) if (device is not None and not sidecar) else None
+    if fast is not None:
+        f, shape, offs, small = fast
+        try:
+            c = {"path": path,
+                 "est_local": np.asarray(small["estimated_local_skeleton"], dtype=np.float64),
+                 "gt": np.asarray(small["gt_global_skeleton"], dtype=np.float64),
+                 "cams": np.asarray(small["camera_pose_list"], dtype=np.float64)}
+            c["heat"], c["heat_ready"] = _stage_file_to_device(f, shape, offs, device, dest)
+        finally:
+            f.close()
         return c
     with open(os.path.join(path, "test_data.pkl"), "rb") as f:
         d = pickle.load(f)

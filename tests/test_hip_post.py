@@ -402,3 +402,54 @@ def test_integration_md_reporting_stub_runs_verbatim(engine, golden):
             tol = dict(rtol=1e-5, atol=1e-7) if "mid" in k else dict(rtol=1e-9, atol=1e-12)
             np.testing.assert_allclose(rep[i], g["err_%s/%s" % (tag, k)], err_msg=k, **tol)
         np.testing.assert_allclose(rep[17:], g["err_%s/joints_error" % tag], rtol=1e-9, atol=1e-12)
+
+
+def test_chunk_pickles_reach_the_device_without_passing_through_python_objects(tmp_path, monkeypatch):
+    """load_chunk(path, device): the pickle is parsed with the heat-maps' payloads skipped, the FILE goes to pinned memory in one read and
+    on to the device, where one strided copy picks the 100 arrays out (protocol 4: equally spaced payloads); a protocol-3 pickle
+    (memo indices in the opcodes: the spacing changes along the list) is scattered on the host with one os.preadv instead; float64
+    heat-maps take the plain un-pickling path.  Every path must deliver exactly what pickle.load delivers."""
+    import pickle
+    import torch
+    from globalegomocap_amd import whole_sequence as ws
+    rng = np.random.default_rng(3)
+    heat = rng.random((100, 64, 64, 15), dtype=np.float32)
+    small = {"estimated_local_skeleton": list(rng.random((100, 15, 3))), "gt_global_skeleton": list(rng.random((100, 15, 3))),
+             "camera_pose_list": list(rng.random((100, 4, 4)))}
+    calls = {"file": 0, "host": 0}
+    orig_file, orig_host = ws._stage_file_to_device, ws._stage_to_device
+
+    def count_file(*a, **k):
+        calls["file"] += 1
+        return orig_file(*a, **k)
+
+    def count_host(*a, **k):
+        calls["host"] += 1
+        return orig_host(*a, **k)
+    monkeypatch.setattr(ws, "_stage_file_to_device", count_file)
+    monkeypatch.setattr(ws, "_stage_to_device", count_host)
+    dev = torch.device("cuda:0")
+    expect = {4: (1, 0), 3: (1, 1), "f64": (0, 1)}
+    for case, (n_file, n_host) in expect.items():
+        d = tmp_path / ("c_%s" % case)
+        d.mkdir()
+        hl = [h.astype(np.float64) for h in heat] if case == "f64" else list(heat)
+        # (protocol 3 with the heat-maps FIRST: the memo indices written behind every array pass 255 inside the list, the opcodes
+        # that carry them grow, and the payloads' spacing changes from 245803 to 245821 bytes)
+        obj = dict(heatmap_list=hl, **small) if case == 3 else dict(small, heatmap_list=hl)
+        with open(d / "test_data.pkl", "wb") as f:
+            pickle.dump(obj, f, protocol=4 if case == "f64" else case)
+        calls["file"] = calls["host"] = 0
+        dest = torch.full((100, 64, 64, 15), -1.0, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()                       # (the reader copies on its own stream)
+        c = ws.load_chunk(str(d), device=dev, dest=dest)
+        c["heat_ready"].synchronize()
+        assert (calls["file"], calls["host"]) == (n_file, n_host), (case, calls)
+        assert c["heat"].data_ptr() == dest.data_ptr()
+        assert np.array_equal(c["heat"].cpu().numpy(), heat), case
+        for k, name in (("est_local", "estimated_local_skeleton"), ("gt", "gt_global_skeleton"), ("cams", "camera_pose_list")):
+            assert np.array_equal(c[k], np.asarray(small[name])), (case, k)
+        # a second chunk through the same reader thread's buffers
+        c2 = ws.load_chunk(str(d), device=dev)
+        c2["heat_ready"].synchronize()
+        assert np.array_equal(c2["heat"].cpu().numpy(), heat), case

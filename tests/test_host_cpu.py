@@ -203,6 +203,55 @@ def test_chunk_listing_and_background_reader(tmp_path):
         list(ws.ChunkStream(ws.list_chunks(str(tmp_path))))
 
 
+def test_pickle_reader_that_skips_the_heat_map_payloads(tmp_path):
+    """whole_sequence._load_pickle_skipping un-pickles a chunk WITHOUT copying the heat-maps' raw data (the unpickler's large reads are
+    answered with a tag, their file offsets recorded) so that the reader threads can bring them from the page cache into pinned memory
+    with os.preadv, outside the GIL.  What it returns must be exactly what pickle.load returns, for every pickle protocol that stores
+    the arrays as byte strings; anything else (protocol 2's latin-1 strings, float64 or ragged heat-maps, a list of lists) makes it
+    decline, and load_chunk falls back to the plain path."""
+    import pickle
+    from globalegomocap_amd import whole_sequence as ws
+    data = synth.make_sequence(n_frames=30, seed=5)
+    keys = ("estimated_local_skeleton", "gt_global_skeleton", "camera_pose_list", "heatmap_list")
+    ref = np.asarray(data["heatmap_list"], dtype=np.float32)
+    d = tmp_path / "c"
+    d.mkdir()
+    for proto in (3, 4, 5):
+        with open(d / "test_data.pkl", "wb") as f:
+            pickle.dump({k: data[k] for k in keys}, f, protocol=proto)
+        got = ws._load_pickle_skipping(str(d))
+        assert got is not None, proto
+        f, shape, offs, small = got
+        try:
+            assert shape == ref.shape and len(offs) == 30 and set(small) == set(keys) - {"heatmap_list"}
+            heat = np.empty(shape, dtype=np.float32)
+            for i, o in enumerate(offs):
+                assert os.preadv(f.fileno(), [memoryview(heat[i]).cast("B")], o) == heat[i].nbytes
+        finally:
+            f.close()
+        assert np.array_equal(heat, ref), proto
+        for k in small:
+            assert np.array_equal(np.asarray(small[k]), np.asarray(data[k])), (proto, k)
+
+    def declines(obj, proto=4):
+        with open(d / "test_data.pkl", "wb") as f:
+            pickle.dump(obj, f, protocol=proto)
+        return ws._load_pickle_skipping(str(d)) is None
+    base = {k: data[k] for k in keys}
+    assert declines(base, proto=2)                                                            # raw data as latin-1 text
+    assert declines(dict(base, heatmap_list=[h.astype(np.float64) for h in data["heatmap_list"]]))
+    assert declines(dict(base, heatmap_list=np.asarray(data["heatmap_list"], dtype=np.float32)))      # ONE array: not a list
+    assert declines(dict(base, heatmap_list=[h.tolist() for h in data["heatmap_list"][:2]]))
+    assert declines(dict(base, heatmap_list=list(data["heatmap_list"][:-1]) + [np.zeros((64, 64, 16), np.float32)]))
+    assert declines(dict(base, extra=np.zeros(100000, np.float32)))                            # another large object lost its bytes
+    assert declines({"estimated_local_skeleton": []})
+    # whatever it declines, load_chunk still reads the plain way
+    with open(d / "test_data.pkl", "wb") as f:
+        pickle.dump(base, f, protocol=2)
+    c = ws.load_chunk(str(d))
+    assert np.array_equal(c["heat"], ref)
+
+
 def test_slam_trajectory_conversion_against_reference_golden(golden):
     """MakeDataForOptimization/slam_reader.py: frame selection, relative poses, scaled translation (golden from the
     reference's read_trajectory) and the Umeyama scale of read_trajectory_new on a trajectory with a known scale."""
