@@ -43,6 +43,15 @@ class GemTrainOpts(C.Structure):
                 ("kld_weight", C.c_double), ("bn_momentum", C.c_double), ("recon_sum", C.c_int32), ("reserved", C.c_int32)]
 
 
+class GemPickleArray(C.Structure):
+    _fields_ = [("offset", C.c_int64), ("nbytes", C.c_int64), ("dtype", C.c_int32), ("ndim", C.c_int32), ("fortran", C.c_int32),
+                ("key", C.c_int32), ("shape", C.c_int64 * 4)]
+
+
+DT_F32, DT_F64 = 0, 1
+PICKLE_UNSUPPORTED = 2
+
+
 class GemWindowStats(C.Structure):
     _fields_ = [("n_iter", C.c_int32), ("func_evals", C.c_int32), ("final_loss", C.c_float), ("status", C.c_int32)]
 
@@ -70,8 +79,20 @@ SIGNATURES = {
     "gem_read_trace": (C.c_int, [_P, C.c_int, C.c_int, _P, _P]),
     "gem_merge_windows": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "gem_calculate_errors": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.POINTER(C.c_double), _P, _P]),
+    "gem_calculate_errors_chunks": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.POINTER(C.c_double), _P, _P]),
     "gem_lift_skeleton": (C.c_int, [_P, _P, _P, C.c_int, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "gem_set_lanes": (C.c_int, [_P, C.c_int]),
+    "gem_pickle_scan": (C.c_int, [_P, C.c_int64, C.POINTER(C.c_char_p), C.c_int, C.POINTER(GemPickleArray), C.c_int64, C.POINTER(C.c_int64)]),
+    "gem_pickle_gather_f64": (C.c_int, [_P, C.c_int64, C.POINTER(GemPickleArray), C.c_int64, _P]),
+    "gem_heat_gather": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "gem_chunk_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.POINTER(_P)]),
+    "gem_chunk_close": (None, [_P]),
+    "gem_chunk_bytes": (C.c_int64, [_P]),
+    "gem_chunk_count": (C.c_int64, [_P, C.c_int]),
+    "gem_chunk_info": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int64)]),
+    "gem_chunk_offsets": (C.c_int, [_P, C.c_int, _P, C.c_int64]),
+    "gem_chunk_gather_f64": (C.c_int, [_P, C.c_int, _P, C.c_int64]),
+    "gem_file_stage": (C.c_int, [C.c_char_p, C.c_int, _P, _P, C.c_int64, C.c_int64, C.POINTER(C.c_int64), _P]),
     "gem_profile_enable": (C.c_int, [_P, C.c_int]),
     "gem_profile_read": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "gem_profile_kernels": (C.c_int, [_P, C.c_int, C.c_char_p, C.c_int]),

@@ -115,7 +115,16 @@ struct ErrArgs {
     int F, J;
     int parents[MAXJ_ERR];
     double bone_mm[MAXJ_ERR];
+    // blockIdx.y = the sequence of a batch of equally long ones laid end to end: strides of src / gt, frame_out and out between them
+    size_t seq_stride, frame_stride, out_stride;
 };
+
+__device__ inline void errors_select_sequence(ErrArgs& a, int c) {
+    for (int s = 0; s < 3; ++s) a.src[s] += c * a.seq_stride;
+    a.gt += c * a.seq_stride;
+    a.frame_out += c * a.frame_stride;
+    a.out += c * a.out_stride;
+}
 
 #define LD3(buf, j, d) buf[((j) * 3 + (d)) * ERR_FT + tx]
 
@@ -156,6 +165,7 @@ __device__ inline void resize_skeleton(double* X, double* W, const ErrArgs& a, i
 
 __global__ __launch_bounds__(ERR_FT) void errors_frame_kernel(ErrArgs a) {
     extern __shared__ double lds_d[];
+    errors_select_sequence(a, blockIdx.y);
     // six independent tasks per frame: (source s = est / mid / opt) x (plain + Procrustes | bone-length normalised)
     const int tx = threadIdx.x, J = a.J;
     const long task = (long)blockIdx.x * ERR_FT + tx;
@@ -236,6 +246,7 @@ __global__ __launch_bounds__(ERR_ST) void errors_sequence_kernel(ErrArgs a) {
     __shared__ double red[2 * 16 * ERR_NW];
     __shared__ Sim3 sim_s;
     int parity = 0;
+    errors_select_sequence(a, blockIdx.y);
     const int tid = threadIdx.x, J = a.J, F = a.F, s = blockIdx.x;
     const size_t N = (size_t)F * J;
     double* out = a.out;
@@ -299,10 +310,11 @@ __global__ __launch_bounds__(ERR_ST) void errors_sequence_kernel(ErrArgs a) {
 size_t errors_frame_lds_bytes(int J) { return (size_t)3 * J * 3 * ERR_FT * sizeof(double); }
 
 int launch_errors(gem_handle* h, const double* est, const double* mid, const double* opt, const double* gt, int F,
-                  const double* bone_mm, double* frame_out, double* out, hipStream_t s) {
+                  const double* bone_mm, double* frame_out, double* out, hipStream_t s, int n_seq) {
     ErrArgs a;
     a.src[0] = est; a.src[1] = mid; a.src[2] = opt; a.gt = gt;
     a.frame_out = frame_out; a.out = out; a.F = F; a.J = h->J;
+    a.seq_stride = (size_t)F * h->J * 3; a.frame_stride = (size_t)(11 + MAXJ_ERR) * F; a.out_stride = 17 + h->J;
     for (int j = 0; j < MAXJ_ERR; ++j) {
         a.parents[j] = j < h->J ? h->cfg.parents[j] : 0;
         a.bone_mm[j] = j < h->J ? bone_mm[j] : 0.0;
@@ -313,9 +325,9 @@ int launch_errors(gem_handle* h, const double* est, const double* mid, const dou
         GEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(errors_frame_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)errors_frame_lds_bytes(MAXJ_ERR)));
     }
-    hipLaunchKernelGGL(errors_frame_kernel, dim3((unsigned)(((long)F * 6 + ERR_FT - 1) / ERR_FT)), dim3(ERR_FT), lds, s, a);
+    hipLaunchKernelGGL(errors_frame_kernel, dim3((unsigned)(((long)F * 6 + ERR_FT - 1) / ERR_FT), (unsigned)n_seq), dim3(ERR_FT), lds, s, a);
     GEM_HIP(hipGetLastError());
-    hipLaunchKernelGGL(errors_sequence_kernel, dim3(3), dim3(ERR_ST), 0, s, a);
+    hipLaunchKernelGGL(errors_sequence_kernel, dim3(3, (unsigned)n_seq), dim3(ERR_ST), 0, s, a);
     GEM_HIP(hipGetLastError());
     return 0;
 }

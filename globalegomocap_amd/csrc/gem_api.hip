@@ -685,6 +685,8 @@ static int stage_begin(StageRun& r) {
     if (r.opt.max_iter < 1 || r.opt.max_eval < 1 || r.opt.max_iter - 1 > w.hist_cap || r.opt.max_iter > MAX_HIST) {
         set_error("optimize: max_iter must be 1.." + std::to_string(w.hist_cap + 1)); return 1;
     }
+    // (the per-round counters of a stage are zeroed by one 1024-thread workgroup, and the trace keeps TRACE_ROUNDS rounds)
+    if (r.opt.max_eval > 1021) { set_error("optimize: max_eval must be at most 1021 (torch's default for max_iter = 25 is 31)"); return 1; }
     r.rounds = r.opt.max_eval + 1;          // upper bound on evaluations per window (see lbfgs.hip)
     if (B == 0) return 0;
     if (encoder_forward(h, stage, B, r.pose_in, s)) return 1;
@@ -1210,7 +1212,21 @@ int gem_calculate_errors(gem_handle* h, const double* d_est, const double* d_mid
     if (!d_est || !d_mid || !d_opt || !d_gt || !h_bone_mm || !d_out) { set_error("gem_calculate_errors: null argument"); return 1; }
     GEM_HIP(hipSetDevice(h->cfg.device));
     if (post_scratch(h, (size_t)(11 + MAXJ_ERR) * n_frames)) return 1;
-    return launch_errors(h, d_est, d_mid, d_opt, d_gt, n_frames, h_bone_mm, h->post_work, d_out, (hipStream_t)stream);
+    return launch_errors(h, d_est, d_mid, d_opt, d_gt, n_frames, h_bone_mm, h->post_work, d_out, (hipStream_t)stream, 1);
+}
+
+int gem_calculate_errors_chunks(gem_handle* h, const double* d_est, const double* d_mid, const double* d_opt, const double* d_gt,
+                                int n_chunks, int frames_per_chunk, const double* h_bone_mm, double* d_out, void* stream) {
+    if (!h) { set_error("gem_calculate_errors_chunks: null handle"); return 1; }
+    if (h->J < 12) { set_error("gem_calculate_errors_chunks: the hip-midpoint error needs joints 7 and 11 (n_joints >= 12)"); return 1; }
+    if (n_chunks < 0 || frames_per_chunk < 1) { set_error("gem_calculate_errors_chunks: need n_chunks >= 0 and frames_per_chunk >= 1"); return 1; }
+    if (n_chunks == 0) return 0;
+    if (!d_est || !d_mid || !d_opt || !d_gt || !h_bone_mm || !d_out) { set_error("gem_calculate_errors_chunks: null argument"); return 1; }
+    GEM_HIP(hipSetDevice(h->cfg.device));
+    const size_t per = (size_t)(11 + MAXJ_ERR) * frames_per_chunk;
+    if (post_scratch(h, per * n_chunks)) return 1;           // (every sequence its own scratch: blockIdx.y picks the sequence)
+    if (n_chunks > 65535) { set_error("gem_calculate_errors_chunks: at most 65535 sequences per call"); return 1; }
+    return launch_errors(h, d_est, d_mid, d_opt, d_gt, frames_per_chunk, h_bone_mm, h->post_work, d_out, (hipStream_t)stream, n_chunks);
 }
 
 int gem_lift_skeleton(gem_handle* h, const float* d_heat, const double* d_depth, int n_frames, const double* h_poly_c2w,

@@ -431,7 +431,7 @@ int launch_to_global(const float* rel, const double* cams, const int32_t* frame0
 
 // sequence post-processing (errors.hip)
 int launch_errors(gem_handle* h, const double* est, const double* mid, const double* opt, const double* gt, int F,
-                  const double* bone_mm, double* frame_out, double* out, hipStream_t s);
+                  const double* bone_mm, double* frame_out, double* out, hipStream_t s, int n_seq);
 int launch_merge(const double* win, double* tmp, double* out, int n_chunks, int wpc, int T, int JC, int overlap, int smooth,
                  hipStream_t s);
 size_t errors_frame_lds_bytes(int J);

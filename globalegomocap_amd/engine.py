@@ -339,6 +339,22 @@ class WindowEngine:
                                                   bone.ctypes.data_as(C.POINTER(C.c_double)), _ptr(out), _stream()), self.lib)
         return out
 
+    def calculate_errors_chunks(self, est, mid, opt, gt, n_chunks):
+        """calculate_errors for each of `n_chunks` equally long sequences laid end to end (device f64 tensors [n_chunks*F,J,3]):
+        [n_chunks, 17+J] f64 on the device, one library call, no synchronisation."""
+        from .skeleton import mean_bone_length_mm
+        for x in (est, mid, opt, gt):
+            if not (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float64 and x.is_contiguous() and x.shape == est.shape):
+                raise TypeError("calculate_errors_chunks wants equally shaped contiguous float64 device tensors")
+        total = est.numel() // (N_JOINTS * 3)
+        if n_chunks < 1 or total % n_chunks:
+            raise ValueError("calculate_errors_chunks: %d frames do not split into %d chunks" % (total, n_chunks))
+        bone = np.ascontiguousarray(mean_bone_length_mm(), dtype=np.float64)
+        out = torch.empty(n_chunks, 17 + N_JOINTS, device=self.device, dtype=torch.float64)
+        _capi.check(self.lib.gem_calculate_errors_chunks(self._h, _ptr(est), _ptr(mid), _ptr(opt), _ptr(gt), n_chunks, total // n_chunks,
+                                                         bone.ctypes.data_as(C.POINTER(C.c_double)), _ptr(out), _stream()), self.lib)
+        return out
+
     def calculate_errors(self, est, mid, opt, gt):
         """Same keys and definitions as the reference's calculate_errors (calculate_errors.py:114-179)."""
         from collections import OrderedDict

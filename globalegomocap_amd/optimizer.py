@@ -108,12 +108,11 @@ class SequenceOptimizer:
         w_local = energy_weights(weight_3d / 10000, smoothness_weight / 100, bone_length_weight, vae_weight, reproj_weight)
         return w_local, w_global
 
-    def run(self, est_local, cams, heat, starts, chunk_of_window, chunk_bounds, w_local, w_global, eps=None, keep_device=False, timings=None, while_device_runs=None):
-        """est_local [F,15,3], cams [F,4,4], heat [F,H,W,15]; starts [B] first frame of each window;
-        chunk_bounds [(f0, f1)] per chunk for the per-chunk mean bone length (optimizer.py:42-43).
-        Returns (mid_local f32 [B,T,15,3], global f64 [B,T,15,3], stats); the two pose arrays stay torch device
-        tensors with keep_device=True (for the device post-processing).  `while_device_runs()` is called between the enqueue
-        and the blocking read-back of the statistics."""
+    def prepare(self, est_local, cams, starts, chunk_of_window, chunk_bounds, timings=None, upload=None):
+        """Checks the window tables and uploads everything a call needs EXCEPT the heat-maps and the noise (poses, cameras, first
+        frames, per-chunk mean bone lengths): what can be done while the heat-maps are still on their way.  -> handle for `fire`.
+        `upload(array, torch dtype) -> device tensor`: the caller's way of bringing a host array to the device (e.g. through a
+        pinned block, asynchronously); default: an ordinary copy."""
         e = self.engine
         dev = e.device
         B = len(starts)
@@ -126,37 +125,71 @@ class SequenceOptimizer:
                 now = time.perf_counter()
                 timings[name] = timings.get(name, 0.0) + (now - tick[0])
                 tick[0] = now
-        if len(cams) != n_frames or len(heat) != n_frames:
-            raise ValueError("est_local, cams and heat must cover the same frames (%d / %d / %d)" % (n_frames, len(cams), len(heat)))
+        if len(cams) != n_frames:
+            raise ValueError("est_local and cams must cover the same frames (%d / %d)" % (n_frames, len(cams)))
         if B and (int(np.min(starts)) < 0 or int(np.max(starts)) + self.seq_len > n_frames):
             raise ValueError("a window [start, start + %d) leaves the %d frames of the sequence" % (self.seq_len, n_frames))
         if len(chunk_of_window) != B or (B and int(np.max(chunk_of_window)) >= len(chunk_bounds)):
             raise ValueError("chunk_of_window must name one of the %d chunks for each of the %d windows" % (len(chunk_bounds), B))
-        pose_d = torch.as_tensor(np.asarray(est_local), dtype=torch.float32).to(dev).contiguous()
-        cams_d = torch.as_tensor(np.asarray(cams), dtype=torch.float64).to(dev).contiguous()
-        heat_d = (heat if torch.is_tensor(heat) else torch.as_tensor(np.asarray(heat))).to(dev, dtype=torch.float32).contiguous()
+        if upload is None:
+            def upload(a, dtype):
+                return torch.as_tensor(np.asarray(a), dtype=dtype).to(dev).contiguous()
+        pose_d = upload(est_local, torch.float32)
+        cams_d = upload(cams, torch.float64)
         lap("run: checks + upload of poses / cameras")
         mb = torch.stack([e.mean_bone_length(pose_d[a:b]) for a, b in chunk_bounds])
-        mb_w = mb[torch.as_tensor(np.asarray(chunk_of_window), dtype=torch.long, device=dev)].contiguous()
+        mb_w = mb[upload(chunk_of_window, torch.long)].contiguous()
+        f0 = upload(starts, torch.int32)
         lap("run: mean bone lengths")
+        return {"pose": pose_d, "cams": cams_d, "mean_bone": mb_w, "frame0": f0, "B": B, "frames": n_frames}
+
+    def fire(self, prep, heat, w_local, w_global, eps=None, timings=None):
+        """Enqueues both stages for every window of a `prepare`d call; returns without waiting for the device (-> `collect`)."""
+        e = self.engine
+        dev = e.device
+        B = prep["B"]
+        if len(heat) != prep["frames"]:
+            raise ValueError("est_local, cams and heat must cover the same frames (%d / %d)" % (prep["frames"], len(heat)))
+        import time
+        t0 = time.perf_counter()
+        heat_d = (heat if torch.is_tensor(heat) else torch.as_tensor(np.asarray(heat))).to(dev, dtype=torch.float32).contiguous()
         if eps is None:
             eps = torch.randn(2 * B, e.D)
         eps = torch.as_tensor(np.asarray(eps) if not torch.is_tensor(eps) else eps, dtype=torch.float32).reshape(B, 2, e.D)
         eps_d = eps.to(dev, non_blocking=True)                 # one copy (asynchronous from a pinned block), split on the device
         eps_l, eps_g = eps_d[:, 0].contiguous(), eps_d[:, 1].contiguous()
-        f0 = torch.as_tensor(np.asarray(starts), dtype=torch.int32).to(dev)
-        lap("run: noise upload")
-        mid, glob, stats = e.optimize_windows(pose_d, cams_d, heat_d, f0, mb_w, eps_l, eps_g, w_local, w_global, self.opts)
-        lap("run: enqueue")
-        if while_device_runs is not None:          # host work that does not need the result (the caller's report preparation)
-            while_device_runs()
-            lap("run: caller's host work behind the device")
+        pending = e.optimize_windows(prep["pose"], prep["cams"], heat_d, prep["frame0"], prep["mean_bone"], eps_l, eps_g, w_local, w_global,
+                                     self.opts)
+        if timings is not None:
+            timings["run: noise upload + enqueue"] = timings.get("run: noise upload + enqueue", 0.0) + time.perf_counter() - t0
+        return pending
+
+    def enqueue(self, est_local, cams, heat, starts, chunk_of_window, chunk_bounds, w_local, w_global, eps=None, timings=None):
+        """`prepare` + `fire`: uploads and enqueues a whole call; returns without waiting for the device.  Arguments as `run`."""
+        if len(heat) != len(est_local):
+            raise ValueError("est_local, cams and heat must cover the same frames (%d / %d / %d)" % (len(est_local), len(cams), len(heat)))
+        prep = self.prepare(est_local, cams, starts, chunk_of_window, chunk_bounds, timings=timings)
+        return self.fire(prep, heat, w_local, w_global, eps=eps, timings=timings)
+
+    def collect(self, pending, keep_device=False):
+        """Waits for an `enqueue`d call: (mid_local, global, stats) as `run` returns them."""
+        mid, glob, stats = pending
         st = stats_to_numpy(stats)
-        lap("run: wait for the device + stats")
         _raise_if_degenerate(st)
         if keep_device:
             return mid, glob, st
         return mid.cpu().numpy(), glob.cpu().numpy(), st
+
+    def run(self, est_local, cams, heat, starts, chunk_of_window, chunk_bounds, w_local, w_global, eps=None, keep_device=False, timings=None, while_device_runs=None):
+        """est_local [F,15,3], cams [F,4,4], heat [F,H,W,15]; starts [B] first frame of each window;
+        chunk_bounds [(f0, f1)] per chunk for the per-chunk mean bone length (optimizer.py:42-43).
+        Returns (mid_local f32 [B,T,15,3], global f64 [B,T,15,3], stats); the two pose arrays stay torch device
+        tensors with keep_device=True (for the device post-processing).  `while_device_runs()` is called between the enqueue
+        and the blocking read-back of the statistics."""
+        pending = self.enqueue(est_local, cams, heat, starts, chunk_of_window, chunk_bounds, w_local, w_global, eps=eps, timings=timings)
+        if while_device_runs is not None:          # host work that does not need the result (the caller's report preparation)
+            while_device_runs()
+        return self.collect(pending, keep_device=keep_device)
 
 
 def main(data_id, camera_model_path, vae_weight, gmm_weight, smoothness_weight, bone_length_weight, weight_3d,

@@ -105,6 +105,24 @@ def make_sequence(n_frames=100, seed=1, camera=None, noise=0.02, sigma=1.5, with
     return out
 
 
+def reference_pickle_dict(seq, frames=slice(None), heat_dtype=np.float32):
+    """The dict `MakeDataForOptimization/process_test_data.py:149-157` pickles for one chunk, from a `make_sequence` dict (or
+    any mapping with its keys): all FIVE keys in the writer's order, every heat-map a separate [H,W,J] array in FORTRAN order
+    as `scipy.io.loadmat(...)['heatmap']` returns it (:65-67; float32 from the network's .mat files, float64 if they were
+    saved as MATLAB doubles).  `pickle.dump(reference_pickle_dict(...), f)` -- default protocol, like the writer -- is a
+    `test_data.pkl` as the reference's tool chain makes it."""
+    est = np.asarray(seq["estimated_local_skeleton"], dtype=np.float64)[frames]
+    cams = np.asarray(seq["camera_pose_list"], dtype=np.float64)[frames]
+    homo = np.concatenate([est, np.ones(est.shape[:2] + (1,))], axis=-1)
+    return {
+        "gt_global_skeleton": [p for p in np.asarray(seq["gt_global_skeleton"], dtype=np.float64)[frames]],
+        "estimated_global_skeleton": [p for p in np.einsum("nij,nkj->nki", cams, homo)[..., :3]],
+        "estimated_local_skeleton": [p for p in est],
+        "camera_pose_list": [c for c in cams],
+        "heatmap_list": [np.asfortranarray(h, dtype=heat_dtype) for h in np.asarray(seq["heatmap_list"])[frames]],
+    }
+
+
 def make_training_windows(n_windows, seq_len, seed):
     """Smooth synthetic motion windows [n, seq_len, 45] for briefly fitting a test VAE."""
     rng = np.random.default_rng(seed)

@@ -366,13 +366,21 @@ def load_checkpoint_file(path, trust=None):
             if ma is not None and hasattr(ma, fn):
                 allow.append(getattr(ma, fn))
     allow += [type(np.dtype(t)) for t in ("float32", "float64", "int64", "int32", "bool")]
+    # the same two functions under the module path of the OTHER numpy generation: the reference's train.py stores
+    # eval_result = np.mean(...), a numpy scalar, so a checkpoint written under numpy 1.x names numpy.core.multiarray.scalar and
+    # one written under 2.x numpy._core.multiarray.scalar -- whichever numpy reads it (torch matches the full name)
+    for legacy in ("numpy.core.multiarray", "numpy._core.multiarray"):
+        for fn in ("scalar", "_reconstruct"):
+            target = next((a for a in allow if getattr(a, "__name__", None) == fn), None)
+            if target is not None:
+                allow.append((target, "%s.%s" % (legacy, fn)))
     try:
         with torch.serialization.safe_globals(allow):
             return torch.load(path, map_location="cpu", weights_only=True)
     except pickle.UnpicklingError as e:
         if not trust:
             raise pickle.UnpicklingError("%s holds objects the restricted unpickler refuses (%s); pass trust=True / set "
-                                         "GEM_TRUST_CHECKPOINTS=1 only for files you wrote yourself" % (path, str(e).splitlines()[0])) from e
+                                         "GEM_TRUST_CHECKPOINTS=1 only for files whose origin you trust" % (path, str(e).splitlines()[0])) from e
     return torch.load(path, map_location="cpu", weights_only=False)
 
 

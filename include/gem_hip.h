@@ -208,6 +208,11 @@ int gem_merge_windows(gem_handle* h, const double* d_windows, int n_chunks, int 
 int gem_calculate_errors(gem_handle* h, const double* d_est, const double* d_mid, const double* d_opt,
                          const double* d_gt, int n_frames, const double* h_bone_mm, double* d_out, void* stream);
 
+/* gem_calculate_errors for each of n_chunks equally long sequences laid end to end (d_* [n_chunks*frames_per_chunk,J,3] f64) in ONE
+ * call: the per-chunk `main()` reports that optimize_whole_sequence.py:55-104 collects.  d_out [n_chunks][17+J] f64. */
+int gem_calculate_errors_chunks(gem_handle* h, const double* d_est, const double* d_mid, const double* d_opt, const double* d_gt,
+                                int n_chunks, int frames_per_chunk, const double* h_bone_mm, double* d_out, void* stream);
+
 /* ---- input lifting: raw network outputs -> estimated_local_skeleton ----
  * Skeleton.set_skeleton_from_file + set_skeleton + get_max_preds (utils/skeleton.py:74-90,32-45,176-204) followed by
  * FishEyeCameraCalibrated.camera2world (utils/fisheye/FishEyeCalibrated.py:18-33), without the bone-length resize
@@ -220,6 +225,67 @@ int gem_calculate_errors(gem_handle* h, const double* d_est, const double* d_mid
  * (what gem_optimize_windows consumes).  Family 3 of the profiling hook times this kernel (bytes instead of flops). */
 int gem_lift_skeleton(gem_handle* h, const float* d_heat, const double* d_depth, int n_frames, const double* h_poly_c2w,
                       int n_poly_c2w, int upscale, int pad_x, int pad_y, double* d_out64, float* d_out32, void* stream);
+
+/* ---- chunk files: `<chunk>/test_data.pkl` as the reference writes and reads it ----
+ * The file is a pickled dict of lists of numpy arrays (written at MakeDataForOptimization/process_test_data.py:149-157, read at
+ * optimizer.py:315-324); its heat-maps are what scipy.io.loadmat returned (process_test_data.py:65-67): [H,W,J] arrays in
+ * FORTRAN order, float32 or float64.  These calls take such a file to the device without building a Python object per array.
+ * None of them needs a gem_handle; the host-side ones need no GPU. */
+enum { GEM_DT_F32 = 0, GEM_DT_F64 = 1 };
+enum { GEM_PICKLE_UNSUPPORTED = 2 };     /* return code: a well-formed call on a file outside the subset -- un-pickle it the ordinary way */
+
+typedef struct gem_pickle_array {
+    int64_t offset;         /* of the array's raw data, in bytes from the start of the file */
+    int64_t nbytes;
+    int32_t dtype;          /* GEM_DT_F32 / GEM_DT_F64 (little-endian) */
+    int32_t ndim;           /* 0..4 */
+    int32_t fortran;        /* 1: the data are in Fortran order (ndarray.flags.f_contiguous and not c_contiguous) */
+    int32_t key;            /* index into the `keys` the scan was given */
+    int64_t shape[4];       /* unused trailing dimensions are 1 */
+} gem_pickle_array;
+
+/* Interprets the pickle in h_image[0, len) (protocols 2-5; the opcodes a dict of lists of ndarrays consists of) WITHOUT constructing
+ * or calling anything it names, and reports where the arrays of the dict's entries `keys[0 .. n_keys)` lie: `out` receives the
+ * arrays key by key in list order (at most `cap`), counts[k] the number of arrays under keys[k], or -1 when the dict has no such
+ * key.  Returns GEM_PICKLE_UNSUPPORTED (text in gem_last_error) for anything else: other opcodes, an entry that is not a list of
+ * float32 / float64 ndarrays, protocol-2 arrays (their bytes are stored as text), big-endian data. */
+int gem_pickle_scan(const void* h_image, int64_t len, const char* const* keys, int n_keys, gem_pickle_array* out, int64_t cap,
+                    int64_t* counts);
+
+/* n equally shaped arrays found by gem_pickle_scan -> h_out [n][shape] float64, C order (np.asarray(list_of_arrays) as at
+ * optimizer.py:318-323 for the skeleton / camera lists). */
+int gem_pickle_gather_f64(const void* h_image, int64_t len, const gem_pickle_array* arrays, int64_t n, double* h_out);
+
+/* Heat-maps out of a DEVICE image of (part of) the file: d_image[0, image_len) holds file bytes, d_offsets [n] the byte position of
+ * every frame's raw data in it (any alignment); dtype / fortran as gem_pickle_scan reported them (all frames alike).
+ * d_out [n, heat_h, heat_w, n_joints] f32 = what `torch.from_numpy(np.asarray(heatmap_list)).float()` holds (optimizer.py:324,248):
+ * the Fortran order undone, float64 rounded to nearest even.  d_image must be 4-byte aligned and readable up to image_len rounded
+ * UP to a multiple of 4; d_out 16-byte aligned; n <= 65535. */
+int gem_heat_gather(const void* d_image, int64_t image_len, const int64_t* d_offsets, int64_t n, int heat_h, int heat_w,
+                    int n_joints, int dtype, int fortran, float* d_out, void* stream);
+
+/* One chunk file as an object: gem_chunk_open opens and maps `path`, scans it for `keys` (gem_pickle_scan) and keeps the table.
+ * gem_chunk_count: arrays under keys[key] (-1: no such key); gem_chunk_bytes: size of the file.
+ * gem_chunk_info: info[8] = { count, ndim, dtype, fortran, shape[0..3] } of the arrays under keys[key]; ndim = -1 when they are not
+ * all of one shape, type and order.  gem_chunk_offsets: the byte offset of every array's raw data in the file (h_out [count]).
+ * gem_chunk_gather_f64: gem_pickle_gather_f64 on the key's arrays (n_out = capacity of h_out in doubles). */
+typedef struct gem_chunk gem_chunk;
+int     gem_chunk_open(const char* path, const char* const* keys, int n_keys, gem_chunk** out);
+void    gem_chunk_close(gem_chunk* c);
+int64_t gem_chunk_bytes(const gem_chunk* c);
+int64_t gem_chunk_count(const gem_chunk* c, int key);
+int     gem_chunk_info(const gem_chunk* c, int key, int64_t* info);
+int     gem_chunk_offsets(const gem_chunk* c, int key, int64_t* h_out, int64_t cap);
+int     gem_chunk_gather_f64(const gem_chunk* c, int key, double* h_out, int64_t n_out);
+
+/* A file on its way to the device: `path` is read (pread, `slice_bytes` at a time) into the caller's PINNED buffer h_pinned and sent
+ * on to d_image slice by slice (hipMemcpyAsync on `stream` of `device`: the next slice is read while the last one crosses PCIe), so
+ * that d_image[0, *file_bytes) is an image of the file once the stream has passed the call's work -- what gem_heat_gather reads, with
+ * the offsets gem_chunk_offsets reports.  Both buffers must hold buffer_bytes >= file size + 8; h_pinned must stay untouched until the
+ * stream has passed.  Nothing synchronises; needs no scan of the file, so it can run beside gem_chunk_open on another thread.
+ * Calls on different files may run concurrently from different threads (one stream and one pair of buffers each). */
+int gem_file_stage(const char* path, int device, void* h_pinned, void* d_image, int64_t buffer_bytes, int64_t slice_bytes,
+                   int64_t* file_bytes, void* stream);
 
 /* Timing hook for bench.py's roofline: average device time (ms) of the launches of the dominant
  * kernel family since the last reset, measured with HIP events on the launch stream.

@@ -244,33 +244,34 @@ def test_several_sequences_in_one_batch_match_sequence_by_sequence_runs(golden, 
             np.testing.assert_allclose(b[0][k], a[0][k], rtol=0, atol=tol, err_msg=k)
 
 
-def test_equal_chunks_take_the_vectorised_report_path_and_the_sidecar_cache(golden, tmp_path):
-    """Equal 100-frame chunks (the reference's data layout): all chunks' bookkeeping and error reports in one go, heat-maps
-    read from the raw-array cache on the second run; reports must be those of the per-chunk main() loop and of the
-    pickle-only run."""
+def test_equal_chunks_take_the_vectorised_report_path_and_the_batch_pipeline(golden, tmp_path):
+    """Equal 100-frame chunks written the reference's way (five keys, Fortran-ordered heat-maps, default protocol): all chunks'
+    bookkeeping and error reports in one go; the same chunks as a PIPELINE of device calls (one or two chunks per call: the next
+    call's files arrive and its noise is drawn while this one computes, three frame buffers rotate) must report what the
+    per-chunk main() loop reports, and nothing may be written next to the data."""
     import pickle
     import torch
     from globalegomocap_amd import optimizer as gopt, whole_sequence as ws
     from helpers import sd_from_npz
     lt = golden("lbfgs_tiny")
     kw = dict(global_vae_path=sd_from_npz(lt, "global/"), local_vae_path=sd_from_npz(lt, "local/"))
-    for i in range(3):
+    for i in range(5):
         d = tmp_path / ("chunk_%d" % i)
         d.mkdir()
         data = synth.make_sequence(n_frames=100, seed=70 + i, cam_jitter=(0.3, 0.002))
         with open(d / "test_data.pkl", "wb") as f:
-            pickle.dump({k: data[k] for k in ("estimated_local_skeleton", "gt_global_skeleton", "camera_pose_list", "heatmap_list")}, f)
+            pickle.dump(synth.reference_pickle_dict(data), f)
     torch.manual_seed(9)
     per_chunk = [gopt.main(p, DEFAULT_CALIBRATION, 0.0, 0.0, 0.001, 0.01, 0.01, 0.01, final_smooth=True, **kw)
                  for p in ws.list_chunks(str(tmp_path))]
     runs = []
-    for sidecar in (False, True, True):             # pickles only; pickles + cache written; cache read
+    for cpb in (None, 1, 2, None):
         torch.manual_seed(9)
-        runs.append(ws.optimize_directory(str(tmp_path), DEFAULT_CALIBRATION, verbose=False, sidecar=sidecar, **kw))
-    assert os.path.exists(tmp_path / "chunk_0" / ws.SIDE_CACHE)
+        runs.append(ws.optimize_directory(str(tmp_path), DEFAULT_CALIBRATION, verbose=False, chunks_per_batch=cpb, **kw))
+    assert sorted(os.listdir(tmp_path / "chunk_0")) == ["test_data.pkl"]
     ref_opt = np.concatenate([np.asarray(r[3]) for r in per_chunk])
     for summary, results, est, opt, gt in runs:
-        assert len(results) == 3 and len(opt) == 3 * 98 == len(est) == len(gt)
+        assert len(results) == 5 and len(opt) == 5 * 98 == len(est) == len(gt)
         assert np.linalg.norm(np.asarray(opt) - ref_opt, axis=-1).mean() < 0.5e-3
         np.testing.assert_allclose(np.asarray(est), np.concatenate([np.asarray(r[1]) for r in per_chunk]), rtol=1e-9, atol=1e-12)
         np.testing.assert_allclose(np.asarray(gt), np.concatenate([np.asarray(r[4]) for r in per_chunk]), rtol=1e-9, atol=1e-12)
@@ -278,8 +279,8 @@ def test_equal_chunks_take_the_vectorised_report_path_and_the_sidecar_cache(gold
             ref = np.mean([r[0][k] for r in per_chunk], axis=0)
             tol = 1e-9 if k.startswith("original") or k in ("aligned_original_mpjpe", "bone_length_aligned_original_mpjpe") else 0.5e-3
             np.testing.assert_allclose(summary[k], ref, rtol=0, atol=tol, err_msg=k)
-    # cache vs pickle: the same device inputs, so the same results bit for bit
-    assert np.array_equal(np.asarray(runs[0][3]), np.asarray(runs[2][3]))
+    # the same call twice: the same device inputs and noise, so the same results bit for bit
+    assert np.array_equal(np.asarray(runs[0][3]), np.asarray(runs[3][3]))
 
 
 # ------------------------------------------------------------------------------------------------ INTEGRATION.md, executed
@@ -405,51 +406,75 @@ def test_integration_md_reporting_stub_runs_verbatim(engine, golden):
 
 
 def test_chunk_pickles_reach_the_device_without_passing_through_python_objects(tmp_path, monkeypatch):
-    """load_chunk(path, device): the pickle is parsed with the heat-maps' payloads skipped, the FILE goes to pinned memory in one read and
-    on to the device, where one strided copy picks the 100 arrays out (protocol 4: equally spaced payloads); a protocol-3 pickle
-    (memo indices in the opcodes: the spacing changes along the list) is scattered on the host with one os.preadv instead; float64
-    heat-maps take the plain un-pickling path.  Every path must deliver exactly what pickle.load delivers."""
+    """load_chunk(path, device): the library interprets the pickle (gem_chunk_open), the FILE goes to pinned memory and on to the
+    device in slices (gem_file_stage), and one kernel there picks the 100 arrays out -- undoing the Fortran order of
+    scipy.io.loadmat's arrays and rounding float64 to float32 on the way (gem_heat_gather).  The cases are built the reference's
+    way (process_test_data.py:65-67,149-157): heat-maps through savemat / loadmat, float32 AND float64, five keys, every protocol
+    that stores raw bytes; C-ordered lists (what np.ascontiguousarray'd data give) as well.  Files outside the library reader's
+    subset (protocol 2, ragged lists) are stacked on the host.  Every path must deliver exactly what
+    `torch.from_numpy(np.asarray(pickle.load(f)['heatmap_list'])).float()` holds (optimizer.py:324,248)."""
     import pickle
+    import scipy.io as sio
     import torch
-    from globalegomocap_amd import whole_sequence as ws
+    from globalegomocap_amd import _capi, whole_sequence as ws
     rng = np.random.default_rng(3)
-    heat = rng.random((100, 64, 64, 15), dtype=np.float32)
-    small = {"estimated_local_skeleton": list(rng.random((100, 15, 3))), "gt_global_skeleton": list(rng.random((100, 15, 3))),
-             "camera_pose_list": list(rng.random((100, 4, 4)))}
-    calls = {"file": 0, "host": 0}
-    orig_file, orig_host = ws._stage_file_to_device, ws._stage_to_device
+    n = 100
+    small = {"gt_global_skeleton": list(rng.random((n, 15, 3))), "estimated_global_skeleton": list(rng.random((n, 15, 3))),
+             "estimated_local_skeleton": list(rng.random((n, 15, 3))), "camera_pose_list": list(rng.random((n, 4, 4)))}
+    lib = _capi.load_library()
+    calls = {"native": 0}
+    orig = lib.gem_heat_gather
 
-    def count_file(*a, **k):
-        calls["file"] += 1
-        return orig_file(*a, **k)
+    class Counting:                                   # (ctypes function pointers cannot be monkeypatched in place)
+        def __getattr__(self, name):
+            if name == "gem_heat_gather":
+                def f(*a):
+                    rc = orig(*a)
+                    calls["native"] += rc == 0
+                    return rc
+                return f
+            return getattr(lib, name)
+    monkeypatch.setattr(_capi, "load_library", lambda path=None: Counting())
 
-    def count_host(*a, **k):
-        calls["host"] += 1
-        return orig_host(*a, **k)
-    monkeypatch.setattr(ws, "_stage_file_to_device", count_file)
-    monkeypatch.setattr(ws, "_stage_to_device", count_host)
+    def from_mat(a, k):
+        sio.savemat(str(tmp_path / ("h%d.mat" % k)), {"heatmap": a})
+        return sio.loadmat(str(tmp_path / ("h%d.mat" % k)))["heatmap"]
+    base32 = rng.random((n, 64, 64, 15), dtype=np.float32)
+    base32[0, :4, :4, 0] = [1e-40, -1e-42, 0.0, -0.0]                 # (denormals and signed zeros travel too)
+    base64 = rng.random((n, 64, 64, 15)) * 1e-3
+    base64[0, 0, :8, 1] = [1e-40, 1e-46, 1.0000000596046448, 1.00000017881393433, 3.5e38, -3.5e38, np.inf, np.nan]      # rounding cases of the f64 -> f32 cast
     dev = torch.device("cuda:0")
-    expect = {4: (1, 0), 3: (1, 1), "f64": (0, 1)}
-    for case, (n_file, n_host) in expect.items():
-        d = tmp_path / ("c_%s" % case)
+    cases = [("F32", base32, "mat", None, 1), ("F64", base64, "mat", None, 1), ("F32", base32, "mat", 3, 1), ("F64", base64, "mat", 5, 1),
+             ("C32", base32, "C", 4, 1), ("C64", base64, "C", 3, 1), ("C32", base32, "C", 5, 1), ("F32", base32, "mat", 2, 0),
+             ("ragged", base32, "ragged", 4, 0)]
+    for ci, (tag, data, order, proto, native) in enumerate(cases):
+        d = tmp_path / ("c_%d" % ci)
         d.mkdir()
-        hl = [h.astype(np.float64) for h in heat] if case == "f64" else list(heat)
-        # (protocol 3 with the heat-maps FIRST: the memo indices written behind every array pass 255 inside the list, the opcodes
-        # that carry them grow, and the payloads' spacing changes from 245803 to 245821 bytes)
-        obj = dict(heatmap_list=hl, **small) if case == 3 else dict(small, heatmap_list=hl)
+        if order == "mat":
+            hl = [from_mat(h, ci) for h in data[:6]] + [np.asfortranarray(h) for h in data[6:]]      # (loadmat for the first few, its layout for the rest)
+            assert hl[0].flags.f_contiguous and not hl[0].flags.c_contiguous and hl[0].dtype == data.dtype
+        else:
+            hl = [h.copy() for h in data]
+        expect = torch.from_numpy(np.asarray(hl)).float().numpy()
+        if order == "ragged":
+            hl[-1] = np.zeros((64, 64, 15), dtype=np.float64)          # one array of another type: the list is stacked on the host
+            expect[-1] = 0.0
+        obj = dict(small, heatmap_list=hl)
         with open(d / "test_data.pkl", "wb") as f:
-            pickle.dump(obj, f, protocol=4 if case == "f64" else case)
-        calls["file"] = calls["host"] = 0
-        dest = torch.full((100, 64, 64, 15), -1.0, dtype=torch.float32, device=dev)
+            pickle.dump(obj, f) if proto is None else pickle.dump(obj, f, protocol=proto)
+        calls["native"] = 0
+        dest = torch.full((n, 64, 64, 15), -1.0, dtype=torch.float32, device=dev)
         torch.cuda.synchronize()                       # (the reader copies on its own stream)
         c = ws.load_chunk(str(d), device=dev, dest=dest)
         c["heat_ready"].synchronize()
-        assert (calls["file"], calls["host"]) == (n_file, n_host), (case, calls)
+        assert calls["native"] == native, (tag, proto, calls)
         assert c["heat"].data_ptr() == dest.data_ptr()
-        assert np.array_equal(c["heat"].cpu().numpy(), heat), case
+        got = c["heat"].cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), expect.view(np.uint32)), (tag, proto)          # bit for bit (NaN, -0.0 and denormals included)
         for k, name in (("est_local", "estimated_local_skeleton"), ("gt", "gt_global_skeleton"), ("cams", "camera_pose_list")):
-            assert np.array_equal(c[k], np.asarray(small[name])), (case, k)
-        # a second chunk through the same reader thread's buffers
-        c2 = ws.load_chunk(str(d), device=dev)
-        c2["heat_ready"].synchronize()
-        assert np.array_equal(c2["heat"].cpu().numpy(), heat), case
+            assert np.array_equal(c[k], np.asarray(small[name])), (tag, k)
+        # a second and third chunk through the same reader thread's buffers (both staging buffers get reused)
+        for _ in range(2):
+            c2 = ws.load_chunk(str(d), device=dev)
+            c2["heat_ready"].synchronize()
+            assert np.array_equal(c2["heat"].cpu().numpy().view(np.uint32), expect.view(np.uint32)), (tag, proto)

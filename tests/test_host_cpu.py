@@ -20,7 +20,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     from globalegomocap_amd import _capi
     lib = _capi.load_library()
     header = open(os.path.join(ROOT, "include", "gem_hip.h")).read()
-    declared = set(re.findall(r"\b(gem_[a-z_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(gem_[a-z0-9_]+)\s*\(", header))
     assert declared == set(_capi.SIGNATURES), declared ^ set(_capi.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name)
@@ -53,6 +53,7 @@ def test_struct_layouts_match_the_header():
     # int32 x4, int32[8], int32 x2, int32 (+pad), double[16], double x2, int32[16], int32 x2
     assert C.sizeof(_capi.GemConfig) == 16 + 32 + 8 + 8 + 128 + 16 + 64 + 8
     assert C.sizeof(_capi.GemTrainOpts) == 7 * 8 + 8          # struct gem_train_opts: 7 doubles, 2 int32
+    assert C.sizeof(_capi.GemPickleArray) == 2 * 8 + 4 * 4 + 4 * 8 and _capi.GemPickleArray.shape.offset == 32
 
 
 def test_missing_library_fails_loudly(tmp_path):
@@ -148,6 +149,39 @@ def test_checkpoint_schema_roundtrip(tmp_path):
         vae_schema.flatten_state_dict(bad, TINY)
 
 
+def test_checkpoints_written_under_either_numpy_generation_load_through_the_restricted_unpickler(tmp_path):
+    """networks/train.py:102-108 stores eval_result = np.mean(...), a numpy scalar: a checkpoint written under numpy 1.x pickles it as
+    numpy.core.multiarray.scalar, one written under numpy 2.x as numpy._core.multiarray.scalar.  Both module paths must pass the
+    restricted loader whichever numpy is installed (no trust flag); something that is neither is still refused."""
+    import pickle
+    import zipfile
+    import torch
+    sd = vae_schema.synthetic_state_dict(TINY, 2)
+    src = str(tmp_path / "19.pth.tar")
+    torch.save({"epoch": 19, "eval_result": np.mean(np.arange(4.0)), "args": {"lr": 1e-3},
+                "state_dict": {k: torch.from_numpy(np.array(v)) for k, v in sd.items()}}, src)
+    ours = b"numpy._core.multiarray" if hasattr(np, "_core") else b"numpy.core.multiarray"
+    other = b"numpy.core.multiarray" if ours == b"numpy._core.multiarray" else b"numpy._core.multiarray"
+    variants = {"as_written": None, "other_generation": (ours, other), "refused": (ours, b"posixpath_xx.multiarray")}
+    for tag, swap in variants.items():
+        dst = str(tmp_path / (tag + ".pth.tar"))
+        with zipfile.ZipFile(src) as zin, zipfile.ZipFile(dst, "w") as zout:
+            for item in zin.infolist():
+                data = zin.read(item.filename)
+                if swap and item.filename.endswith("data.pkl"):
+                    assert swap[0] in data
+                    # (protocol 2 GLOBAL opcodes are newline-terminated text: a name of another length is still a valid pickle)
+                    data = data.replace(swap[0], swap[1])
+                zout.writestr(item, data)
+        if tag == "refused":
+            with pytest.raises(pickle.UnpicklingError):
+                vae_schema.load_checkpoint_file(dst, trust=False)
+            continue
+        ck = vae_schema.load_checkpoint_file(dst, trust=False)
+        assert float(ck["eval_result"]) == 1.5 and ck["epoch"] == 19, tag
+        assert vae_schema.infer_shape(ck["state_dict"]) == TINY, tag
+
+
 def test_full_size_parameter_count_matches_the_reference():
     # SURVEY 8a-A3: 32 557 677 parameters incl. BatchNorm running stats excluded? count float tensors w/o running stats
     n = 0
@@ -167,89 +201,142 @@ def test_chunk_listing_and_background_reader(tmp_path):
         d = tmp_path / ("chunk_%d" % i)
         d.mkdir()
         data = synth.make_sequence(n_frames=n, seed=i)
-        with open(d / "test_data.pkl", "wb") as f:
-            pickle.dump({k: data[k] for k in ("estimated_local_skeleton", "gt_global_skeleton", "camera_pose_list", "heatmap_list")}, f)
+        with open(d / "test_data.pkl", "wb") as f:                  # the reference's writer: five keys, Fortran-ordered heat-maps
+            pickle.dump(synth.reference_pickle_dict(data), f)
     (tmp_path / "notes.txt").write_text("not a chunk")
     paths = ws.list_chunks(str(tmp_path))
     assert [os.path.basename(p) for p in paths] == ["chunk_1", "chunk_2", "chunk_10"]
-    got = list(ws.ChunkStream(paths, depth=1, sidecar=True))
+    got = list(ws.ChunkStream(paths, depth=1))
     assert [len(c["est_local"]) for c in got] == [25, 30, 20]
     assert got[0]["heat"].dtype == np.float32 and got[0]["heat"].shape == (25, 64, 64, 15) and got[0]["cams"].shape == (25, 4, 4)
-    assert [len(b) for b in ws._batches(iter(got), 2)] == [2, 1] and [len(b) for b in ws._batches(iter(got), None)] == [3]
-    # the first read left a raw-array cache next to every pickle; the second read comes from it, bit for bit
-    for p_ in paths:
-        assert os.path.exists(os.path.join(p_, ws.SIDE_CACHE))
-    again = list(ws.ChunkStream(paths, depth=2, sidecar=True))
-    plain = list(ws.ChunkStream(paths, depth=2))                    # default: pickles only, nothing written
-    for a_, b_, c_ in zip(got, again, plain):
-        for k in ("est_local", "gt", "cams", "heat"):
-            assert np.array_equal(a_[k], b_[k]) and np.array_equal(a_[k], c_[k]) and a_[k].dtype == b_[k].dtype == c_[k].dtype, k
-    # a cache made from another pickle (size or modification time differ -- also an OLDER time stamp, as cp -p / rsync -t / a
-    # restore leave it), or of the wrong length, is ignored and rewritten
-    pk = os.path.join(paths[0], "test_data.pkl")
-    st = os.stat(pk)
-    os.utime(pk, ns=(st.st_atime_ns, st.st_mtime_ns - 10 ** 9))
-    assert ws._read_sidecar(paths[0]) is None
-    ws.load_chunk(paths[0], sidecar=True)
-    assert ws._read_sidecar(paths[0]) is not None
+    assert np.array_equal(got[0]["heat"], np.asarray(synth.make_sequence(n_frames=25, seed=1)["heatmap_list"]))
+    # the library's own reading of the same files (no Python object per array) finds the same small arrays
+    for p_, c in zip(paths, got):
+        q = ws.parse_chunk(p_)
+        assert len(q["heat_offsets"]) == q["n"] == len(c["est_local"]) and q["heat_shape"] == (64, 64, 15) and q["heat_fortran"] == 1 and q["heat_dtype"] == 0
+        for k in ("est_local", "gt", "cams"):
+            assert np.array_equal(q[k], c[k]) and q[k].dtype == np.float64, k
+    assert sorted(os.listdir(paths[0])) == ["test_data.pkl"]          # nothing is written next to the data
     ws.release_pools()
-    with open(os.path.join(paths[1], ws.SIDE_CACHE), "ab") as f:
-        f.write(b"xx")
-    assert ws._read_sidecar(paths[1]) is None
     (tmp_path / "chunk_3").mkdir()
     with open(tmp_path / "chunk_3" / "test_data.pkl", "wb") as f:
         pickle.dump({"estimated_local_skeleton": []}, f)
     with pytest.raises(KeyError):                      # a broken chunk surfaces in the consumer, like the reference's KeyError
         list(ws.ChunkStream(ws.list_chunks(str(tmp_path))))
+    with pytest.raises(KeyError):
+        ws.parse_chunk(str(tmp_path / "chunk_3"))
 
 
-def test_pickle_reader_that_skips_the_heat_map_payloads(tmp_path):
-    """whole_sequence._load_pickle_skipping un-pickles a chunk WITHOUT copying the heat-maps' raw data (the unpickler's large reads are
-    answered with a tag, their file offsets recorded) so that the reader threads can bring them from the page cache into pinned memory
-    with os.preadv, outside the GIL.  What it returns must be exactly what pickle.load returns, for every pickle protocol that stores
-    the arrays as byte strings; anything else (protocol 2's latin-1 strings, float64 or ragged heat-maps, a list of lists) makes it
-    decline, and load_chunk falls back to the plain path."""
+def _scan(lib, blob, keys):
+    import ctypes as C
+    from globalegomocap_amd import _capi
+    buf = np.frombuffer(blob, dtype=np.uint8)
+    ck = (C.c_char_p * len(keys))(*[k.encode() for k in keys])
+    out = (_capi.GemPickleArray * 4096)()
+    cnt = (C.c_int64 * len(keys))()
+    rc = lib.gem_pickle_scan(buf.ctypes.data, len(blob), ck, len(keys), out, 4096, cnt)
+    return rc, out, list(cnt)
+
+
+def test_library_pickle_scanner_against_pickle_load(tmp_path):
+    """gem_pickle_scan (csrc/chunk_io.hip, host code) interprets a chunk pickle WITHOUT building the arrays: for every array of the
+    requested keys it reports dtype, shape, order and where the raw data lie in the file.  Checked against what pickle.load
+    returns for the reference's kind of file -- heat-maps straight from scipy.io.loadmat (Fortran order; float32 and float64),
+    all five keys, protocols 3 / 4 / 5 and the default -- and it must decline (GEM_PICKLE_UNSUPPORTED, never crash) everything
+    outside its subset, corrupted and truncated files included."""
     import pickle
-    from globalegomocap_amd import whole_sequence as ws
-    data = synth.make_sequence(n_frames=30, seed=5)
-    keys = ("estimated_local_skeleton", "gt_global_skeleton", "camera_pose_list", "heatmap_list")
-    ref = np.asarray(data["heatmap_list"], dtype=np.float32)
-    d = tmp_path / "c"
-    d.mkdir()
-    for proto in (3, 4, 5):
-        with open(d / "test_data.pkl", "wb") as f:
-            pickle.dump({k: data[k] for k in keys}, f, protocol=proto)
-        got = ws._load_pickle_skipping(str(d))
-        assert got is not None, proto
-        f, shape, offs, small = got
-        try:
-            assert shape == ref.shape and len(offs) == 30 and set(small) == set(keys) - {"heatmap_list"}
-            heat = np.empty(shape, dtype=np.float32)
-            for i, o in enumerate(offs):
-                assert os.preadv(f.fileno(), [memoryview(heat[i]).cast("B")], o) == heat[i].nbytes
-        finally:
-            f.close()
-        assert np.array_equal(heat, ref), proto
-        for k in small:
-            assert np.array_equal(np.asarray(small[k]), np.asarray(data[k])), (proto, k)
+    import scipy.io as sio
+    from globalegomocap_amd import _capi
+    lib = _capi.load_library()
+    rng = np.random.default_rng(7)
+    n = 12
+
+    def from_mat(a):
+        sio.savemat(str(tmp_path / "h.mat"), {"heatmap": a})
+        return sio.loadmat(str(tmp_path / "h.mat"))["heatmap"]
+    keys = ["estimated_local_skeleton", "gt_global_skeleton", "camera_pose_list", "heatmap_list", "absent"]
+    for heat_dtype in (np.float32, np.float64):
+        heat = [from_mat(rng.random((64, 64, 15)).astype(heat_dtype)) for _ in range(n)]
+        assert heat[0].flags.f_contiguous and not heat[0].flags.c_contiguous and heat[0].dtype == heat_dtype       # what loadmat returns
+        data = {"gt_global_skeleton": list(rng.random((n, 15, 3))), "estimated_global_skeleton": list(rng.random((n, 15, 3))),
+                "estimated_local_skeleton": [np.asfortranarray(x) for x in rng.random((n, 15, 3))],           # (an F-ordered small array)
+                "camera_pose_list": list(rng.random((n, 4, 4)).astype(np.float32)), "heatmap_list": heat}
+        for proto in (3, 4, 5, None):
+            blob = pickle.dumps(data) if proto is None else pickle.dumps(data, protocol=proto)
+            rc, out, cnt = _scan(lib, blob, keys)
+            assert rc == 0, (proto, lib.gem_last_error())
+            assert cnt == [n, n, n, n, -1]
+            i = 0
+            for k, key in enumerate(keys[:4]):
+                for j in range(n):
+                    a, ref = out[i], data[key][j]
+                    i += 1
+                    assert a.key == k and (np.float32, np.float64)[a.dtype] == ref.dtype and tuple(a.shape[:a.ndim]) == ref.shape
+                    assert bool(a.fortran) == (ref.flags.f_contiguous and not ref.flags.c_contiguous)
+                    raw = np.frombuffer(blob, dtype=ref.dtype, count=ref.size, offset=a.offset)
+                    assert a.nbytes == raw.nbytes and np.array_equal(raw.reshape(ref.shape, order="F" if a.fortran else "C"), ref), (proto, key, j)
+            buf = np.frombuffer(blob, dtype=np.uint8)
+            import ctypes as C
+            for k, key in enumerate(keys[:3]):                    # np.asarray(list) of the small arrays, as float64
+                dense = np.empty((n,) + data[key][0].shape)
+                first = C.cast(C.byref(out, k * n * C.sizeof(_capi.GemPickleArray)), C.POINTER(_capi.GemPickleArray))
+                assert lib.gem_pickle_gather_f64(buf.ctypes.data, len(blob), first, n, dense.ctypes.data) == 0
+                assert np.array_equal(dense, np.asarray(data[key], dtype=np.float64)), (proto, key)
+    base = dict(data)
 
     def declines(obj, proto=4):
-        with open(d / "test_data.pkl", "wb") as f:
-            pickle.dump(obj, f, protocol=proto)
-        return ws._load_pickle_skipping(str(d)) is None
-    base = {k: data[k] for k in keys}
+        rc, _, _ = _scan(lib, pickle.dumps(obj, protocol=proto), keys)
+        return rc == _capi.PICKLE_UNSUPPORTED
     assert declines(base, proto=2)                                                            # raw data as latin-1 text
-    assert declines(dict(base, heatmap_list=[h.astype(np.float64) for h in data["heatmap_list"]]))
-    assert declines(dict(base, heatmap_list=np.asarray(data["heatmap_list"], dtype=np.float32)))      # ONE array: not a list
-    assert declines(dict(base, heatmap_list=[h.tolist() for h in data["heatmap_list"][:2]]))
-    assert declines(dict(base, heatmap_list=list(data["heatmap_list"][:-1]) + [np.zeros((64, 64, 16), np.float32)]))
-    assert declines(dict(base, extra=np.zeros(100000, np.float32)))                            # another large object lost its bytes
-    assert declines({"estimated_local_skeleton": []})
-    # whatever it declines, load_chunk still reads the plain way
-    with open(d / "test_data.pkl", "wb") as f:
-        pickle.dump(base, f, protocol=2)
-    c = ws.load_chunk(str(d))
-    assert np.array_equal(c["heat"], ref)
+    assert declines(dict(base, heatmap_list=np.asarray(heat)))                                # ONE array: not a list
+    assert declines(dict(base, heatmap_list=[h.tolist() for h in heat[:2]]))
+    assert declines(dict(base, heatmap_list=[h.astype(">f4") for h in heat]))                 # big-endian
+    assert declines(dict(base, heatmap_list=[h.astype(np.float16) for h in heat]))
+    assert declines([1, 2, 3]) and declines({"a": {1, 2}})
+    # an equally shaped list with one odd member is reported array by array (the caller compares the shapes) ...
+    rc, out, cnt = _scan(lib, pickle.dumps(dict(base, heatmap_list=heat[:-1] + [np.zeros((64, 64, 16), np.float32)])), keys)
+    assert rc == 0 and tuple(out[4 * n - 1].shape[:3]) == (64, 64, 16)
+    # ... repeated objects (memo references) resolve to the same bytes, and a key missing from the file is -1, not an error
+    rc, out, cnt = _scan(lib, pickle.dumps({"heatmap_list": [heat[0]] * 5}), keys)
+    assert rc == 0 and cnt == [-1, -1, -1, 5, -1] and len({out[i].offset for i in range(5)}) == 1
+    # corrupted / truncated / random input: an error code, never a crash, never an offset outside the file
+    blob = np.frombuffer(pickle.dumps(base, protocol=4), dtype=np.uint8)
+    for trial in range(400):
+        bad = blob.copy()
+        idx = rng.integers(0, 4000, size=4)
+        bad[idx] = rng.integers(0, 256, size=4)
+        if trial % 4 == 0:
+            bad = bad[:rng.integers(1, len(bad))]
+        rc, out, cnt = _scan(lib, bad.tobytes(), keys)
+        if rc == 0:
+            for i in range(sum(c for c in cnt if c > 0)):
+                assert 0 <= out[i].offset and out[i].offset + out[i].nbytes <= len(bad)
+    for trial in range(200):
+        rc, _, _ = _scan(lib, rng.integers(0, 256, size=2000, dtype=np.uint8).tobytes(), keys)
+        assert rc != 0
+
+
+def test_chunks_outside_the_library_readers_subset_take_the_ordinary_path(tmp_path):
+    """parse_chunk un-pickles what gem_chunk_open declines -- protocol 2, a heat-map list that is one array, ragged small arrays --
+    and reports the same dense arrays either way."""
+    import pickle
+    from globalegomocap_amd import whole_sequence as ws
+    data = synth.make_sequence(n_frames=14, seed=5)
+    ref = np.asarray(data["heatmap_list"], dtype=np.float32)
+    full = synth.reference_pickle_dict(data)
+    d = tmp_path / "c"
+    d.mkdir()
+    for tag, obj, proto in (("native", full, None), ("proto2", full, 2), ("one_array", dict(full, heatmap_list=ref), 4),
+                            ("f64", dict(full, heatmap_list=[h.astype(np.float64) for h in full["heatmap_list"]]), 4)):
+        with open(d / "test_data.pkl", "wb") as f:
+            pickle.dump(obj, f) if proto is None else pickle.dump(obj, f, protocol=proto)
+        q = ws.parse_chunk(str(d))
+        assert ("heat_offsets" in q) == (tag in ("native", "f64")) and ("heat_list" in q) != ("heat_offsets" in q), tag
+        assert q["n"] == 14 and tuple(q["heat_shape"]) == (64, 64, 15)
+        c = ws.load_chunk(str(d))                          # (host arrays: always the ordinary way)
+        assert np.array_equal(c["heat"], ref) and c["heat"].dtype == np.float32, tag
+        for k, name in (("est_local", "estimated_local_skeleton"), ("gt", "gt_global_skeleton"), ("cams", "camera_pose_list")):
+            assert np.array_equal(c[k], np.asarray(data[name])) and np.array_equal(q[k], c[k]), (tag, k)
 
 
 def test_slam_trajectory_conversion_against_reference_golden(golden):

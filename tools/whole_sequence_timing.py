@@ -34,49 +34,59 @@ else:
     sd_g, _ = bench.fit_weights(shape, 102, dev, 2000, True)
 
 root = tempfile.mkdtemp(prefix="gem_seq_")
-seq = synth.make_sequence_device(2000, 1000, dev, cam, cam_jitter=bench.CAM_JITTER)
-heat = seq["heat"].cpu().numpy()
-for c in range(20):
-    sl = slice(c * 100, (c + 1) * 100)
-    d = os.path.join(root, "chunk_%d" % c)
-    os.makedirs(d)
-    with open(os.path.join(d, "test_data.pkl"), "wb") as f:
-        pickle.dump({"estimated_local_skeleton": list(seq["est_local_np"][sl]), "gt_global_skeleton": list(seq["gt_global"][sl]),
-                     "camera_pose_list": list(seq["cams_np"][sl]), "heatmap_list": list(heat[sl])}, f, protocol=4)
-size_mb = sum(os.path.getsize(os.path.join(root, d, "test_data.pkl")) for d in os.listdir(root)) / 1e6
+order = os.environ.get("GEM_WS_ORDER", "F")            # F: the reference's files (loadmat's Fortran order); C: C-ordered lists
+hdt = np.float64 if os.environ.get("GEM_WS_F64") else np.float32
+dirs = []
+for si in range(3):
+    seq = synth.make_sequence_device(2000, 1000 + si, dev, cam, cam_jitter=bench.CAM_JITTER)
+    heat = seq["heat"].cpu().numpy()
+    dirs.append(os.path.join(root, "seq_%d" % si))
+    for c in range(20):
+        sl = slice(c * 100, (c + 1) * 100)
+        d = os.path.join(dirs[-1], "chunk_%d" % c)
+        os.makedirs(d)
+        obj = synth.reference_pickle_dict({"estimated_local_skeleton": seq["est_local_np"][sl], "gt_global_skeleton": seq["gt_global"][sl],
+                                           "camera_pose_list": seq["cams_np"][sl], "heatmap_list": heat[sl]}, heat_dtype=hdt)
+        if order == "C":
+            obj["heatmap_list"] = [np.ascontiguousarray(h) for h in obj["heatmap_list"]]
+        with open(os.path.join(d, "test_data.pkl"), "wb") as f:
+            pickle.dump(obj, f)
+size_mb = sum(os.path.getsize(os.path.join(dirs[0], d, "test_data.pkl")) for d in os.listdir(dirs[0])) / 1e6
 
 opt = SequenceOptimizer(DEFAULT_CALIBRATION, sd_g, sd_l, max_windows=240)
-print("pickles: %.0f MB in 20 chunks" % size_mb)
-for tag, sidecar, cpb in (("pickles only (sidecar=False)", False, None), ("raw-array cache (sidecar=True, warm), one batch", True, None),
-                          ("raw-array cache, 2 batches of 10 chunks (reads overlap the device)", True, 10),
-                          ("raw-array cache, 4 batches of 5 chunks", True, 5)):
-    ws.optimize_directory(root, DEFAULT_CALIBRATION, optimizer=opt, verbose=False, sidecar=sidecar, chunks_per_batch=cpb)      # warm-up
+print("pickles: %.0f MB in 20 chunks per sequence, heat-maps %s-ordered %s" % (size_mb, order, hdt.__name__))
+for tag, fn, nw in (("one sequence (optimize_directory)", lambda tm: ws.optimize_directory(dirs[0], DEFAULT_CALIBRATION, optimizer=opt, verbose=False, timings=tm), 240),
+                    ("one sequence, 2 batches of 10 chunks", lambda tm: ws.optimize_directory(dirs[0], DEFAULT_CALIBRATION, optimizer=opt, verbose=False, timings=tm, chunks_per_batch=10), 240),
+                    ("three sequences pipelined (optimize_sequences per_sequence)", lambda tm: ws.optimize_sequences(dirs, DEFAULT_CALIBRATION, optimizer=opt, verbose=False, timings=tm, per_sequence=True), 720)):
+    fn(None)      # warm-up
     torch.cuda.synchronize()
     t_read = time.perf_counter()
-    chunks = list(ws.ChunkStream(ws.list_chunks(root), device=dev, sidecar=sidecar))
+    chunks = list(ws.ChunkStream(ws.list_chunks(dirs[0]), device=dev, depth=20))
     torch.cuda.synchronize()
     t_read = time.perf_counter() - t_read
     del chunks
     runs = []
-    for _ in range(7):
+    for _ in range(9):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         tm = {}
-        summary = ws.optimize_directory(root, DEFAULT_CALIBRATION, optimizer=opt, verbose=False, sidecar=sidecar, chunks_per_batch=cpb, timings=tm)[0]
+        res = fn(tm)
         torch.cuda.synchronize()
         runs.append(time.perf_counter() - t0)
         if runs[-1] == min(runs):
             best_tm = tm
     best = min(runs)
-    print("   phases of the best run (ms):", {k: round(v * 1e3, 1) for k, v in best_tm.items()})
-    print("%s: reading + upload alone %.1f ms; optimize_directory end to end %.1f ms (best of 7; %s) = %.0f windows/s host-inclusive; "
-          "optimized_global_mpjpe %.2f mm" % (tag, t_read * 1e3, best * 1e3, ", ".join("%.1f" % (r * 1e3) for r in runs), 240 / best,
+    summary = res[0] if isinstance(res, tuple) else res[0][0]
+    print("   phases of the best run (ms):", {k: round(v * 1e3, 2) for k, v in best_tm.items() if not k.startswith("_")})
+    print("   main thread's log of the best run (ms since the call began):", best_tm.get("_log"))
+    print("%s: reading + upload of one sequence alone %.1f ms; end to end %.1f ms (best of 9; %s) = %.0f windows/s host-inclusive; "
+          "optimized_global_mpjpe %.2f mm" % (tag, t_read * 1e3, best * 1e3, ", ".join("%.1f" % (r * 1e3) for r in runs), nw / best,
                                                summary["optimized_global_mpjpe"] * 1e3))
 if os.environ.get("GEM_WS_PROFILE"):
     import cProfile, pstats
     pr = cProfile.Profile()
     pr.enable()
-    ws.optimize_directory(root, DEFAULT_CALIBRATION, optimizer=opt, verbose=False)
+    ws.optimize_directory(dirs[0], DEFAULT_CALIBRATION, optimizer=opt, verbose=False)
     torch.cuda.synchronize()
     pr.disable()
     pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
