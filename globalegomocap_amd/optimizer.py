@@ -237,12 +237,15 @@ def main(data_id, camera_model_path, vae_weight, gmm_weight, smoothness_weight, 
         from .sequence import final_smooth as _smooth
         final_optimized_seq = _smooth(final_optimized_seq)
     if save_pose:
+        # optimizer.py:469-483: out/<dataset>/<sequence>/result_pose.pkl under the working directory, the four sequences in the
+        # containers the reference pickles (merge_batches' lists of [15,3] frames; the optimised one an ndarray after the smoothing)
         dataset_dir, seq_name = os.path.split(data_id)
         out_dir = "out/{}/{}".format(os.path.split(dataset_dir)[1], seq_name)
         os.makedirs(out_dir, exist_ok=True)
         with open(os.path.join(out_dir, "result_pose.pkl"), "wb") as f:
-            pickle.dump({"estimated_pose": final_estimated_seq, "optimized_pose": final_optimized_seq,
-                         "mid_optimized_pose": mid_estimated_seq, "gt_pose": final_gt_seq}, f)
+            pickle.dump({"estimated_pose": list(final_estimated_seq),
+                         "optimized_pose": final_optimized_seq if final_smooth is True else list(np.asarray(final_optimized_seq)),
+                         "mid_optimized_pose": list(mid_estimated_seq), "gt_pose": list(final_gt_seq)}, f)
     if device_metrics:
         errors = opt.engine.calculate_errors(final_estimated_seq, mid_estimated_seq, final_optimized_d, final_gt_seq)
     else:

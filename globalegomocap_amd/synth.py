@@ -67,31 +67,62 @@ def make_cameras(n_frames, step=0.004):
     return cams
 
 
-def jitter_cameras(cams, rng, rot_deg, trans_m):
+def jitter_cameras(cams, rng, rot_deg, trans_m, scale=None):
     """SLAM-like estimation noise: an independent small rotation (axis-angle, sigma rot_deg) and
     translation offset (sigma trans_m) per frame.  The optimiser is given these noisy cameras while the
-    ground truth uses the true ones, like OpenVSLAM trajectories vs mocap in the reference's data."""
+    ground truth uses the true ones, like OpenVSLAM trajectories vs mocap in the reference's data.
+    scale [n]: per-frame factor on both sigmas (an `activity_profile`)."""
     from scipy.spatial.transform import Rotation
     n = cams.shape[0]
     out = cams.copy()
-    R = Rotation.from_rotvec(rng.normal(0.0, np.deg2rad(rot_deg), size=(n, 3))).as_matrix()
+    k = np.ones(n) if scale is None else np.asarray(scale, dtype=np.float64)
+    R = Rotation.from_rotvec(rng.normal(0.0, np.deg2rad(rot_deg), size=(n, 3)) * k[:, None]).as_matrix()
     out[:, :3, :3] = R @ cams[:, :3, :3]
-    out[:, :3, 3] = cams[:, :3, 3] + rng.normal(0.0, trans_m, size=(n, 3))
+    out[:, :3, 3] = cams[:, :3, 3] + rng.normal(0.0, trans_m, size=(n, 3)) * k[:, None]
     return out
 
 
-def make_sequence(n_frames=100, seed=1, camera=None, noise=0.02, sigma=1.5, with_heatmaps=True, cam_jitter=None):
+def activity_profile(n_frames, seed, stretch=(500, 5000), ramp=25, quiet_first=None):
+    """[n_frames] in [0, 1]: a recording that alternates between QUIET stretches (0: the wearer stands still, the estimator and the
+    SLAM trajectory are nearly noise-free -- the optimiser's L-BFGS leaves such windows after a few evaluations,
+    /root/reference/optimizer.py:261-270) and BUSY ones (1: full motion amplitude and noise -- the stages run to their evaluation
+    limit), each `stretch[0] .. stretch[1]` frames long (uniform), with linear ramps of `ramp` frames between them.  What a
+    contiguous shard of a real recording looks like to one GPU: mostly one or the other."""
+    rng = np.random.default_rng(seed)
+    level = np.empty(n_frames)
+    at, busy = 0, bool(rng.integers(2)) if quiet_first is None else not quiet_first
+    while at < n_frames:
+        n = int(rng.integers(stretch[0], stretch[1] + 1))
+        level[at:at + n] = 1.0 if busy else 0.0
+        at, busy = at + n, not busy
+    if ramp > 1:
+        k = np.ones(ramp) / ramp
+        level = np.convolve(np.pad(level, (ramp // 2, ramp - 1 - ramp // 2), mode="edge"), k, mode="valid")
+    return level
+
+
+def make_sequence(n_frames=100, seed=1, camera=None, noise=0.02, sigma=1.5, with_heatmaps=True, cam_jitter=None, activity=None,
+                  quiet_level=0.02):
     """Synthetic `test_data.pkl` content (numpy float64 poses/cams, float32 heat-maps).
-    cam_jitter=(rot_deg, trans_m) adds SLAM-like noise to `camera_pose_list` (not to the ground truth)."""
+    cam_jitter=(rot_deg, trans_m) adds SLAM-like noise to `camera_pose_list` (not to the ground truth).
+    activity [n_frames] in [0, 1] (`activity_profile`): motion amplitude, estimator noise and camera noise of every frame are
+    scaled by quiet_level + (1 - quiet_level) * activity, and the heat-maps' peak by the activity itself -- in a quiet stretch
+    the wearer stands still and the 2-D detector sees nothing (blank heat-maps: the reprojection term of optimizer.py:139-149
+    contributes nothing there and the local stage's L-BFGS leaves after a few evaluations), next to busy stretches that use
+    every evaluation.  The per-frame peak is returned as `heatmap_scale` (not in the reference pickle)."""
     cam = camera or FisheyeCamera.from_json(DEFAULT_CALIBRATION)
     rng = np.random.default_rng(seed)
     clean = make_motion(n_frames, rng)
-    est = clean + rng.normal(0.0, noise, size=clean.shape)
+    level = None
+    if activity is not None:
+        level = quiet_level + (1.0 - quiet_level) * np.asarray(activity, dtype=np.float64)[:n_frames]
+        clean = rest_skeleton()[None] + level[:, None, None] * (clean - rest_skeleton()[None])
+    est = clean + rng.normal(0.0, noise, size=clean.shape) * (1.0 if level is None else level[:, None, None])
     cams = make_cameras(n_frames)
     homo = np.concatenate([clean, np.ones(clean.shape[:2] + (1,))], axis=-1)
     gt_global = np.einsum("nij,nkj->nki", cams, homo)[..., :3]
     if cam_jitter is not None:
-        cams = jitter_cameras(cams, rng, *cam_jitter)
+        cams = jitter_cameras(cams, rng, *cam_jitter, scale=level)
     out = {
         "estimated_local_skeleton": [p for p in est],
         "gt_global_skeleton": [p for p in gt_global],
@@ -100,8 +131,12 @@ def make_sequence(n_frames=100, seed=1, camera=None, noise=0.02, sigma=1.5, with
     uv = cam.project_numpy(clean.reshape(-1, 3)).reshape(n_frames, N_JOINTS, 2)
     ix, iy = heatmap_coords(uv)
     out["heatmap_centres"] = np.stack([ix, iy], axis=-1)          # not in the reference pickle
+    out["heatmap_scale"] = np.ones(n_frames) if activity is None else np.asarray(activity, dtype=np.float64)[:n_frames].copy()
     if with_heatmaps:
-        out["heatmap_list"] = [h for h in gaussian_heatmaps(ix, iy, sigma=sigma)]
+        hm = gaussian_heatmaps(ix, iy, sigma=sigma)
+        if activity is not None:
+            hm = hm * out["heatmap_scale"][:, None, None, None].astype(np.float32)
+        out["heatmap_list"] = [h for h in hm]
     return out
 
 
@@ -176,10 +211,11 @@ def make_stream_device(n_frames, seed, device, runs=None, camera=None, noise=0.0
     heat = torch.empty(n, HEATMAP_SIZE, HEATMAP_SIZE, N_JOINTS, dtype=torch.float32, device=device)
     ys = torch.arange(HEATMAP_SIZE, dtype=torch.float32, device=device)[None, :, None, None]
     xs = torch.arange(HEATMAP_SIZE, dtype=torch.float32, device=device)[None, None, :, None]
+    peak = torch.as_tensor(np.asarray(seq.get("heatmap_scale", np.ones(n_frames)))[keep], dtype=torch.float32, device=device)
     for a in range(0, n, block):
         c = cen[a:a + block]
         d2 = (xs - c[:, None, None, :, 0]) ** 2 + (ys - c[:, None, None, :, 1]) ** 2
-        heat[a:a + block] = torch.exp(-d2 / (2.0 * sigma * sigma))
+        heat[a:a + block] = torch.exp(-d2 / (2.0 * sigma * sigma)) * peak[a:a + block, None, None, None]
     return {"est_local": torch.as_tensor(est, dtype=torch.float32, device=device).contiguous(),
             "cams": torch.as_tensor(cams, dtype=torch.float64, device=device).contiguous(), "heat": heat,
             "gt_global": np.asarray(seq["gt_global_skeleton"]), "est_all_np": np.asarray(seq["estimated_local_skeleton"]), "frames": keep}

@@ -131,3 +131,39 @@ def check_full_training_step(c, losses, grads, params, running, loss_rtol, grad_
     for k, v in c["final"].items():
         d = np.abs(np.asarray(running[k], np.float64) - v).max()
         assert d <= 1e-5 * max(1.0, float(np.abs(v).max())) + (4 * c["lr"] if k.endswith("running_mean") else 0.0), (k, d)
+
+
+def device_identity():
+    """Which card ran a GPU test: what torch knows (name, gcnArchName, PCI address, uuid) plus rocm-smi's unique id and firmware
+    versions read through a fresh child process.  Goes into the records the determinism tests leave behind."""
+    import subprocess
+    import torch
+    p = torch.cuda.get_device_properties(0)
+    ident = {"name": p.name, "gcnArchName": getattr(p, "gcnArchName", None),
+             "pci": "%04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", 0), getattr(p, "pci_device_id", 0)),
+             "uuid": str(getattr(p, "uuid", "")), "multi_processor_count": p.multi_processor_count, "hip": torch.version.hip}
+    try:
+        r = subprocess.run(["rocm-smi", "--showuniqueid", "--showfw", "--csv"], capture_output=True, text=True, timeout=60)
+        ident["rocm_smi"] = [l for l in r.stdout.splitlines() if l.strip()][:6]
+    except Exception as e:          # noqa: BLE001  (no rocm-smi on the box: the torch fields stand alone)
+        ident["rocm_smi"] = repr(e)
+    return ident
+
+
+def record_observation(name, payload):
+    """Prints a one-line JSON record of a GPU test's observation (so that the test log carries it) and leaves it under
+    gpurun_out/observations/ (merged back from the GPU box)."""
+    import json
+    import os
+    import time
+    rec = dict(payload, test=name, device=device_identity(), unix_time=int(time.time()))
+    line = json.dumps(rec, sort_keys=True, default=str)
+    print("OBSERVATION " + line)
+    try:
+        d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "observations")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "%s_%d.json" % (name, rec["unix_time"])), "w") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass
+    return rec

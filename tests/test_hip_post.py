@@ -371,6 +371,41 @@ def test_main_returns_the_reference_container_types(golden, tmp_path):
             assert isinstance(opt, list) and len(opt) == 98 and opt[0].shape == (15, 3) and opt[0].dtype == np.float64
 
 
+def test_save_pose_writes_the_reference_result_pickle(golden, tmp_path, monkeypatch):
+    """main(..., save_pose=True) (/root/reference/optimizer.py:469-483): `out/<dataset>/<sequence>/result_pose.pkl` under the working
+    directory with the keys estimated_pose / optimized_pose / mid_optimized_pose / gt_pose, in the reference's containers, holding
+    the sequences the call returns (mid_optimized_pose is the GLOBAL stage-one sequence the error report's mid_* entries use)."""
+    import pickle
+    import torch
+    from globalegomocap_amd import optimizer as gopt
+    from globalegomocap_amd.errors import mpjpe
+    from helpers import sd_from_npz
+    g, lt = golden("pipeline_tiny"), golden("lbfgs_tiny")
+    data = synth.make_sequence(n_frames=100, seed=int(g["seq_seed"]))
+    d = tmp_path / "studio-x" / "chunk_7"
+    d.mkdir(parents=True)
+    with open(d / "test_data.pkl", "wb") as f:
+        pickle.dump(synth.reference_pickle_dict(data), f)
+    monkeypatch.chdir(tmp_path)
+    for smooth in (True, False):
+        errors, est, mid, opt, gt = gopt.main(str(d), DEFAULT_CALIBRATION, 0.0, 0.0, float(g["smooth"]), 0.01, float(g["weight_3d"]), 0.01,
+                                             final_smooth=smooth, save_pose=True, global_vae_path=sd_from_npz(lt, "global/"),
+                                             local_vae_path=sd_from_npz(lt, "local/"), eps=torch.randn(24, 32, generator=torch.Generator().manual_seed(5)))
+        out = tmp_path / "out" / "studio-x" / "chunk_7" / "result_pose.pkl"
+        assert out.exists()
+        with open(out, "rb") as f:
+            saved = pickle.load(f)
+        assert list(saved) == ["estimated_pose", "optimized_pose", "mid_optimized_pose", "gt_pose"]
+        for k in ("estimated_pose", "mid_optimized_pose", "gt_pose"):
+            assert isinstance(saved[k], list) and len(saved[k]) == 98 and np.asarray(saved[k][0]).shape == (15, 3), k
+        assert isinstance(saved["optimized_pose"], np.ndarray if smooth else list)
+        assert np.array_equal(np.asarray(saved["estimated_pose"]), np.asarray(est)) and np.array_equal(np.asarray(saved["gt_pose"]), np.asarray(gt))
+        assert np.array_equal(np.asarray(saved["optimized_pose"]), np.asarray(opt))
+        assert abs(mpjpe(np.asarray(saved["mid_optimized_pose"]), np.asarray(saved["gt_pose"])) - errors["mid_global_mpjpe"]) < 1e-12
+        assert abs(mpjpe(np.asarray(saved["optimized_pose"]), np.asarray(saved["gt_pose"])) - errors["optimized_global_mpjpe"]) < 1e-12
+        out.unlink()
+
+
 def test_integration_md_reporting_stub_runs_verbatim(engine, golden):
     """The second ctypes block of INTEGRATION.md section 2 (the reporting call a maintainer would put behind
     /root/reference/optimize_whole_sequence.py's calculate_errors, calculate_errors.py:114-179), executed verbatim against the library

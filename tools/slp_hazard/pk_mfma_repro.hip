@@ -33,11 +33,38 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
     X(10, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1]", a[0] + b[1], a[1] + b[1])                                                          \
     X(11, "v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]", a[1], b[0])                                                                        \
     X(12, "v_pk_mov_b32 %0, %1, %2", a[0], b[1])
-constexpr int N_FORMS = 13;
+// Round 6: the other VALU forms of the bf16 tail's energy phase / gradient hand-over that share a data path with the packed ones or
+// write 16-bit halves (candidates for the one-rounding anomaly of round 5): checked against software references
+constexpr int N_PACKED = 13, N_FORMS = 17;
+static const char* const EXTRA_NAMES[N_FORMS - N_PACKED] = {
+    "v_cvt_pk_bf16_f32 (two floats -> one dword of bf16, RNE)", "v_mov_b64 (64-bit VALU move)",
+    "v_mov_b32_dpp row_shr:1 (DPP reduction step)", "v_add_f64 (fp64 sum, against a copy made before the loop)"};
+
+__device__ __forceinline__ unsigned bf16_rne(float f) {          // software round-to-nearest-even, NaN quieted like the hardware
+    unsigned u = __builtin_bit_cast(unsigned, f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
 
 template <int FORM>
 __device__ __forceinline__ f32x2 apply(f32x2 a, f32x2 b, f32x2 c) {
     f32x2 d;
+    if constexpr (FORM == 13) {
+        unsigned r;
+        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a[0]), "v"(b[0]));
+        return f32x2{__builtin_bit_cast(float, r), a[1]};
+    } else if constexpr (FORM == 14) {
+        asm volatile("v_mov_b64 %0, %1" : "=v"(d) : "v"(a));
+        return d;
+    } else if constexpr (FORM == 15) {
+        float r = a[0];
+        asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(r) : "v"(a[0]));
+        return f32x2{r, a[1]};
+    } else if constexpr (FORM == 16) {
+        double x = __builtin_bit_cast(double, a), y = __builtin_bit_cast(double, b), r;
+        asm volatile("v_add_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+        return __builtin_bit_cast(f32x2, r);
+    }
 #define X(id, text, lo, hi)                                                                                 \
     if (FORM == id) asm volatile(text : "=v"(d) : "v"(a), "v"(b), "v"(c));
     FORMS(X)
@@ -46,6 +73,10 @@ __device__ __forceinline__ f32x2 apply(f32x2 a, f32x2 b, f32x2 c) {
 }
 template <int FORM>
 __device__ __forceinline__ f32x2 reference(f32x2 a, f32x2 b, f32x2 c) {
+    if constexpr (FORM == 13) return f32x2{__builtin_bit_cast(float, bf16_rne(a[0]) | (bf16_rne(b[0]) << 16)), a[1]};
+    if constexpr (FORM == 14) return a;
+    if constexpr (FORM == 15) { const float up = __shfl_up(a[0], 1, 64); return f32x2{(threadIdx.x & 15) == 0 ? a[0] : up, a[1]}; }
+    if constexpr (FORM == 16) return apply<16>(a, b, c);          // (taken once, before the loop)
 #define X(id, text, lo, hi) if (FORM == id) return f32x2{lo, hi};
     FORMS(X)
 #undef X
@@ -130,7 +161,7 @@ int main(int argc, char** argv) {
 #define X(id, text, lo, hi) text,
         FORMS(X)
 #undef X
-    };
+        EXTRA_NAMES[0], EXTRA_NAMES[1], EXTRA_NAMES[2], EXTRA_NAMES[3]};
     const char* mnames[4] = {"no matrix waves", "v_mfma_f32_16x16x32_bf16", "v_mfma_f32_32x32x16_bf16", "v_mfma_f32_16x16x4_f32"};
     int any = 0;
     for (int matrix = m_lo; matrix <= m_hi; ++matrix) {
