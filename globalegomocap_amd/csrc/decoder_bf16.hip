@@ -170,7 +170,11 @@ static int gemm_bf16a(gem_handle* h, const Layer& L, int epi, const uint16_t* A,
     if (M <= 0) return 0;
     if (L.K % 64 != 0 || L.N % 64 != 0 || !L.wb_hi) { set_error("gemm_bf16a: layer is not padded to 64 or has no bf16 weights"); return 1; }
     w.deferred = SlabSrc{};
-    const bool bn128 = L.N % 128 == 0;
+    // developer switch (round 6 A/B): the forward front product as 128 x 64 tiles (1) or 128 x 128 tiles (2) over the WHOLE of K, so
+    // that it hands the tail one bf16 activation instead of fp32 split-K slabs
+    const char* ffm = (family == 0 && out_bf16 && epi == EPI_BIAS_LRELU && L.taps == 1) ? dev_env("GEM_FRONT_FWD_MODE") : nullptr;
+    if (ffm && ffm[0] != '0') allow_split = false;
+    const bool bn128 = L.N % 128 == 0 && !(ffm && ffm[0] == '1');
     const int BN = bn128 ? 128 : 64;
     const int tiles = ((M + 127) / 128) * (L.N / BN);
     const int k_tiles = L.taps * (L.K / 64);

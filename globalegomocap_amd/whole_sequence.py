@@ -650,6 +650,7 @@ def optimize_sequences(data_dirs, camera_model_path, vae_weight=0.0, gmm_weight=
         _drain(submitted)
         if any(b.pending is not None for b in batches):
             torch.cuda.synchronize()      # (an exception left device work behind that reads this call's buffers)
+    lap("readers drained")
     out = []
     for gi in range(n_groups):
         summary = OrderedDict()
@@ -665,6 +666,7 @@ def optimize_sequences(data_dirs, camera_model_path, vae_weight=0.0, gmm_weight=
             print("-------------------------------------------------------------")
         # the three pose sequences as arrays [frames,15,3] (iterating them yields the [15,3] frames the reference's lists hold)
         out.append((summary, results[gi]) + tuple(np.concatenate(x) if x else np.empty((0, 15, 3)) for x in (est_all[gi], opt_all[gi], gt_all[gi])))
+    lap("summaries")
     return out
 
 

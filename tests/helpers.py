@@ -156,7 +156,8 @@ def record_observation(name, payload):
     import json
     import os
     import time
-    rec = dict(payload, test=name, device=device_identity(), unix_time=int(time.time()))
+    rec = dict(payload, test=name, device=device_identity(), unix_time=int(time.time()),
+               library=os.path.basename(os.environ.get("GEM_HIP_LIB") or "libgem_hip.so (the product build)"))
     line = json.dumps(rec, sort_keys=True, default=str)
     print("OBSERVATION " + line)
     try:

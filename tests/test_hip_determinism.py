@@ -62,10 +62,10 @@ def test_repeated_evaluations_are_bitwise_identical(windows, precision):
 def test_bf16_tail_instantiations_agree_over_8192_windows_ten_times(monkeypatch):
     """The bf16 tail with 2 row tiles per workgroup (3 windows, two workgroups per CU) against 5 row tiles (8 windows, one energy
     trip per window group more): the same 8192 windows evaluated TEN times by each, alternating -- energies, parts and poses must
-    agree bit for bit between the two and from repeat to repeat; for dE/dz the test records how many windows differ between the
-    instantiations (round 5 saw one rounding of one window's gradient fall the other way for some 45 minutes, then never again:
-    DESIGN.md section 5) and asserts that each instantiation repeats itself bit for bit and that the two stay within one bf16
-    rounding of one another."""
+    agree bit for bit between the two and from repeat to repeat, dE/dz included (round 5 saw one rounding of one window's gradient
+    fall the other way: the compiler's fused-multiply-add choice under -ffp-contract=fast differed between the instantiations;
+    the library is built with -ffp-contract=on since round 6).  What is seen is recorded with the card's
+    identity either way."""
     import torch
     from globalegomocap_amd import vae as V
     from globalegomocap_amd.engine import WindowEngine, energy_weights
@@ -109,7 +109,7 @@ def test_bf16_tail_instantiations_agree_over_8192_windows_ten_times(monkeypatch)
                                                           "bitwise": all(r["windows_differing"] == 0 for r in per_repeat)})
         assert self_repeats[2] and self_repeats[5], self_repeats
         for r in per_repeat:
-            assert r["windows_differing"] <= 0.005 * windows and r["max_abs_over_largest"] <= 4e-6, r
+            assert r["windows_differing"] == 0, r
     finally:
         eng.close()
 

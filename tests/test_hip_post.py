@@ -283,6 +283,37 @@ def test_equal_chunks_take_the_vectorised_report_path_and_the_batch_pipeline(gol
     assert np.array_equal(np.asarray(runs[0][3]), np.asarray(runs[3][3]))
 
 
+def test_a_broken_chunk_in_a_later_batch_surfaces_and_leaves_the_pipeline_usable(golden, tmp_path):
+    """Batches are in flight three deep (files arriving, on the device, being reported): a chunk without `camera_pose_list` in the
+    THIRD batch must surface as the reference's KeyError (optimizer.py:322) after the earlier batches' device work has been
+    waited for, and the next call must run as if nothing had happened."""
+    import pickle
+    import torch
+    from globalegomocap_amd import whole_sequence as ws
+    from helpers import sd_from_npz
+    lt = golden("lbfgs_tiny")
+    kw = dict(global_vae_path=sd_from_npz(lt, "global/"), local_vae_path=sd_from_npz(lt, "local/"))
+    good, bad = tmp_path / "good", tmp_path / "bad"
+    for root in (good, bad):
+        for i in range(4):
+            d = root / ("chunk_%d" % i)
+            d.mkdir(parents=True)
+            obj = synth.reference_pickle_dict(synth.make_sequence(n_frames=100, seed=90 + i))
+            if root is bad and i == 2:
+                del obj["camera_pose_list"]
+            with open(d / "test_data.pkl", "wb") as f:
+                pickle.dump(obj, f)
+    torch.manual_seed(3)
+    first = ws.optimize_directory(str(good), DEFAULT_CALIBRATION, verbose=False, chunks_per_batch=1, **kw)
+    with pytest.raises(KeyError, match="camera_pose_list"):
+        ws.optimize_directory(str(bad), DEFAULT_CALIBRATION, verbose=False, chunks_per_batch=1, **kw)
+    with pytest.raises(FileNotFoundError):
+        ws.optimize_directory(str(tmp_path / "nowhere"), DEFAULT_CALIBRATION, verbose=False, **kw)
+    torch.manual_seed(3)
+    again = ws.optimize_directory(str(good), DEFAULT_CALIBRATION, verbose=False, chunks_per_batch=1, **kw)
+    assert np.array_equal(first[3], again[3]) and len(again[1]) == 4
+
+
 # ------------------------------------------------------------------------------------------------ INTEGRATION.md, executed
 def test_integration_md_ctypes_stub_runs_verbatim():
     """The reference-side ctypes stub of INTEGRATION.md section 2 (what a maintainer would paste into
