@@ -122,6 +122,7 @@ def parse_chunk(path, native=True):
 
 
 N_COPY_STREAMS = int(os.environ.get("GEM_WS_STREAMS", 2))
+STREAM_PRIORITY = int(os.environ.get("GEM_WS_PRIORITY", 0))          # (0 = torch's default pool; -1 measured the same: tools/r06_stream_prio.sh)
 _copy_streams = {}
 _report_streams = {}
 _copy_lock = threading.Lock()
@@ -136,7 +137,7 @@ def copy_stream(device):
     with _copy_lock:
         st = _copy_streams.setdefault(device, [[], 0])
         if len(st[0]) < N_COPY_STREAMS:
-            st[0].append(torch.cuda.Stream(device=device))
+            st[0].append(torch.cuda.Stream(device=device, priority=STREAM_PRIORITY))
         st[1] += 1
         return st[0][(st[1] - 1) % len(st[0])]
 
@@ -563,7 +564,7 @@ def optimize_sequences(data_dirs, camera_model_path, vae_weight=0.0, gmm_weight=
         # behind the next batch's whole device call, which is already enqueued there
         rs = _report_streams.get(device)
         if rs is None:
-            rs = _report_streams[device] = torch.cuda.Stream(device=device)
+            rs = _report_streams[device] = torch.cuda.Stream(device=device, priority=STREAM_PRIORITY)
         rs.wait_event(b.done)
         for t in b.pending:
             if t is not None:

@@ -437,6 +437,40 @@ def test_save_pose_writes_the_reference_result_pickle(golden, tmp_path, monkeypa
         out.unlink()
 
 
+def test_integration_md_chunk_reader_stub_runs_verbatim(tmp_path):
+    """The chunk-reader stub of INTEGRATION.md section 2 (what replaces pickle.load + np.asarray(heatmap_list) + .float() at
+    /root/reference/optimizer.py:315-324,248), extracted from the markdown and executed VERBATIM -- its own CDLL handle and struct
+    mirror -- on a file written the way the reference's tool writes it; its `heat` and `est` must be exactly what the reference's
+    three lines produce."""
+    import ctypes as C
+    import pickle
+    import re
+    import torch
+    md = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", md, flags=re.S)
+    stub = next(b for b in blocks if "gem_chunk_open" in b)
+    head = next(b for b in blocks if "lib = C.CDLL(" in b).split("class Cfg")[0]          # the CDLL line of the first stub
+    data = synth.make_sequence(n_frames=40, seed=12)
+    d = tmp_path / "chunk_0"
+    d.mkdir()
+    with open(d / "test_data.pkl", "wb") as f:
+        pickle.dump(synth.reference_pickle_dict(data), f)
+    env = {"C": C, "np": np, "torch": torch, "path": str(d / "test_data.pkl")}
+    cwd = os.getcwd()
+    os.chdir(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        exec(head, env)
+        exec(stub, env)
+    finally:
+        os.chdir(cwd)
+    torch.cuda.synchronize()
+    with open(d / "test_data.pkl", "rb") as f:
+        ref = pickle.load(f)
+    assert np.array_equal(env["heat"].cpu().numpy(), torch.from_numpy(np.asarray(ref["heatmap_list"])).float().numpy())
+    assert np.array_equal(env["est"], np.asarray(ref["estimated_local_skeleton"]))
+    assert env["n"] == 40 and list(env["info"])[:4] == [40, 3, 0, 1]          # 40 arrays, 3-D, float32, Fortran order
+
+
 def test_integration_md_reporting_stub_runs_verbatim(engine, golden):
     """The second ctypes block of INTEGRATION.md section 2 (the reporting call a maintainer would put behind
     /root/reference/optimize_whole_sequence.py's calculate_errors, calculate_errors.py:114-179), executed verbatim against the library

@@ -53,6 +53,7 @@ for si in range(3):
             pickle.dump(obj, f)
 size_mb = sum(os.path.getsize(os.path.join(dirs[0], d, "test_data.pkl")) for d in os.listdir(dirs[0])) / 1e6
 
+_burnt = [torch.cuda.Stream() for _ in range(int(os.environ.get("GEM_WS_BURN_STREAMS", 0)))]      # (experiment: other users of torch's stream pool before us)
 opt = SequenceOptimizer(DEFAULT_CALIBRATION, sd_g, sd_l, max_windows=240)
 print("pickles: %.0f MB in 20 chunks per sequence, heat-maps %s-ordered %s" % (size_mb, order, hdt.__name__))
 for tag, fn, nw in (("one sequence (optimize_directory)", lambda tm: ws.optimize_directory(dirs[0], DEFAULT_CALIBRATION, optimizer=opt, verbose=False, timings=tm), 240),
