@@ -3,7 +3,7 @@
 # of the default bench command (BASELINE configs[1], fp32) and of the bf16 decoder mode at configs[2] / configs[3] sizes.
 #   gpurun --timeout 1200 -- 'bash tools/collect_profiles.sh r04'
 set -o pipefail
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=gpurun_out/${TAG}p
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p $OUT
@@ -28,6 +28,13 @@ run bf16_8192/pmc_mfma  "--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_
 run bf16_1536/pmc_fetch "--pmc FETCH_SIZE"       "--steps 2 --warmup 1 --workload 128 --precision bf16 --no-profile"
 run bf16_1536/pmc_write "--pmc WRITE_SIZE"       "--steps 2 --warmup 1 --workload 128 --precision bf16 --no-profile"
 run bf16_1536/pmc_mfma  "--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "--steps 2 --warmup 1 --workload 128 --precision bf16 --no-profile"
+# fourth counter pass (round 6, bf16 only): how full the chip is and what the waves wait for -- lbfgs_advance reaches 0.68 of HBM at 8192
+# windows and 0.48 at 1536 (wave counts, resident wave-cycles, busy cycles, cycles waiting for any instruction to issue)
+for d in bf16_1536 bf16_8192; do
+  wl=$([ $d = bf16_1536 ] && echo 128 || echo w8192x)
+  mkdir -p $OUT/$d
+  rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $OUT/$d/pmc_occ -- python bench.py --steps 1 --warmup 1 --workload $wl --precision bf16 --no-profile $COMMON > $OUT/$d/pmc_occ.log 2>&1 || echo "pmc_occ $d failed (not fatal)"
+done
 # fp32 at configs[2] size (the LDS-DMA fp32 kernel takes over the decoder_input products)
 run f32_1536/trace      "--kernel-trace --stats" "--steps 3 --warmup 1 --workload 128"
 run f32_1536/pmc_fetch  "--pmc FETCH_SIZE"       "--steps 2 --warmup 1 --workload 128 --no-profile"
@@ -43,7 +50,7 @@ grep "^B=" $OUT/train1024/trace.log
 # keep the summaries small: per-dispatch traces are dropped, the stats / counter tables stay
 find $OUT -name '*_kernel_trace.csv' -delete
 for d in f32 bf16_8192 bf16_1536 f32_1536; do
-  for k in pmc_fetch pmc_write pmc_mfma; do
+  for k in pmc_fetch pmc_write pmc_mfma pmc_occ; do
     f=$(find $OUT/$d/$k -name '*counter_collection.csv' | head -1)
     [ -n "$f" ] && python - "$f" <<'PY'
 import csv, sys, collections

@@ -138,3 +138,31 @@ if b:
     for k, v in b["kernels"].items():
         if "glds" in k or "big" in k or "lbfgs" in k or "energy" in k or "tail" in k:
             print(k, v)
+
+
+def occupancy(sub, out_name):
+    """round 6: the wave-occupancy pass (SQ_WAVES, SQ_WAVE_CYCLES, SQ_BUSY_CYCLES, SQ_WAIT_INST_ANY) per kernel, means over dispatches"""
+    f = newest(glob.glob(os.path.join(src, sub, "pmc_occ", "*", "*counter_summary.csv")))
+    if not f:
+        return
+    m = {}
+    for r in csv.DictReader(open(f[0])):
+        k = short(r["kernel"])
+        if k.startswith("gem::"):
+            m.setdefault(k, {"dispatches": int(r["dispatches"])})[r["counter"]] = round(float(r["mean_value"]))
+    for k, v in m.items():
+        if v.get("SQ_BUSY_CYCLES") and v.get("SQ_WAVE_CYCLES"):
+            v["resident_waves_per_busy_cycle"] = round(v["SQ_WAVE_CYCLES"] / v["SQ_BUSY_CYCLES"], 2)
+        if v.get("SQ_WAVE_CYCLES") and v.get("SQ_WAIT_INST_ANY") is not None:
+            v["wave_cycles_waiting_frac"] = round(v["SQ_WAIT_INST_ANY"] / v["SQ_WAVE_CYCLES"], 3)
+    json.dump({"note": "rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY (a pass of its own); counters summed over the chip's "
+                       "shader engines as rocprofv3 reports them, means over a kernel's dispatches; resident_waves_per_busy_cycle = SQ_WAVE_CYCLES / "
+                       "SQ_BUSY_CYCLES, wave_cycles_waiting_frac = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES", "kernels": m},
+              open(os.path.join(dst, out_name), "w"), indent=1)
+    for k in m:
+        if "lbfgs" in k or "tail" in k:
+            print(sub, k, m[k])
+
+
+occupancy("bf16_1536", "occupancy_%s_bf16_1536_windows.json" % tag)
+occupancy("bf16_8192", "occupancy_%s_bf16_8192_windows.json" % tag)
