@@ -675,18 +675,32 @@ def main():
         root_dir = tempfile.mkdtemp(prefix="gem_bench_seq_")
         try:
             seq_dirs = []
-            for si in range(3):
-                sq = seqd if si == 0 else synth.make_sequence_device(n_frames, seed=1500 + si, device=device, camera=cam, cam_jitter=CAM_JITTER)
-                heat_np = sq["heat"].cpu().numpy()
-                seq_dirs.append(os.path.join(root_dir, "seq_%d" % si))
-                for c in range(n_chunks):
-                    sl = slice(c * CHUNK, (c + 1) * CHUNK)
-                    dch = os.path.join(seq_dirs[-1], "chunk_%d" % c)
-                    os.makedirs(dch)
-                    with open(os.path.join(dch, "test_data.pkl"), "wb") as f:
-                        pickle.dump(synth.reference_pickle_dict({"estimated_local_skeleton": sq["est_local_np"][sl], "gt_global_skeleton": sq["gt_global"][sl],
-                                                                 "camera_pose_list": sq["cams_np"][sl], "heatmap_list": heat_np[sl]}), f)
-                del heat_np, sq
+
+            def write_sequences():
+                # (written from a thread on the NUMA node of the GPU's PCIe root: that is where the page cache of files READ from
+                # disk by the library's node-confined readers ends up; files written here from an arbitrary CPU may sit on the other
+                # socket, which costs the read + host-to-device pipeline 14.5 instead of 10.4 ms -- tools/r06_numa_probe.py)
+                near = ws_mod.cpus_near(device)
+                if near:
+                    os.sched_setaffinity(0, near)
+                for si in range(3):
+                    sq = seqd if si == 0 else synth.make_sequence_device(n_frames, seed=1500 + si, device=device, camera=cam, cam_jitter=CAM_JITTER)
+                    heat_np = sq["heat"].cpu().numpy()
+                    seq_dirs.append(os.path.join(root_dir, "seq_%d" % si))
+                    for c in range(n_chunks):
+                        sl = slice(c * CHUNK, (c + 1) * CHUNK)
+                        dch = os.path.join(seq_dirs[-1], "chunk_%d" % c)
+                        os.makedirs(dch)
+                        with open(os.path.join(dch, "test_data.pkl"), "wb") as f:
+                            pickle.dump(synth.reference_pickle_dict({"estimated_local_skeleton": sq["est_local_np"][sl], "gt_global_skeleton": sq["gt_global"][sl],
+                                                                     "camera_pose_list": sq["cams_np"][sl], "heatmap_list": heat_np[sl]}), f)
+                    del heat_np, sq
+            import threading
+            wt = threading.Thread(target=write_sequences)
+            wt.start()
+            wt.join()
+            if len(seq_dirs) != 3:
+                raise RuntimeError("writing the bench's chunk directories failed")
             opt = SequenceOptimizer(DEFAULT_CALIBRATION, sd_global, sd_local, max_windows=B)
             host_inclusive = {"frames": int(n_frames), "windows": int(B), "pickle_bytes": int(sum(
                 os.path.getsize(os.path.join(seq_dirs[0], dn, "test_data.pkl")) for dn in os.listdir(seq_dirs[0]))),
@@ -704,25 +718,30 @@ def main():
             host_inclusive["pcie_floor_ms"] = round(min(t_h2d) * 1e3, 2)          # one pinned copy of the same number of bytes: what the link alone takes
 
             def timed(fn, n_windows, reps):
-                fn()                                                               # warm-up (pools, buffers)
-                best, res = None, None
+                fn(None)                                                           # warm-up (pools, buffers)
+                best, res, log = None, None, None
                 for _ in range(reps):
+                    tm = {}
                     torch.cuda.synchronize()
                     th = time.perf_counter()
-                    res = fn()
+                    res = fn(tm)
                     torch.cuda.synchronize()
                     dtw = time.perf_counter() - th
-                    best = dtw if best is None else min(best, dtw)
-                return {"ms_end_to_end": round(best * 1e3, 2), "windows_per_s": round(n_windows / best, 1)}, res
-            rec, res = timed(lambda: ws_mod.optimize_directory(seq_dirs[0], DEFAULT_CALIBRATION, optimizer=opt, verbose=False), B, 5)
+                    if best is None or dtw < best:
+                        best, log = dtw, tm.get("_log")
+                return {"ms_end_to_end": round(best * 1e3, 2), "windows_per_s": round(n_windows / best, 1),
+                        "main_thread_timeline_ms": [[t_, name] for t_, name in (log or []) if not name.startswith("run:")]}, res
+            import gc
+            gc.collect()
+            rec, res = timed(lambda tm: ws_mod.optimize_directory(seq_dirs[0], DEFAULT_CALIBRATION, optimizer=opt, verbose=False, timings=tm), B, 7)
             rec["optimized_global_mpjpe_mm"] = round(float(res[0]["optimized_global_mpjpe"]) * 1e3, 3)
             host_inclusive["pickles_only"] = rec
-            rec, res = timed(lambda: ws_mod.optimize_sequences(seq_dirs, DEFAULT_CALIBRATION, optimizer=opt, verbose=False, per_sequence=True), 3 * B, 5)
+            rec, res = timed(lambda tm: ws_mod.optimize_sequences(seq_dirs, DEFAULT_CALIBRATION, optimizer=opt, verbose=False, per_sequence=True, timings=tm), 3 * B, 7)
             rec["optimized_global_mpjpe_mm"] = [round(float(r[0]["optimized_global_mpjpe"]) * 1e3, 3) for r in res]
             rec["floor_windows_per_s"] = round(3 * B / (3 * host_inclusive["pcie_floor_ms"] * 1e-3 + elapsed / a.steps), 1)
             host_inclusive["three_sequences_pipelined"] = rec
             host_inclusive["what"] = ("whole_sequence.optimize_directory (the reference's optimize_whole_sequence.py:48-118) on 20 chunk directories, page-cached "
-                                      "files, best of 5 calls: read + host-to-device + optimise + device merge / report, nothing cached next to the data; "
+                                      "files, best of 7 calls: read + host-to-device + optimise + device merge / report, nothing cached next to the data; "
                                       "three_sequences_pipelined = optimize_sequences(per_sequence=True) on three such directories (720 windows): one device call "
                                       "per sequence, the next sequence's files cross PCIe meanwhile; floor = 3 x pcie_floor_ms + one resident step, nothing else")
             opt.engine.close()

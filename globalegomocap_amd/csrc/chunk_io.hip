@@ -387,26 +387,32 @@ __global__ __launch_bounds__(256) void heat_copy_kernel(HeatArgs a) {
 }
 
 // Fortran-ordered payloads (what loadmat returns): the payload is the C-ordered [J][W][H] image, out wants [H][W][J].
-// One workgroup moves TH rows h of one frame through LDS: reads run along h (TH consecutive elements of one (j, w)), writes along
-// (w, j) (a whole output row of W*J floats is contiguous).  Row stride W*J + 1 keeps both sides of the tile off the same banks.
-template <bool F64>
+// One workgroup moves WT columns w of one frame (all h, all j) through LDS: for every joint the WT * H elements of those columns are
+// ONE contiguous run of the payload (4 KB for 16 columns of 64 rows: whole cache lines, consecutive lanes on consecutive words); on
+// the way out every row h is one contiguous run of WT * J floats (960 B; the launcher takes WT = 8: 2 KB in, 480 B out).  LDS pitches
+// H + 1 per (j, w) run and WT * (H + 1) + 5 per joint keep both sides at two-way bank conflicts at most.  HC / WC / JC / WTC: the geometry as constants (0 = from the arguments;
+// the 64 x 64 x 15 maps of the path divide by constants only).
+constexpr int TR_PAD_J = 5;
+template <bool F64, int HC, int WC, int JC, int WTC>
 __global__ __launch_bounds__(256) void heat_transpose_kernel(HeatArgs a) {
     extern __shared__ float tile[];
-    const int f = blockIdx.y, h0 = blockIdx.x * a.TH, TH = a.TH, H = a.H, W = a.W, J = a.J;
-    const int rows = min(TH, H - h0), WJ = W * J, stride = WJ + 1;
+    const int H = HC ? HC : a.H, W = WC ? WC : a.W, J = JC ? JC : a.J, WT = WTC ? WTC : a.TH;
+    const int f = blockIdx.y, w0 = blockIdx.x * WT, wn = WTC ? WTC : min(WT, W - w0);
+    const int PH = H + 1, PJ = WT * PH + TR_PAD_J;
     const int64_t payload = a.offsets[f];
-    for (int r = threadIdx.x; r < WJ * TH; r += 256) {
-        const int hh = r % TH, jw = r / TH;             // jw = j * W + w: the payload's slow index
-        if (hh < rows) {
-            const int j = jw / W, w = jw - j * W;
-            tile[hh * stride + w * J + j] = element_at<F64>(a, payload, (int64_t)jw * H + h0 + hh);
-        }
+    const int run = wn * H;                           // elements of one joint's run
+#pragma unroll 4
+    for (int r = threadIdx.x; r < J * run; r += 256) {
+        const int j = r / run, rem = r - j * run, w = rem / H, h = rem - w * H;
+        tile[j * PJ + w * PH + h] = element_at<F64>(a, payload, ((int64_t)j * W + w0) * H + rem);
     }
     __syncthreads();
-    float* dst = a.out + ((int64_t)f * H + h0) * WJ;
-    for (int r = threadIdx.x; r < WJ * rows; r += 256) {
-        const int hh = r / WJ, c = r - hh * WJ;
-        dst[(int64_t)hh * WJ + c] = tile[hh * stride + c];
+    float* dst = a.out + ((int64_t)f * H * W + w0) * J;
+    const int orun = wn * J;                          // floats of one output row's run
+#pragma unroll 4
+    for (int r = threadIdx.x; r < H * orun; r += 256) {
+        const int h = r / orun, rem = r - h * orun, w = rem / J, j = rem - w * J;
+        dst[(int64_t)h * W * J + rem] = tile[j * PJ + w * PH + h];
     }
 }
 
@@ -474,20 +480,27 @@ int gem_heat_gather(const void* d_image, int64_t image_len, const int64_t* d_off
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int64_t per = (int64_t)heat_h * heat_w * n_joints;
     if (per > (1ll << 30)) { set_error("gem_heat_gather: heat-maps too large"); return 1; }
-    if (!fortran || heat_h == 1) {
+    if (!fortran) {
         const dim3 grid((unsigned)((per + 1023) / 1024), (unsigned)n);
         if (dtype == GEM_DT_F64) hipLaunchKernelGGL(heat_copy_kernel<true>, grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL(heat_copy_kernel<false>, grid, dim3(256), 0, s, a);
     } else {
-        const int64_t WJ = (int64_t)heat_w * n_joints;
-        int TH = 16;
-        while (TH > 1 && (TH > heat_h || (int64_t)TH * (WJ + 1) * 4 > 64 * 1024)) TH >>= 1;
-        if ((WJ + 1) * 4 * TH > 64 * 1024) { set_error("gem_heat_gather: a heat-map row of W*J floats does not fit the transposing tile"); return 1; }
-        a.TH = TH;
-        const dim3 grid((unsigned)((heat_h + TH - 1) / TH), (unsigned)n);
-        const size_t lds = (size_t)TH * (WJ + 1) * 4;
-        if (dtype == GEM_DT_F64) hipLaunchKernelGGL(heat_transpose_kernel<true>, grid, dim3(256), lds, s, a);
-        else hipLaunchKernelGGL(heat_transpose_kernel<false>, grid, dim3(256), lds, s, a);
+        // columns per workgroup: 8 (31 KB of LDS at 64 x 64 x 15: five workgroups per CU hide the loads' latency; 16 columns -- two
+        // workgroups per CU -- measured 0.71 against 0.34 ms for 2000 frames, 2.9 TB/s), fewer where the tile would not fit 64 KB
+        int WT = 8;
+        auto lds_of = [&](int wt) { return (size_t)n_joints * ((size_t)wt * (heat_h + 1) + TR_PAD_J) * 4; };
+        while (WT > 1 && (WT > heat_w || lds_of(WT) > 64 * 1024)) WT >>= 1;
+        if (lds_of(WT) > 64 * 1024) { set_error("gem_heat_gather: a heat-map column of H * J floats does not fit the transposing tile"); return 1; }
+        a.TH = WT;
+        const dim3 grid((unsigned)((heat_w + WT - 1) / WT), (unsigned)n);
+        const size_t lds = lds_of(WT);
+        if (heat_h == 64 && heat_w == 64 && n_joints == 15) {
+            if (dtype == GEM_DT_F64) hipLaunchKernelGGL((heat_transpose_kernel<true, 64, 64, 15, 8>), grid, dim3(256), lds, s, a);
+            else hipLaunchKernelGGL((heat_transpose_kernel<false, 64, 64, 15, 8>), grid, dim3(256), lds, s, a);
+        } else {
+            if (dtype == GEM_DT_F64) hipLaunchKernelGGL((heat_transpose_kernel<true, 0, 0, 0, 0>), grid, dim3(256), lds, s, a);
+            else hipLaunchKernelGGL((heat_transpose_kernel<false, 0, 0, 0, 0>), grid, dim3(256), lds, s, a);
+        }
     }
     GEM_HIP(hipGetLastError());
     return 0;

@@ -504,7 +504,8 @@ def optimize_sequences(data_dirs, camera_model_path, vae_weight=0.0, gmm_weight=
                 slot[0] = torch.empty((frames,) + hs, dtype=torch.float32, device=device)
             b.heat = slot[0][:frames]
             b.dests = [b.heat[lo:hi] for lo, hi in bounds]
-        native = [c["heat_offsets"] for c in b.chunks if "heat_offsets" in c]
+        # (where every heat-map's raw data lie in the ARENA of file images: the file's place in the arena + the array's place in the file)
+        native = [c["heat_offsets"] + (img.data_ptr() - slot[1].data_ptr()) for c, img in zip(b.chunks, b.images) if "heat_offsets" in c]
         b.offsets = slot[2].upload(np.concatenate(native), torch.int64) if native else None
         lap("small uploads")
         # the report's half that does not depend on the optimiser's result (equal chunks -- the reference's 100-frame chunks:
@@ -533,14 +534,28 @@ def optimize_sequences(data_dirs, camera_model_path, vae_weight=0.0, gmm_weight=
         lap("wait for the noise")
         cur = torch.cuda.current_stream()
         at, parts = 0, [None] * len(b.chunks)
-        for i, c in enumerate(b.chunks):
-            if "heat_offsets" not in c:
-                continue
+        native = [i for i, c in enumerate(b.chunks) if "heat_offsets" in c]
+        for i in native:
             ev, _ = b.reading[i].result()             # (the file's last copy has been issued: its event is recorded)
             cur.wait_event(ev)
-            parts[i] = b.dests[i] if b.dests[i] is not None else torch.empty((c["n"],) + tuple(c["heat_shape"]), dtype=torch.float32, device=device)
-            gather_heat(c, b.images[i], b.offsets[at:at + c["n"]], parts[i], cur)
-            at += c["n"]
+        kinds = {(b.chunks[i]["heat_dtype"], b.chunks[i]["heat_fortran"], tuple(b.chunks[i]["heat_shape"])) for i in native}
+        if b.heat is not None and len(native) == len(b.chunks) and len(kinds) == 1 and sum(c["n"] for c in b.chunks) <= 65535:
+            # every chunk's file image lies in ONE arena and their frames side by side in the batch's frame buffer: one launch picks all
+            # heat-maps out (b.offsets was built relative to the arena in prepare())
+            arena = slots[b.index % N_BUFFERS][1]
+            c0 = b.chunks[0]
+            whole = ParsedChunk(n=sum(c["n"] for c in b.chunks), heat_shape=c0["heat_shape"], heat_dtype=c0["heat_dtype"], heat_fortran=c0["heat_fortran"],
+                                file_bytes=arena.numel())
+            gather_heat(whole, arena, b.offsets, b.heat, cur)
+            for i in native:
+                parts[i] = b.dests[i]
+        else:
+            for i in native:
+                c = b.chunks[i]
+                parts[i] = b.dests[i] if b.dests[i] is not None else torch.empty((c["n"],) + tuple(c["heat_shape"]), dtype=torch.float32, device=device)
+                base = b.images[i].data_ptr() - slots[b.index % N_BUFFERS][1].data_ptr()
+                gather_heat(ParsedChunk(c, file_bytes=base + c["file_bytes"]), slots[b.index % N_BUFFERS][1], b.offsets[at:at + c["n"]], parts[i], cur)
+                at += c["n"]
         for i, f in b.listed:
             t, ev = f.result()
             cur.wait_event(ev)

@@ -283,6 +283,34 @@ def test_equal_chunks_take_the_vectorised_report_path_and_the_batch_pipeline(gol
     assert np.array_equal(np.asarray(runs[0][3]), np.asarray(runs[3][3]))
 
 
+@pytest.mark.parametrize("H,W,J", [(64, 64, 15), (48, 40, 13), (7, 5, 3), (1, 9, 2), (130, 3, 16)])
+def test_heat_gather_kernels_against_numpy(H, W, J):
+    """gem_heat_gather by itself: n payloads at ODD byte offsets of an image in HBM, C and Fortran order, float32 and float64, the
+    path's 64 x 64 x 15 maps (compile-time geometry) and other shapes (run-time geometry, partial column tiles) -> [n,H,W,J] float32,
+    bit for bit what numpy's reshape(order) + astype(float32) give."""
+    import ctypes as C
+    import torch
+    from globalegomocap_amd import _capi
+    lib = _capi.load_library()
+    rng = np.random.default_rng(H * 1000 + W * 10 + J)
+    n = 7
+    for dt, np_dt in ((0, np.float32), (1, np.float64)):
+        for fortran in (0, 1):
+            arrays = [rng.standard_normal((H, W, J)).astype(np_dt) for _ in range(n)]
+            blob, offs = bytearray(b"\x7f" * 5), []
+            for k, a in enumerate(arrays):
+                offs.append(len(blob))
+                blob += a.tobytes(order="F" if fortran else "C") + b"\x01" * (1 + 2 * k)          # every alignment 0 .. 3 occurs
+            blob += b"\0" * 16
+            image = torch.frombuffer(bytearray(blob), dtype=torch.uint8).cuda()
+            offs_d = torch.as_tensor(offs, dtype=torch.int64, device="cuda")
+            out = torch.full((n, H, W, J), float("nan"), device="cuda")
+            _capi.check(lib.gem_heat_gather(C.c_void_p(image.data_ptr()), len(blob) - 16, C.c_void_p(offs_d.data_ptr()), n, H, W, J, dt, fortran,
+                                            C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)), lib)
+            expect = np.stack(arrays).astype(np.float32)
+            assert np.array_equal(out.cpu().numpy().view(np.uint32), expect.view(np.uint32)), (dt, fortran)
+
+
 def test_a_broken_chunk_in_a_later_batch_surfaces_and_leaves_the_pipeline_usable(golden, tmp_path):
     """Batches are in flight three deep (files arriving, on the device, being reported): a chunk without `camera_pose_list` in the
     THIRD batch must surface as the reference's KeyError (optimizer.py:322) after the earlier batches' device work has been

@@ -53,6 +53,35 @@ for si in range(3):
             pickle.dump(obj, f)
 size_mb = sum(os.path.getsize(os.path.join(dirs[0], d, "test_data.pkl")) for d in os.listdir(dirs[0])) / 1e6
 
+if os.environ.get("GEM_WS_BENCHCTX"):          # (experiment: what bench.py has done to the process before its host-inclusive leg)
+    from globalegomocap_amd.engine import WindowEngine, energy_weights
+    from globalegomocap_amd.sequence import window_starts
+    seqd = synth.make_sequence_device(2000, seed=1000, device=dev, camera=cam, cam_jitter=bench.CAM_JITTER)
+    eng = WindowEngine(shape, cam, max_windows=240)
+    eng.load_vae(0, sd_l); eng.load_vae(1, sd_g)
+    st_ = np.concatenate([c * 100 + window_starts(100) for c in range(20)]).astype(np.int32)
+    f0 = torch.as_tensor(st_, device=dev)
+    mb = eng.mean_bone_length(seqd["est_local"][:100]).reshape(1, 15).expand(240, 15).contiguous()
+    eps = torch.randn(240, 2, 2048)
+    el, eg = eps[:, 0].contiguous().to(dev), eps[:, 1].contiguous().to(dev)
+    wl, wg = energy_weights(1e-6, 1e-5, 1e-2, 0, 1e-2), energy_weights(1e-2, 1e-3, 1e-2, 0, 0)
+    mode = os.environ["GEM_WS_BENCHCTX"]
+    for i in range(60):
+        if "p" in mode:
+            eng.profile_enable(i < 2)
+        eng.optimize_windows(seqd["est_local"], seqd["cams"], seqd["heat"], f0, mb, el, eg, wl, wg)
+    torch.cuda.synchronize()
+    if "p" in mode:
+        eng.profile_enable(False); eng.profile_read(0); eng.profile_read(1); eng.profile_read(2)
+    if "m" in mode:
+        for m_ in ("bf16x3", "bf16", "f32"):
+            eng.set_precision(m_)
+            for i in range(10):
+                eng.optimize_windows(seqd["est_local"], seqd["cams"], seqd["heat"], f0, mb, el, eg, wl, wg)
+        torch.cuda.synchronize()
+    if "c" in mode:
+        eng.close(); del eng, seqd
+        torch.cuda.empty_cache()
 _burnt = [torch.cuda.Stream() for _ in range(int(os.environ.get("GEM_WS_BURN_STREAMS", 0)))]      # (experiment: other users of torch's stream pool before us)
 opt = SequenceOptimizer(DEFAULT_CALIBRATION, sd_g, sd_l, max_windows=240)
 print("pickles: %.0f MB in 20 chunks per sequence, heat-maps %s-ordered %s" % (size_mb, order, hdt.__name__))
