@@ -101,8 +101,9 @@ int gem_set_lanes(gem_handle* h, int min_windows);
  *       (error ~2^-16 relative, i.e. fp32-grade, at ~1.5x the fp32 rate); the narrow tail layers stay fp32;
  *   2 = bf16 operands, fp32 accumulate (BASELINE configs[2..4] "bf16 VAE decoder / fp32 energy"): the wide products always; the
  *       narrow tail layers too, at every batch size (csrc/tail_bf16.hip: bf16 weights and bf16 activations between the layers;
- *       1..8 windows per workgroup, chosen from the batch size, every choice bitwise the same -- so a window's bf16 result does
- *       not depend on the size of the batch it arrives in).  It is the fp32 result plus zero-mean noise of the order of 2^-9 per decoded
+ *       1..8 windows per workgroup, chosen from the batch size, every choice bitwise the same (asserted by the tests; the library
+ *       is compiled with -ffp-contract=on so that no template instantiation fuses multiply-adds differently from another) -- so the
+ *       tail's part of a window's bf16 result does not depend on the size of the batch it arrives in.  It is the fp32 result plus zero-mean noise of the order of 2^-9 per decoded
  *       coordinate (tests/test_hip_full_size.py::test_bf16_on_fitted_vae_against_the_oracle: ~1.3 mm per window on fitted
  *       weights, 0.06 mm on a sequence's MPJPE).
  * May be switched at any time between calls. */
