@@ -33,7 +33,7 @@ def test_frame_span_is_contiguous_and_minimal():
 def test_block_cyclic_shards_cover_everything_once():
     for n in (0, 1, 15, 16, 17, 1563, 12499):
         for world in (1, 2, 8):
-            for block in (None, 1, 16):
+            for block in (None, 1, 8, 16):
                 idx = [shard_indices(n, r, world, block) for r in range(world)]
                 allidx = np.sort(np.concatenate(idx)) if n else np.zeros(0)
                 assert np.array_equal(allidx, np.arange(n))
@@ -47,7 +47,7 @@ def test_frame_runs_of_block_cyclic_shards():
     from globalegomocap_amd.dist import frame_runs
     n, T = 12499, 10
     starts = 8 * np.arange(n)
-    for world, block in ((1, 64), (2, 64), (8, 64), (8, 1), (3, 5)):
+    for world, block in ((1, 64), (2, 64), (8, 64), (8, 8), (8, 1), (3, 5)):
         held = 0
         for r in range(world):
             idx = shard_indices(n, r, world, block)
