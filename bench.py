@@ -733,15 +733,31 @@ def main():
                         "main_thread_timeline_ms": [[t_, name] for t_, name in (log or []) if not name.startswith("run:")]}, res
             import gc
             gc.collect()
-            rec, res = timed(lambda tm: ws_mod.optimize_directory(seq_dirs[0], DEFAULT_CALIBRATION, optimizer=opt, verbose=False, timings=tm), B, 7)
+            single = lambda tm: ws_mod.optimize_directory(seq_dirs[0], DEFAULT_CALIBRATION, optimizer=opt, verbose=False, timings=tm)      # noqa: E731
+            rec, res = timed(single, B, 7)
+            rec3, res3 = timed(lambda tm: ws_mod.optimize_sequences(seq_dirs, DEFAULT_CALIBRATION, optimizer=opt, verbose=False, per_sequence=True, timings=tm), 3 * B, 7)
+            # (the single sequence once more behind the pipelined leg: the files were written seconds ago, and a box whose page cache was
+            # still being written back read the first leg's files at 14.6 instead of 9.2 ms; best of both legs = best of 14 calls)
+            rec_b, res_b = timed(single, B, 7)
+            rec["ms_end_to_end_first_leg"], rec_b["ms_end_to_end_first_leg"] = rec["ms_end_to_end"], rec["ms_end_to_end"]
+            if rec_b["ms_end_to_end"] < rec["ms_end_to_end"]:
+                rec, res = rec_b, res_b
             rec["optimized_global_mpjpe_mm"] = round(float(res[0]["optimized_global_mpjpe"]) * 1e3, 3)
             host_inclusive["pickles_only"] = rec
-            rec, res = timed(lambda tm: ws_mod.optimize_sequences(seq_dirs, DEFAULT_CALIBRATION, optimizer=opt, verbose=False, per_sequence=True, timings=tm), 3 * B, 7)
-            rec["optimized_global_mpjpe_mm"] = [round(float(r[0]["optimized_global_mpjpe"]) * 1e3, 3) for r in res]
-            rec["floor_windows_per_s"] = round(3 * B / (3 * host_inclusive["pcie_floor_ms"] * 1e-3 + elapsed / a.steps), 1)
-            host_inclusive["three_sequences_pipelined"] = rec
+            rec3["optimized_global_mpjpe_mm"] = [round(float(r[0]["optimized_global_mpjpe"]) * 1e3, 3) for r in res3]
+            rec3["floor_windows_per_s"] = round(3 * B / (3 * host_inclusive["pcie_floor_ms"] * 1e-3 + elapsed / a.steps), 1)
+            host_inclusive["three_sequences_pipelined"] = rec3
+            near = ws_mod.cpus_near(device)
+            try:
+                p_ = torch.cuda.get_device_properties(device)
+                gpu_node = int(open("/sys/bus/pci/devices/%04x:%02x:%02x.0/numa_node" % (p_.pci_domain_id, p_.pci_bus_id, p_.pci_device_id)).read())
+            except (OSError, ValueError, AttributeError):
+                gpu_node = None
+            host_inclusive["placement"] = {"gpu_numa_node": gpu_node, "readers_confined_to_cpus": len(near) if near else None,
+                                           "main_thread_cpu": os.sched_getcpu() if hasattr(os, "sched_getcpu") else None,
+                                           "process_cpus": len(os.sched_getaffinity(0))}
             host_inclusive["what"] = ("whole_sequence.optimize_directory (the reference's optimize_whole_sequence.py:48-118) on 20 chunk directories, page-cached "
-                                      "files, best of 7 calls: read + host-to-device + optimise + device merge / report, nothing cached next to the data; "
+                                      "files, best of 7 calls (the single sequence: of 14, in two legs): read + host-to-device + optimise + device merge / report, nothing cached next to the data; "
                                       "three_sequences_pipelined = optimize_sequences(per_sequence=True) on three such directories (720 windows): one device call "
                                       "per sequence, the next sequence's files cross PCIe meanwhile; floor = 3 x pcie_floor_ms + one resident step, nothing else")
             opt.engine.close()
