@@ -317,6 +317,7 @@ class ChunkStream:
 
 def _drain(futures):
     """Cancel what has not started, wait for what has (its buffers are about to be reused or released)."""
+    futures[:] = [f for f in futures if not f.done()]          # (the normal way out: everything has long finished)
     for f in futures:
         f.cancel()
     for f in futures:
@@ -434,7 +435,7 @@ def optimize_sequences(data_dirs, camera_model_path, vae_weight=0.0, gmm_weight=
     batches = [_Batch(i, l) for i, l in enumerate(lists)]
     n_groups = len(data_dirs)
     opt = [optimizer]
-    results, est_all, opt_all, gt_all = ([[] for _ in range(n_groups)] for _ in range(4))
+    results, est_all, opt_all, gt_all, raw_rows = ([[] for _ in range(n_groups)] for _ in range(5))
     device = torch.device("cuda", torch.cuda.current_device())
     parse_pool, read_pool, noise_pool = _pool("parse", 8), _pool("read", 8, cpus_near(device)), _pool("noise", 1)
     slots = _heat_pool.setdefault(device, [[None, None, _Scratch(device)] for _ in range(N_BUFFERS)])
@@ -617,6 +618,7 @@ def optimize_sequences(data_dirs, camera_model_path, vae_weight=0.0, gmm_weight=
                 res["joints_error"] = reps[k, 17:].copy()
                 gi = group_of[c["path"]]
                 results[gi].append(res)
+                raw_rows[gi].append(reps[k])
                 est_all[gi].append(r["est_m"][k]); opt_all[gi].append(opt_m[k]); gt_all[gi].append(r["gt_m"][k])
                 if verbose and res["bone_length_aligned_optimized_mpjpe"] > res["bone_length_aligned_mid_optimized_mpjpe"]:
                     print(res)
@@ -670,9 +672,14 @@ def optimize_sequences(data_dirs, camera_model_path, vae_weight=0.0, gmm_weight=
     out = []
     for gi in range(n_groups):
         summary = OrderedDict()
-        for k in results[gi][0]:
-            summary[k] = (np.mean([r[k] for r in results[gi]], axis=0) if k == "joints_error"
-                          else float(np.average([r[k] for r in results[gi]])))
+        if len(raw_rows[gi]) == len(results[gi]):          # (every chunk of the sequence came as a row of the device report: one mean)
+            mean = np.mean(np.stack(raw_rows[gi]), axis=0)
+            for i, k in enumerate(results[gi][0]):
+                summary[k] = mean[17:].copy() if k == "joints_error" else float(mean[i])
+        else:
+            for k in results[gi][0]:
+                summary[k] = (np.mean([r[k] for r in results[gi]], axis=0) if k == "joints_error"
+                              else float(np.average([r[k] for r in results[gi]])))
         if verbose:
             if n_groups > 1:
                 print("sequence: {}".format(data_dirs[gi]))
