@@ -35,7 +35,7 @@ struct Node {
     std::vector<int32_t> items;    // K_TUPLE / K_LIST: elements; K_DICT: key, value, key, value ...
 };
 
-constexpr size_t MAX_NODES = 1u << 24, MAX_MEMO = 1u << 24;
+constexpr size_t MAX_NODES = 1u << 23, MAX_MEMO = 1u << 23;          // (a chunk of 100 frames makes ~5 k objects)
 
 struct Scanner {
     const uint8_t* p;
@@ -352,6 +352,7 @@ struct HeatArgs {
 // the 32-bit word that starts at BYTE address `at` of the image, whatever `at`'s alignment (words past the end read as 0)
 __device__ __forceinline__ uint32_t word_at(const HeatArgs& a, int64_t at) {
     const int64_t k = at >> 2;
+    if (k < 0) return 0u;                                    // (an offset in front of the image: the caller's table is wrong, nothing is read)
     const uint32_t lo = 4 * k + 4 <= a.image_len ? a.image[k] : 0u;
     const int m = (int)(at & 3);
     if (m == 0) return lo;
