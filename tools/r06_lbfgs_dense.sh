@@ -1,4 +1,5 @@
 #!/bin/bash
+# (the kernel variants this script switched between -- GEM_LBFGS_DENSE -- were NOT kept: see profiles/lbfgs_dense_experiment_r06.txt; the script stays as the record of the command)
 # round 6: lbfgs_advance with the bf16 ring packed in registers, product form (103 VGPRs, four workgroups per CU) against the form held to
 # 80 VGPRs (six per CU: 1536 windows resident at once), bf16, 1536 / 1563-like / 8192 windows
 for rep in 1 2; do for wl in 128 w8192x; do for dense in 0 1; do
