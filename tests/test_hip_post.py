@@ -188,7 +188,7 @@ def test_whole_sequence_driver_matches_per_chunk_main(golden, tmp_path, capsys):
         d.mkdir()
         data = synth.make_sequence(n_frames=n, seed=40 + i)
         with open(d / "test_data.pkl", "wb") as f:
-            pickle.dump({k: data[k] for k in ("estimated_local_skeleton", "gt_global_skeleton", "camera_pose_list", "heatmap_list")}, f)
+            pickle.dump(synth.reference_pickle_dict(data), f)          # as the reference's tool writes it
     kw = dict(global_vae_path=sd_g, local_vae_path=sd_l)
     torch.manual_seed(77)
     per_chunk = [gopt.main(p, DEFAULT_CALIBRATION, 0.0, 0.0, 0.001, 0.01, 0.01, 0.01, final_smooth=True, **kw)
@@ -230,7 +230,7 @@ def test_several_sequences_in_one_batch_match_sequence_by_sequence_runs(golden, 
             d.mkdir()
             data = synth.make_sequence(n_frames=n, seed=100 * (ord(s[-1]) - ord("A")) + i)
             with open(d / "test_data.pkl", "wb") as f:
-                pickle.dump({k: data[k] for k in ("estimated_local_skeleton", "gt_global_skeleton", "camera_pose_list", "heatmap_list")}, f)
+                pickle.dump(synth.reference_pickle_dict(data), f)          # as the reference's tool writes it
     torch.manual_seed(5)
     one_by_one = [ws.optimize_directory(d, DEFAULT_CALIBRATION, **kw) for d in dirs]
     torch.manual_seed(5)
